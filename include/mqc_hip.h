@@ -1,0 +1,195 @@
+/*
+ * mqc_hip.h -- C ABI of libmqc_hip.so, the MI355X (gfx950) SCF engine that drops in
+ * behind metalquicha's qc_method_t where the cuEST backend sits today.
+ *
+ * Boundary being replaced (all paths relative to the reference tree):
+ *   run_cuest_scf(settings, fragment, result, want_gradient)
+ *       backends/cuest/backend/mqc_cuest_bridge.f90:32-39  (module-level Fortran ABI)
+ *       backends/cuest/backend/mqc_cuest_driver.f90:37-276 (what it does)
+ *   cuest_backend_available()
+ *       backends/cuest/backend/mqc_cuest_bridge.f90:20-30
+ *   get_cuest_context / context_create / context_destroy
+ *       backends/cuest/backend/mqc_cuest_context.f90:166-306
+ * The Fortran shim that binds these (fortran/mqc_hip_bridge.f90, shown in
+ * INTEGRATION.md) keeps basis-file parsing and error_t on the Fortran side and hands
+ * the engine plain arrays: nothing but pointers, sizes and PODs crosses this header.
+ *
+ * Conventions
+ *   - all floating point is IEEE double; geometry in Bohr, energies in Hartree
+ *   - every entry point returns an int status: 0 = ok, never aborts or throws;
+ *     mqc_hip_last_error() gives the message for the calling thread's last failure
+ *     (the shim turns it into result%error%set(...), mqc_cuest_driver.f90:385-393)
+ *   - the caller owns every host array for the duration of the call; the engine owns
+ *     all device memory (grow-only pools, released by mqc_hip_finalize), like
+ *     device_pool_t in mqc_cuest_context.f90:40-53,142-156
+ *   - one calling thread per process (the context is a process-wide singleton,
+ *     mqc_cuest_context.f90:134-138); no re-entrancy
+ *   - the engine FAILS (MQC_HIP_ERR_NO_DEVICE) when no HIP device is present: there is
+ *     no CPU fallback behind this ABI.
+ */
+#ifndef MQC_HIP_H
+#define MQC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MQC_HIP_ABI_VERSION 1
+
+/* status codes (0 = ok).  VALIDATION mirrors ERROR_VALIDATION, GENERIC mirrors ERROR_GENERIC
+ * (src/utils/mqc_error.f90:22-44). */
+enum {
+    MQC_HIP_OK = 0,
+    MQC_HIP_ERR_VALIDATION = 1,
+    MQC_HIP_ERR_GENERIC = 2,
+    MQC_HIP_ERR_NO_DEVICE = 3,
+    MQC_HIP_ERR_UNSUPPORTED = 4,
+    MQC_HIP_ERR_DEVICE = 5
+};
+
+/* scf_status values, same meaning as the reference's tri-state
+ * (backends/cuest/backend/mqc_cuest_driver.f90:219-224). */
+enum { MQC_HIP_SCF_NOT_RUN = 0, MQC_HIP_SCF_CONVERGED = 1, MQC_HIP_SCF_NOT_CONVERGED = 2 };
+
+/* initial guess (cuest_scf_settings_t%guess, src/methods/mqc_cuest_iface.f90:104-121).
+ * AUTO resolves to GWH, as the cuEST backend does. */
+enum { MQC_HIP_GUESS_AUTO = 0, MQC_HIP_GUESS_CORE = 1, MQC_HIP_GUESS_GWH = 2 };
+
+/* two-electron path.  AUTO = in-core packed ERIs in HBM when they fit the per-fragment
+ * budget, else the direct build (the reference's choice at mqc_libcint_bridge.f90:819-892,
+ * with the 2 GB host limit replaced by an HBM budget). */
+enum { MQC_HIP_ERI_AUTO = 0, MQC_HIP_ERI_INCORE = 1, MQC_HIP_ERI_DIRECT = 2 };
+
+typedef struct mqc_hip_context mqc_hip_context;   /* opaque, process-wide singleton */
+
+/* physical_fragment_t flattened (src/fragmentation/common/mqc_physical_fragment.f90:45-94) */
+typedef struct {
+    int32_t n_atoms;
+    const int32_t *atomic_numbers;   /* [n_atoms] */
+    const double *xyz;               /* [3*n_atoms], atom-major, Bohr */
+    const uint8_t *ghost;            /* [n_atoms] or NULL; ghost = basis functions, Z = 0 */
+    int32_t charge;
+    int32_t multiplicity;
+    int32_t nelec;                   /* excludes ghosts */
+} mqc_hip_molecule_t;
+
+/* molecular_basis_type flattened (src/basis/mqc_cgto.f90); RAW Basis-Set-Exchange
+ * coefficients of unnormalised primitives -- the engine normalises exactly as
+ * backends/libcint/mqc_libcint_integrals.F90:519-555 does. */
+typedef struct {
+    int32_t spherical;               /* must be 1: Cartesian sets are refused
+                                        (mqc_cuest_driver.f90:331-341) */
+    int32_t n_atoms;
+    const int64_t *nshell_per_atom;  /* [n_atoms] */
+    int32_t n_shells;                /* = sum nshell_per_atom */
+    const int32_t *shell_l;          /* [n_shells] */
+    const int32_t *shell_nprim;      /* [n_shells] */
+    const double *exponents;         /* [sum nprim] */
+    const double *coefficients;      /* [sum nprim] */
+} mqc_hip_basis_t;
+
+/* the subset of cuest_scf_settings_t the engine acts on (mqc_cuest_iface.f90:35-142) */
+typedef struct {
+    char functional[32];             /* "" = Hartree-Fock */
+    int32_t density_fitting;
+    int32_t grid_level;              /* 1..5, default 3 */
+    int32_t radial_points;           /* 0 = from grid_level */
+    int32_t angular_points;          /* 0 = from grid_level */
+    int32_t max_iter;                /* default 100 */
+    double energy_tol;               /* default 1e-8 */
+    double density_tol;              /* default 1e-6 */
+    int32_t use_diis;
+    int32_t diis_size;               /* default 8 */
+    int32_t guess;                   /* MQC_HIP_GUESS_* */
+    int32_t unrestricted;            /* refused for now (MQC_HIP_ERR_UNSUPPORTED) */
+    int32_t want_gradient;           /* refused for now */
+    int32_t allow_crap_scf;
+    int32_t verbose;
+    int32_t eri_mode;                /* MQC_HIP_ERI_* */
+    double schwarz_tol;              /* 0 = default 1e-11 (mqc_libcint_direct.f90:61) */
+} mqc_hip_scf_options_t;
+
+/* what run_cuest_scf writes into calculation_result_t (mqc_cuest_driver.f90:211-275) */
+typedef struct {
+    double e_total;                  /* energy%scf */
+    double e_electronic;
+    double e_nuclear;
+    double e_xc;
+    int32_t scf_status;              /* MQC_HIP_SCF_* */
+    int32_t iterations;
+    int32_t n_ao;
+    int32_t n_mo;
+    int32_t n_occ;
+    double homo;                     /* orbital energies, Hartree */
+    double lumo;
+    int32_t has_orbitals;
+    double *orbital_energies;        /* optional out [n_mo capacity >= n_ao] or NULL */
+    double *density;                 /* optional out [n_ao*n_ao] row-major or NULL */
+    int32_t has_error;
+    char message[256];
+} mqc_hip_scf_result_t;
+
+/* ---- lifecycle -------------------------------------------------------------------- */
+/* cuest_backend_available(): 1 if a HIP device is visible, else 0 */
+int mqc_hip_backend_available(void);
+/* get_cuest_context(): lazy singleton; device = local_rank mod device_count
+ * (mqc_cuest_context.f90:188) */
+int mqc_hip_context_get(int32_t local_rank, mqc_hip_context **ctx);
+int mqc_hip_finalize(void);
+const char *mqc_hip_last_error(void);
+int mqc_hip_abi_version(void);
+void mqc_hip_default_options(mqc_hip_scf_options_t *opts);
+
+/* ---- the hot path ----------------------------------------------------------------- */
+/* run_cuest_scf for ONE fragment */
+int mqc_hip_scf_run(mqc_hip_context *ctx, const mqc_hip_molecule_t *mol,
+                    const mqc_hip_basis_t *orbital, const mqc_hip_basis_t *aux /* NULL unless DF */,
+                    const mqc_hip_scf_options_t *opts, mqc_hip_scf_result_t *result);
+
+/* The same for MANY fragments at once (batch-submit API).
+ * Fragments are independent (do_fragment_work has no cross-fragment state,
+ * src/fragmentation/mbe/mqc_mbe_mpi_fragment_distribution_scheme.F90:156-238); the engine
+ * groups them by topology and advances whole groups through each SCF stage in single
+ * launches.  Per-fragment failures are reported in results[i] and do not fail the call. */
+int mqc_hip_scf_run_batch(mqc_hip_context *ctx, int64_t n_fragments,
+                          const mqc_hip_molecule_t *mols, const mqc_hip_basis_t *orbitals,
+                          const mqc_hip_basis_t *auxes /* NULL unless DF */,
+                          const mqc_hip_scf_options_t *opts, mqc_hip_scf_result_t *results);
+
+/* ---- stage-level entry points (same kernels, used by the parity tests) ------------- */
+/* S, T, V (n_ao x n_ao, row-major):  compute_overlap/kinetic/potential,
+ * mqc_cuest_integrals.f90:1525-1634 <-> one_electron, mqc_libcint_integrals.F90:843-911 */
+int mqc_hip_int1e(mqc_hip_context *ctx, const mqc_hip_molecule_t *mol, const mqc_hip_basis_t *orbital,
+                  double *S, double *T, double *V);
+/* packed in-core ERI matrix M[pair(i,j)][pair(k,l)], pair(i,j) = i(i+1)/2 + j, i >= j
+ * (molecule_eris, mqc_libcint_integrals.F90:1449) */
+int mqc_hip_eri_packed(mqc_hip_context *ctx, const mqc_hip_molecule_t *mol, const mqc_hip_basis_t *orbital,
+                       double schwarz_tol, double *M /* [npair*npair] */);
+/* J[D], K[D] from the in-core tensor (build_fock, mqc_libcint_rhf.f90:1491-1574) */
+int mqc_hip_jk_incore(mqc_hip_context *ctx, const mqc_hip_molecule_t *mol, const mqc_hip_basis_t *orbital,
+                      const double *D, double *J, double *K);
+/* symmetric eigen-decomposition by the engine's LDS Jacobi kernel: A (n x n) -> w ascending,
+ * V columns = eigenvectors, row-major (diagonalize_fock_device, mqc_cuest_scf.f90:1132-1221) */
+int mqc_hip_syev(mqc_hip_context *ctx, int32_t n, const double *A, double *w, double *V);
+/* DIIS coefficients from an age-ordered overlap matrix, the device routine's algorithm
+ * (diis_coefficients/solve_diis, src/methods/mqc_diis.f90:164-273) */
+int mqc_hip_diis_coefficients(mqc_hip_context *ctx, int32_t n_stored, const double *overlap /* [n*n] */,
+                              double *coefficients /* [n_stored] */, int32_t *ok);
+
+/* ---- introspection ----------------------------------------------------------------- */
+typedef struct {
+    double t_setup, t_int1e, t_eri, t_fock, t_scf_step, t_total;   /* seconds, last batch call */
+    int64_t fock_launches, eri_quartets, scf_iterations_total;
+    double fock_kernel_seconds;   /* HIP-event time of the in-core J/K kernel, last batch */
+    double fock_bytes;            /* algorithmic bytes it streamed */
+    double eri_kernel_seconds;
+} mqc_hip_stats_t;
+int mqc_hip_get_stats(mqc_hip_context *ctx, mqc_hip_stats_t *stats);
+int mqc_hip_device_name(mqc_hip_context *ctx, char *buf, int32_t len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MQC_HIP_H */

@@ -1,0 +1,534 @@
+// engine.cpp -- context, batch driver and the extern "C" entry points of libmqc_hip.so.
+//
+// Host control flow of one batch (the device-resident SCF loop of
+// backends/cuest/backend/mqc_cuest_scf.f90:281-611, re-cut for whole batches):
+//   upload geometry -> int1e -> orthogonaliser -> ERI tensor -> guess ->
+//   repeat { J/K stream ; scf_step ; read ONE int (fragments still running) } -> fetch results
+// Only that one integer crosses the bus per iteration.
+#include "engine.hpp"
+#include "md_integrals.hpp"
+#include <algorithm>
+#include <array>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace mqc {
+const std::string& last_error_string();
+
+static double now_s()
+{
+    using namespace std::chrono;
+    return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+
+struct TopoDevHolder {
+    TopologyDev dev;
+};
+
+static int upload_topology(mqc_hip_context* ctx, const Topology& topo, TopologyDev& td)
+{
+    const int ns = (int)topo.shells.size();
+    std::vector<int> l(ns), np(ns), po(ns), at(ns), ao(ns);
+    for (int s = 0; s < ns; ++s) {
+        l[s] = topo.shells[s].l; np[s] = topo.shells[s].nprim; po[s] = topo.shells[s].poff;
+        at[s] = topo.shells[s].atom; ao[s] = topo.shells[s].aoff;
+    }
+    const size_t ib = sizeof(int) * (size_t)ns;
+    const size_t nprim = topo.exps.size();
+    const size_t bytes = 5 * ((ib + 255) & ~size_t(255)) + 3 * ((sizeof(double) * (nprim + topo.natoms) + 255) & ~size_t(255)) + 1024;
+    char* base = (char*)ctx->pool_topo.ensure(bytes);
+    if (!base) return fail(MQC_HIP_ERR_DEVICE, "out of device memory (topology)");
+    auto take = [&base](size_t b) { char* p = base; base += (b + 255) & ~size_t(255); return p; };
+    td.sh_l = (int*)take(ib); td.sh_nprim = (int*)take(ib); td.sh_poff = (int*)take(ib);
+    td.sh_atom = (int*)take(ib); td.sh_aoff = (int*)take(ib);
+    td.exps = (double*)take(sizeof(double) * nprim); td.coefs = (double*)take(sizeof(double) * nprim);
+    td.zeff = (double*)take(sizeof(double) * topo.natoms);
+    td.nshell = ns; td.nao = topo.nao; td.npair = topo.npair; td.natoms = topo.natoms;
+    hipStream_t s = ctx->stream;
+    HIP_CHECK_RET(hipMemcpyAsync(td.sh_l, l.data(), ib, hipMemcpyHostToDevice, s));
+    HIP_CHECK_RET(hipMemcpyAsync(td.sh_nprim, np.data(), ib, hipMemcpyHostToDevice, s));
+    HIP_CHECK_RET(hipMemcpyAsync(td.sh_poff, po.data(), ib, hipMemcpyHostToDevice, s));
+    HIP_CHECK_RET(hipMemcpyAsync(td.sh_atom, at.data(), ib, hipMemcpyHostToDevice, s));
+    HIP_CHECK_RET(hipMemcpyAsync(td.sh_aoff, ao.data(), ib, hipMemcpyHostToDevice, s));
+    HIP_CHECK_RET(hipMemcpyAsync(td.exps, topo.exps.data(), sizeof(double) * nprim, hipMemcpyHostToDevice, s));
+    HIP_CHECK_RET(hipMemcpyAsync(td.coefs, topo.coefs.data(), sizeof(double) * nprim, hipMemcpyHostToDevice, s));
+    HIP_CHECK_RET(hipMemcpyAsync(td.zeff, topo.zeff.data(), sizeof(double) * topo.natoms, hipMemcpyHostToDevice, s));
+    HIP_CHECK_RET(hipStreamSynchronize(s));   // the host vectors go out of scope
+    return MQC_HIP_OK;
+}
+
+static size_t per_fragment_main_doubles(int n, int natoms)
+{
+    const size_t nn = (size_t)n * n;
+    return 8 * nn      // S H X F D C J K
+           + 6 * nn    // W
+           + 2 * DIIS_MAX * nn   // DIIS histories
+           + DIIS_MAX * DIIS_MAX + n + 8 + 3 * (size_t)natoms + 8;   // diis_b, eps, scal, xyz, ints (padded)
+}
+
+// carve one chunk's arrays out of the pools
+static int carve_batch(mqc_hip_context* ctx, const Topology& topo, const TopologyDev& td, int nfrag, bool with_eri, BatchView& bv)
+{
+    const int n = topo.nao;
+    const size_t nn = (size_t)n * n, nf = (size_t)nfrag;
+    const size_t main_bytes = sizeof(double) * nf * per_fragment_main_doubles(n, topo.natoms) + 4096;
+    char* base = (char*)ctx->pool_main.ensure(main_bytes);
+    if (!base) return fail(MQC_HIP_ERR_DEVICE, "out of device memory (SCF matrices)");
+    auto take = [&base](size_t b) { char* p = base; base += (b + 255) & ~size_t(255); return p; };
+    bv.topo = td; bv.nfrag = nfrag; bv.n = n; bv.npair = topo.npair;
+    bv.boys = ctx->d_boys; bv.c2s = ctx->d_c2s;
+    bv.xyz = (double*)take(sizeof(double) * nf * topo.natoms * 3);
+    bv.S = (double*)take(sizeof(double) * nf * nn); bv.H = (double*)take(sizeof(double) * nf * nn);
+    bv.X = (double*)take(sizeof(double) * nf * nn); bv.F = (double*)take(sizeof(double) * nf * nn);
+    bv.D = (double*)take(sizeof(double) * nf * nn); bv.C = (double*)take(sizeof(double) * nf * nn);
+    bv.J = (double*)take(sizeof(double) * nf * nn); bv.K = (double*)take(sizeof(double) * nf * nn);
+    bv.W = (double*)take(sizeof(double) * nf * 6 * nn);
+    bv.diis_f = (double*)take(sizeof(double) * nf * DIIS_MAX * nn);
+    bv.diis_e = (double*)take(sizeof(double) * nf * DIIS_MAX * nn);
+    bv.diis_b = (double*)take(sizeof(double) * nf * DIIS_MAX * DIIS_MAX);
+    bv.eps = (double*)take(sizeof(double) * nf * n);
+    bv.scal = (double*)take(sizeof(double) * nf * 8);
+    bv.diis_state = (int*)take(sizeof(int) * nf * 2);
+    bv.istate = (int*)take(sizeof(int) * nf * 4);
+    bv.counters = (int*)ctx->pool_misc.ensure(256);
+    if (!bv.counters) return fail(MQC_HIP_ERR_DEVICE, "out of device memory (counters)");
+    bv.eri = nullptr;
+    if (with_eri) {
+        const size_t np = (size_t)topo.npair;
+        bv.eri = (double*)ctx->pool_eri.ensure(sizeof(double) * nf * np * np);
+        if (!bv.eri) return fail(MQC_HIP_ERR_DEVICE, "out of device memory (ERI tensor)");
+    }
+    return MQC_HIP_OK;
+}
+
+static bool incore_supported(int n)
+{
+    // the J/K kernel stages whole packed rows through LDS: 3 row-sized buffers must fit 160 KB
+    const size_t np = (size_t)n * (n + 1) / 2;
+    return n <= 256 && (sizeof(double) * 3 * np <= 160 * 1024 - 512);
+}
+
+static int validate_options(const mqc_hip_scf_options_t& o, const Topology& topo, std::string& msg)
+{
+    if (o.functional[0] != '\0') { msg = "Kohn-Sham functionals are not available in this build of the HIP backend (Hartree-Fock only)"; return MQC_HIP_ERR_UNSUPPORTED; }
+    if (o.density_fitting) { msg = "density fitting is not available in this build of the HIP backend"; return MQC_HIP_ERR_UNSUPPORTED; }
+    if (o.want_gradient) { msg = "analytic gradients are not available in this build of the HIP backend"; return MQC_HIP_ERR_UNSUPPORTED; }
+    if (o.unrestricted || topo.multiplicity != 1 || (topo.nelec % 2) != 0) {
+        msg = "the HIP backend runs restricted closed-shell SCF only (multiplicity 1, even electron count)";
+        return MQC_HIP_ERR_UNSUPPORTED;
+    }
+    if (topo.nelec < 2) { msg = "RHF: no electrons to place"; return MQC_HIP_ERR_VALIDATION; }
+    if (o.max_iter < 1) { msg = "max_iter must be positive"; return MQC_HIP_ERR_VALIDATION; }
+    if (o.use_diis && (o.diis_size < 0 || o.diis_size > DIIS_MAX)) { msg = "diis_size must be within 0..8"; return MQC_HIP_ERR_VALIDATION; }
+    if (o.eri_mode == MQC_HIP_ERI_DIRECT) { msg = "the direct (integral-recomputing) Fock build is not available in this build; use in-core"; return MQC_HIP_ERR_UNSUPPORTED; }
+    if (!incore_supported(topo.nao)) { msg = "fragment too large for the in-core ERI path (n_ao <= 116) and no other path is built"; return MQC_HIP_ERR_UNSUPPORTED; }
+    return MQC_HIP_OK;
+}
+
+static void fill_error(mqc_hip_scf_result_t* r, const std::string& msg)
+{
+    r->has_error = 1;
+    std::snprintf(r->message, sizeof(r->message), "%s", msg.c_str());
+}
+
+int run_batch(mqc_hip_context* ctx, const Topology& topo, const std::vector<const double*>& xyz,
+              const mqc_hip_scf_options_t& opts, std::vector<mqc_hip_scf_result_t*>& results)
+{
+    const double t_begin = now_s();
+    const int ntot = (int)xyz.size();
+    std::string msg;
+    int rc = validate_options(opts, topo, msg);
+    if (rc != MQC_HIP_OK) {
+        for (auto* r : results) { fill_error(r, msg); r->scf_status = MQC_HIP_SCF_NOT_RUN; }
+        return fail(rc, msg);
+    }
+    hipStream_t s = ctx->stream;
+    TopologyDev td;
+    rc = upload_topology(ctx, topo, td);
+    if (rc != MQC_HIP_OK) return rc;
+
+    const int n = topo.nao;
+    const size_t np = (size_t)topo.npair;
+    const size_t per_frag = sizeof(double) * (per_fragment_main_doubles(n, topo.natoms) + np * np);
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    free_b += ctx->pool_main.capacity() + ctx->pool_eri.capacity();
+    size_t budget = (size_t)(0.80 * (double)free_b);
+    if (ctx->hbm_budget_bytes && ctx->hbm_budget_bytes < budget) budget = ctx->hbm_budget_bytes;
+    long chunk = (long)(budget / per_frag);
+    if (chunk < 1) return fail(MQC_HIP_ERR_DEVICE, "not enough device memory for one fragment");
+    if (chunk > ntot) chunk = ntot;
+    if (chunk > 60000) chunk = 60000;    // grid.y limit of the J/K kernel
+
+    const int nocc = topo.nelec / 2;
+    int* h_counter = nullptr;
+    HIP_CHECK_RET(hipHostMalloc((void**)&h_counter, 64));
+
+    for (int start = 0; start < ntot; start += (int)chunk) {
+        const int nf = std::min<long>(chunk, ntot - start);
+        const double t0 = now_s();
+        BatchView bv{};
+        rc = carve_batch(ctx, topo, td, nf, true, bv);
+        if (rc != MQC_HIP_OK) { (void)hipHostFree(h_counter); return rc; }
+        bv.nocc = nocc; bv.exx = 1.0; bv.e_tol = opts.energy_tol; bv.d_tol = opts.density_tol;
+        bv.max_iter = opts.max_iter; bv.diis_size = opts.use_diis ? opts.diis_size : 0;
+        std::vector<double> hx((size_t)nf * topo.natoms * 3);
+        for (int f = 0; f < nf; ++f) std::memcpy(&hx[(size_t)f * topo.natoms * 3], xyz[start + f], sizeof(double) * topo.natoms * 3);
+        HIP_CHECK_RET(hipMemcpyAsync(bv.xyz, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice, s));
+        HIP_CHECK_RET(hipMemsetAsync(bv.istate, 0, sizeof(int) * (size_t)nf * 4, s));
+        HIP_CHECK_RET(hipStreamSynchronize(s));
+        const double t1 = now_s();
+        ctx->stats.t_setup += t1 - t0;
+
+        launch_int1e(bv, topo, s);
+        launch_orthogonalizer(bv, s);
+        HIP_CHECK_RET(hipStreamSynchronize(s));
+        const double t2 = now_s();
+        ctx->stats.t_int1e += t2 - t1;
+
+        const double stol = opts.schwarz_tol > 0.0 ? opts.schwarz_tol : 0.0;
+        HIP_CHECK_RET(hipEventRecord(ctx->ev0, s));
+        launch_eri(bv, topo, stol, s);
+        HIP_CHECK_RET(hipEventRecord(ctx->ev1, s));
+        HIP_CHECK_RET(hipStreamSynchronize(s));
+        {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+            ctx->stats.eri_kernel_seconds += ms * 1e-3;
+        }
+        HIP_CHECK_RET(hipGetLastError());
+        const double t3 = now_s();
+        ctx->stats.t_eri += t3 - t2;
+        ctx->stats.eri_quartets += topo.n_quartets * nf;
+
+        // nmo check: more occupied orbitals than the basis supports after dropping near-null modes
+        launch_guess(bv, opts.guess == MQC_HIP_GUESS_CORE ? MQC_HIP_GUESS_CORE : MQC_HIP_GUESS_GWH, s);
+        HIP_CHECK_RET(hipStreamSynchronize(s));
+        HIP_CHECK_RET(hipGetLastError());
+
+        int remaining = nf;
+        int guard = 0;
+        while (remaining > 0 && guard < opts.max_iter + 2) {
+            HIP_CHECK_RET(hipEventRecord(ctx->ev0, s));
+            launch_jk_incore(bv, true, s);
+            HIP_CHECK_RET(hipEventRecord(ctx->ev1, s));
+            launch_scf_step(bv, s);
+            HIP_CHECK_RET(hipMemcpyAsync(h_counter, bv.counters, sizeof(int), hipMemcpyDeviceToHost, s));
+            HIP_CHECK_RET(hipStreamSynchronize(s));
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+            ctx->stats.fock_kernel_seconds += ms * 1e-3;
+            ctx->stats.fock_bytes += (double)remaining * (double)np * (double)np * 8.0;
+            ctx->stats.fock_launches += 1;
+            remaining = h_counter[0];
+            ++guard;
+        }
+        HIP_CHECK_RET(hipGetLastError());
+        const double t4 = now_s();
+        ctx->stats.t_fock += t4 - t3;
+
+        std::vector<double> scal((size_t)nf * 8), eps((size_t)nf * n);
+        std::vector<int> ist((size_t)nf * 4);
+        HIP_CHECK_RET(hipMemcpyAsync(scal.data(), bv.scal, sizeof(double) * scal.size(), hipMemcpyDeviceToHost, s));
+        HIP_CHECK_RET(hipMemcpyAsync(eps.data(), bv.eps, sizeof(double) * eps.size(), hipMemcpyDeviceToHost, s));
+        HIP_CHECK_RET(hipMemcpyAsync(ist.data(), bv.istate, sizeof(int) * ist.size(), hipMemcpyDeviceToHost, s));
+        HIP_CHECK_RET(hipStreamSynchronize(s));
+        for (int f = 0; f < nf; ++f) {
+            mqc_hip_scf_result_t* r = results[start + f];
+            const int nmo = ist[4 * f + 2];
+            r->n_ao = n; r->n_mo = nmo; r->n_occ = nocc;
+            if (nocc > nmo) {
+                fill_error(r, "RHF: more occupied orbitals than the basis supports after near-null modes were dropped");
+                r->scf_status = MQC_HIP_SCF_NOT_RUN;
+                continue;
+            }
+            r->e_nuclear = nuclear_repulsion(topo, xyz[start + f]);
+            r->e_electronic = scal[8 * f + 4];
+            r->e_total = r->e_electronic + r->e_nuclear;
+            r->e_xc = 0.0;
+            r->iterations = ist[4 * f + 1];
+            const bool conv = ist[4 * f + 3] != 0 && ist[4 * f] == ST_DONE;
+            r->scf_status = conv ? MQC_HIP_SCF_CONVERGED : MQC_HIP_SCF_NOT_CONVERGED;
+            r->homo = eps[(size_t)f * n + nocc - 1];
+            r->lumo = nocc < nmo ? eps[(size_t)f * n + nocc] : 0.0;
+            r->has_orbitals = 1;
+            if (r->orbital_energies) std::memcpy(r->orbital_energies, &eps[(size_t)f * n], sizeof(double) * nmo);
+            if (r->density) HIP_CHECK_RET(hipMemcpy(r->density, bv.D + (size_t)f * n * n, sizeof(double) * n * n, hipMemcpyDeviceToHost));
+            r->has_error = 0; r->message[0] = '\0';
+            if (!std::isfinite(r->e_total)) fill_error(r, "SCF produced a non-finite energy");
+            else if (!conv && !opts.allow_crap_scf)
+                fill_error(r, "SCF did not converge in " + std::to_string(r->iterations) + " iterations");
+            ctx->stats.scf_iterations_total += r->iterations;
+        }
+        ctx->stats.t_scf_step += now_s() - t4;
+    }
+    (void)hipHostFree(h_counter);
+    ctx->stats.t_total += now_s() - t_begin;
+    return MQC_HIP_OK;
+}
+
+}  // namespace mqc
+
+// =========================================================================================
+using namespace mqc;
+
+static mqc_hip_context* g_ctx = nullptr;
+
+extern "C" {
+
+int mqc_hip_abi_version(void) { return MQC_HIP_ABI_VERSION; }
+
+const char* mqc_hip_last_error(void) { return last_error_string().c_str(); }
+
+int mqc_hip_backend_available(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n > 0 ? 1 : 0;
+}
+
+void mqc_hip_default_options(mqc_hip_scf_options_t* o)
+{
+    std::memset(o, 0, sizeof(*o));
+    o->grid_level = 3;
+    o->max_iter = 100;            // src/methods/mqc_method_config.f90:24-29
+    o->energy_tol = 1.0e-8;
+    o->density_tol = 1.0e-6;
+    o->use_diis = 1;
+    o->diis_size = 8;
+    o->guess = MQC_HIP_GUESS_AUTO;
+    o->eri_mode = MQC_HIP_ERI_AUTO;
+    o->schwarz_tol = 0.0;
+}
+
+int mqc_hip_context_get(int32_t local_rank, mqc_hip_context** out)
+{
+    if (!out) return fail(MQC_HIP_ERR_VALIDATION, "null context pointer");
+    if (g_ctx) { *out = g_ctx; return MQC_HIP_OK; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(MQC_HIP_ERR_NO_DEVICE, "no HIP device is visible: the MI355X backend has no CPU fallback");
+    auto* ctx = new mqc_hip_context();
+    ctx->device = ((local_rank % ndev) + ndev) % ndev;    // mqc_cuest_context.f90:188
+    HIP_CHECK_RET(hipSetDevice(ctx->device));
+    HIP_CHECK_RET(hipGetDeviceProperties(&ctx->prop, ctx->device));
+    HIP_CHECK_RET(hipStreamCreate(&ctx->stream));
+    HIP_CHECK_RET(hipEventCreate(&ctx->ev0));
+    HIP_CHECK_RET(hipEventCreate(&ctx->ev1));
+    std::vector<double> boys;
+    build_boys_table(boys);
+    HIP_CHECK_RET(hipMalloc((void**)&ctx->d_boys, sizeof(double) * boys.size()));
+    HIP_CHECK_RET(hipMemcpy(ctx->d_boys, boys.data(), sizeof(double) * boys.size(), hipMemcpyHostToDevice));
+    build_c2s_tables(ctx->h_c2s, ctx->c2s_off);
+    HIP_CHECK_RET(hipMalloc((void**)&ctx->d_c2s, sizeof(double) * ctx->h_c2s.size()));
+    HIP_CHECK_RET(hipMemcpy(ctx->d_c2s, ctx->h_c2s.data(), sizeof(double) * ctx->h_c2s.size(), hipMemcpyHostToDevice));
+    const char* env = std::getenv("MQC_HIP_HBM_BUDGET_GB");
+    if (env) ctx->hbm_budget_bytes = (size_t)(std::atof(env) * 1024.0 * 1024.0 * 1024.0);
+    g_ctx = ctx;
+    *out = ctx;
+    return MQC_HIP_OK;
+}
+
+int mqc_hip_finalize(void)
+{
+    if (!g_ctx) return MQC_HIP_OK;
+    (void)hipSetDevice(g_ctx->device);
+    (void)hipStreamSynchronize(g_ctx->stream);
+    g_ctx->pool_main.release(); g_ctx->pool_eri.release(); g_ctx->pool_topo.release(); g_ctx->pool_misc.release();
+    if (g_ctx->d_boys) (void)hipFree(g_ctx->d_boys);
+    if (g_ctx->d_c2s) (void)hipFree(g_ctx->d_c2s);
+    (void)hipEventDestroy(g_ctx->ev0); (void)hipEventDestroy(g_ctx->ev1);
+    (void)hipStreamDestroy(g_ctx->stream);
+    delete g_ctx;
+    g_ctx = nullptr;
+    return MQC_HIP_OK;
+}
+
+int mqc_hip_device_name(mqc_hip_context* ctx, char* buf, int32_t len)
+{
+    if (!ctx || !buf || len <= 0) return fail(MQC_HIP_ERR_VALIDATION, "bad arguments");
+    std::snprintf(buf, (size_t)len, "%s (%s, %d CUs)", ctx->prop.name, ctx->prop.gcnArchName, ctx->prop.multiProcessorCount);
+    return MQC_HIP_OK;
+}
+
+int mqc_hip_get_stats(mqc_hip_context* ctx, mqc_hip_stats_t* st)
+{
+    if (!ctx || !st) return fail(MQC_HIP_ERR_VALIDATION, "bad arguments");
+    st->t_setup = ctx->stats.t_setup; st->t_int1e = ctx->stats.t_int1e; st->t_eri = ctx->stats.t_eri;
+    st->t_fock = ctx->stats.t_fock; st->t_scf_step = ctx->stats.t_scf_step; st->t_total = ctx->stats.t_total;
+    st->fock_launches = ctx->stats.fock_launches; st->eri_quartets = ctx->stats.eri_quartets;
+    st->scf_iterations_total = ctx->stats.scf_iterations_total;
+    st->fock_kernel_seconds = ctx->stats.fock_kernel_seconds; st->fock_bytes = ctx->stats.fock_bytes;
+    st->eri_kernel_seconds = ctx->stats.eri_kernel_seconds;
+    ctx->stats = Stats();
+    return MQC_HIP_OK;
+}
+
+static void init_result(mqc_hip_scf_result_t* r)
+{
+    double* oe = r->orbital_energies; double* dn = r->density;
+    std::memset(r, 0, sizeof(*r));
+    r->orbital_energies = oe; r->density = dn;
+    r->scf_status = MQC_HIP_SCF_NOT_RUN;
+}
+
+int mqc_hip_scf_run_batch(mqc_hip_context* ctx, int64_t nfrag, const mqc_hip_molecule_t* mols,
+                          const mqc_hip_basis_t* orbitals, const mqc_hip_basis_t* auxes,
+                          const mqc_hip_scf_options_t* opts, mqc_hip_scf_result_t* results)
+{
+    (void)auxes;
+    if (!ctx) return fail(MQC_HIP_ERR_VALIDATION, "null context (call mqc_hip_context_get first)");
+    if (nfrag < 0 || (nfrag > 0 && (!mols || !orbitals || !opts || !results)))
+        return fail(MQC_HIP_ERR_VALIDATION, "null argument");
+    HIP_CHECK_RET(hipSetDevice(ctx->device));
+    for (int64_t i = 0; i < nfrag; ++i) init_result(&results[i]);
+    // group by topology
+    std::map<std::string, std::vector<int64_t>> groups;
+    for (int64_t i = 0; i < nfrag; ++i) {
+        if (!mols[i].atomic_numbers || !mols[i].xyz || mols[i].n_atoms <= 0 || !orbitals[i].shell_l ||
+            !orbitals[i].nshell_per_atom || !orbitals[i].shell_nprim || !orbitals[i].exponents || !orbitals[i].coefficients) {
+            results[i].has_error = 1;
+            std::snprintf(results[i].message, sizeof(results[i].message), "fragment has no geometry or basis");
+            continue;
+        }
+        groups[topology_key(mols[i], orbitals[i])].push_back(i);
+    }
+    int worst = MQC_HIP_OK;
+    for (auto& kv : groups) {
+        const auto& idx = kv.second;
+        Topology topo;
+        std::string err;
+        int rc = build_topology(mols[idx[0]], orbitals[idx[0]], topo, err);
+        if (rc != MQC_HIP_OK) {
+            for (auto i : idx) { results[i].has_error = 1; std::snprintf(results[i].message, sizeof(results[i].message), "%s", err.c_str()); }
+            set_error(err);
+            worst = rc;
+            continue;
+        }
+        std::vector<const double*> xyz;
+        std::vector<mqc_hip_scf_result_t*> res;
+        for (auto i : idx) { xyz.push_back(mols[i].xyz); res.push_back(&results[i]); }
+        rc = run_batch(ctx, topo, xyz, *opts, res);
+        if (rc != MQC_HIP_OK) {
+            worst = rc;
+            for (auto* r : res)
+                if (!r->has_error) { r->has_error = 1; std::snprintf(r->message, sizeof(r->message), "%s", mqc_hip_last_error()); }
+        }
+    }
+    // single-fragment calls report the fragment's failure as the call's status, like run_cuest_scf
+    if (nfrag == 1 && worst != MQC_HIP_OK) return worst;
+    return (nfrag == 1) ? MQC_HIP_OK : worst;
+}
+
+int mqc_hip_scf_run(mqc_hip_context* ctx, const mqc_hip_molecule_t* mol, const mqc_hip_basis_t* orbital,
+                    const mqc_hip_basis_t* aux, const mqc_hip_scf_options_t* opts, mqc_hip_scf_result_t* result)
+{
+    return mqc_hip_scf_run_batch(ctx, 1, mol, orbital, aux, opts, result);
+}
+
+// ---- stage-level entry points -----------------------------------------------------------
+struct StageBatch {
+    Topology topo;
+    TopologyDev td;
+    BatchView bv{};
+};
+
+static int stage_setup(mqc_hip_context* ctx, const mqc_hip_molecule_t* mol, const mqc_hip_basis_t* bas, bool with_eri, StageBatch& sb)
+{
+    if (!ctx || !mol || !bas) return fail(MQC_HIP_ERR_VALIDATION, "null argument");
+    HIP_CHECK_RET(hipSetDevice(ctx->device));
+    std::string err;
+    int rc = build_topology(*mol, *bas, sb.topo, err);
+    if (rc != MQC_HIP_OK) return fail(rc, err);
+    if (with_eri && !incore_supported(sb.topo.nao)) return fail(MQC_HIP_ERR_UNSUPPORTED, "fragment too large for the in-core ERI path");
+    rc = upload_topology(ctx, sb.topo, sb.td);
+    if (rc != MQC_HIP_OK) return rc;
+    rc = carve_batch(ctx, sb.topo, sb.td, 1, with_eri, sb.bv);
+    if (rc != MQC_HIP_OK) return rc;
+    sb.bv.nocc = std::max(1, sb.topo.nelec / 2); sb.bv.exx = 1.0;
+    HIP_CHECK_RET(hipMemcpy(sb.bv.xyz, mol->xyz, sizeof(double) * 3 * mol->n_atoms, hipMemcpyHostToDevice));
+    HIP_CHECK_RET(hipMemset(sb.bv.istate, 0, sizeof(int) * 4));
+    return MQC_HIP_OK;
+}
+
+int mqc_hip_int1e(mqc_hip_context* ctx, const mqc_hip_molecule_t* mol, const mqc_hip_basis_t* bas, double* S, double* T, double* V)
+{
+    StageBatch sb;
+    int rc = stage_setup(ctx, mol, bas, false, sb);
+    if (rc != MQC_HIP_OK) return rc;
+    launch_int1e(sb.bv, sb.topo, ctx->stream);
+    HIP_CHECK_RET(hipStreamSynchronize(ctx->stream));
+    HIP_CHECK_RET(hipGetLastError());
+    const size_t nn = (size_t)sb.topo.nao * sb.topo.nao;
+    if (S) HIP_CHECK_RET(hipMemcpy(S, sb.bv.S, sizeof(double) * nn, hipMemcpyDeviceToHost));
+    if (T) HIP_CHECK_RET(hipMemcpy(T, sb.bv.W, sizeof(double) * nn, hipMemcpyDeviceToHost));
+    if (V) HIP_CHECK_RET(hipMemcpy(V, sb.bv.W + nn, sizeof(double) * nn, hipMemcpyDeviceToHost));
+    return MQC_HIP_OK;
+}
+
+int mqc_hip_eri_packed(mqc_hip_context* ctx, const mqc_hip_molecule_t* mol, const mqc_hip_basis_t* bas, double schwarz_tol, double* M)
+{
+    StageBatch sb;
+    int rc = stage_setup(ctx, mol, bas, true, sb);
+    if (rc != MQC_HIP_OK) return rc;
+    launch_eri(sb.bv, sb.topo, schwarz_tol, ctx->stream);
+    HIP_CHECK_RET(hipStreamSynchronize(ctx->stream));
+    HIP_CHECK_RET(hipGetLastError());
+    const size_t np = (size_t)sb.topo.npair;
+    HIP_CHECK_RET(hipMemcpy(M, sb.bv.eri, sizeof(double) * np * np, hipMemcpyDeviceToHost));
+    return MQC_HIP_OK;
+}
+
+int mqc_hip_jk_incore(mqc_hip_context* ctx, const mqc_hip_molecule_t* mol, const mqc_hip_basis_t* bas, const double* D, double* J, double* K)
+{
+    StageBatch sb;
+    int rc = stage_setup(ctx, mol, bas, true, sb);
+    if (rc != MQC_HIP_OK) return rc;
+    const size_t nn = (size_t)sb.topo.nao * sb.topo.nao;
+    launch_eri(sb.bv, sb.topo, 0.0, ctx->stream);
+    HIP_CHECK_RET(hipMemcpyAsync(sb.bv.D, D, sizeof(double) * nn, hipMemcpyHostToDevice, ctx->stream));
+    launch_jk_incore(sb.bv, false, ctx->stream);
+    HIP_CHECK_RET(hipStreamSynchronize(ctx->stream));
+    HIP_CHECK_RET(hipGetLastError());
+    HIP_CHECK_RET(hipMemcpy(J, sb.bv.J, sizeof(double) * nn, hipMemcpyDeviceToHost));
+    HIP_CHECK_RET(hipMemcpy(K, sb.bv.K, sizeof(double) * nn, hipMemcpyDeviceToHost));
+    return MQC_HIP_OK;
+}
+
+int mqc_hip_syev(mqc_hip_context* ctx, int32_t n, const double* A, double* w, double* V)
+{
+    if (!ctx || !A || !w || !V || n <= 0) return fail(MQC_HIP_ERR_VALIDATION, "bad arguments");
+    if (n > 140) return fail(MQC_HIP_ERR_UNSUPPORTED, "matrix too large for the LDS Jacobi solver (n <= 140)");
+    HIP_CHECK_RET(hipSetDevice(ctx->device));
+    const size_t nn = (size_t)n * n;
+    double* d = (double*)ctx->pool_main.ensure(sizeof(double) * (2 * nn + n) + 1024);
+    if (!d) return fail(MQC_HIP_ERR_DEVICE, "out of device memory");
+    HIP_CHECK_RET(hipMemcpy(d, A, sizeof(double) * nn, hipMemcpyHostToDevice));
+    launch_syev(n, d, d + 2 * nn, d + nn, ctx->stream);
+    HIP_CHECK_RET(hipStreamSynchronize(ctx->stream));
+    HIP_CHECK_RET(hipGetLastError());
+    HIP_CHECK_RET(hipMemcpy(w, d + 2 * nn, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIP_CHECK_RET(hipMemcpy(V, d + nn, sizeof(double) * nn, hipMemcpyDeviceToHost));
+    return MQC_HIP_OK;
+}
+
+int mqc_hip_diis_coefficients(mqc_hip_context* ctx, int32_t n_stored, const double* overlap, double* coefficients, int32_t* ok)
+{
+    if (!ctx || !overlap || !coefficients || !ok) return fail(MQC_HIP_ERR_VALIDATION, "bad arguments");
+    if (n_stored < 1 || n_stored > DIIS_MAX) return fail(MQC_HIP_ERR_VALIDATION, "n_stored must be within 1..8");
+    HIP_CHECK_RET(hipSetDevice(ctx->device));
+    double* d = (double*)ctx->pool_misc.ensure(4096);
+    if (!d) return fail(MQC_HIP_ERR_DEVICE, "out of device memory");
+    HIP_CHECK_RET(hipMemcpy(d + 32, overlap, sizeof(double) * n_stored * n_stored, hipMemcpyHostToDevice));
+    launch_diis_coeff(n_stored, d + 32, d + 128, (int*)d, ctx->stream);
+    HIP_CHECK_RET(hipStreamSynchronize(ctx->stream));
+    HIP_CHECK_RET(hipMemcpy(coefficients, d + 128, sizeof(double) * n_stored, hipMemcpyDeviceToHost));
+    int okv = 0;
+    HIP_CHECK_RET(hipMemcpy(&okv, d, sizeof(int), hipMemcpyDeviceToHost));
+    *ok = okv;
+    return MQC_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,146 @@
+// engine.hpp -- internal types of the MI355X SCF engine (host side, C++17).
+//
+// Design in one paragraph: the unit of work is a BATCH of fragments that share a topology
+// (same elements in the same order, same basis, same electron count) -- exactly what an
+// MBE/GMBE fragment list is made of (all monomers alike, all dimers alike).  Every stage
+// of the SCF (one-electron integrals, in-core ERI formation, J/K contraction, the linear
+// algebra of an iteration) is ONE kernel launch over the whole batch, so a 2080-fragment
+// (H2O)64 MBE-2 run keeps all 256 CUs busy instead of issuing thousands of
+// latency-bound launches per fragment (the regime mqc_cuest_scf.f90:9-23 fights).
+// A single fragment (the run_cuest_scf drop-in) is simply a batch of one.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <string>
+#include <vector>
+#include <map>
+#include <memory>
+#include "../../include/mqc_hip.h"
+
+namespace mqc {
+
+constexpr int KERNEL_LMAX = 2;      // highest AO angular momentum the compiled kernel classes cover
+constexpr int DIIS_MAX = 8;         // subspace size the device ring buffers are laid out for
+
+// fragment state machine driven by the scf_step kernel
+enum : int { ST_ITER = 0, ST_FINAL = 1, ST_DONE = 2 };
+
+struct HostShell {
+    int l, nprim, poff, atom, aoff;
+};
+
+// Everything that is identical for all fragments of a batch.
+struct Topology {
+    std::string key;
+    int natoms = 0;
+    std::vector<int> Z;
+    std::vector<double> zeff;        // ghost -> 0
+    int nelec = 0, charge = 0, multiplicity = 1;
+    std::vector<HostShell> shells;
+    std::vector<double> exps, coefs; // normalised radial coefficients (s,p angular factor folded in)
+    int nao = 0, npair = 0, lmax = 0;
+    // shell-quartet task lists, one per (la,lb,lc,ld) class, canonical order
+    struct ClassList { int la, lb, lc, ld; std::vector<int> quartets; /* 4 ints each */ };
+    std::vector<ClassList> classes;
+    std::vector<int> pairs;          // (A,B) with A>=B, 2 ints each, for the 1e kernel (la>=lb ordering)
+    int64_t n_quartets = 0;
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+// grow-only device pool, the engine's device_pool_t (mqc_cuest_context.f90:40-53,142-156)
+class DevicePool {
+public:
+    void* ensure(size_t bytes);
+    void release();
+    size_t capacity() const { return cap_; }
+private:
+    void* ptr_ = nullptr;
+    size_t cap_ = 0;
+};
+
+struct TopologyDev {
+    int *sh_l, *sh_nprim, *sh_poff, *sh_atom, *sh_aoff;
+    double *exps, *coefs, *zeff;
+    int nshell, nao, npair, natoms;
+};
+
+struct BatchView {      // plain pointers handed to kernels
+    TopologyDev topo;
+    int nfrag;
+    int n, npair;                 // n = nao
+    int nocc;
+    double exx;                   // exact-exchange fraction (1 for HF)
+    double e_tol, d_tol;
+    int max_iter, diis_size;
+    const double* boys;           // Boys Taylor table
+    const double* c2s;            // cart->sph tables, l = 0..LMAX_AO, offsets in c2s_off
+    double* xyz;                  // [nfrag][natoms][3]
+    double *S, *H, *X, *F, *D, *C, *J, *K, *W;   // [nfrag][n*n]; W = [nfrag][6][n*n] workspace
+    double* eps;                  // [nfrag][n]
+    double* eri;                  // [nfrag][npair*npair]
+    double *diis_f, *diis_e, *diis_b;   // [nfrag][8][n*n], [nfrag][8][n*n], [nfrag][8*8]
+    int* diis_state;              // [nfrag][2] = n_stored, newest
+    double* scal;                 // [nfrag][8]: e_elec, e_old, de, drms, e_final, enuc(unused), -, -
+    int* istate;                  // [nfrag][4]: state, iterations, nmo, converged
+    int* counters;                // [4]: n_not_done, ...
+};
+
+struct Stats {
+    double t_setup = 0, t_int1e = 0, t_eri = 0, t_fock = 0, t_scf_step = 0, t_total = 0;
+    int64_t fock_launches = 0, eri_quartets = 0, scf_iterations_total = 0;
+    double fock_kernel_seconds = 0, fock_bytes = 0, eri_kernel_seconds = 0;
+};
+
+}  // namespace mqc
+
+struct mqc_hip_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop;
+    double* d_boys = nullptr;
+    double* d_c2s = nullptr;
+    std::vector<double> h_c2s;                 // packed l = 0..LMAX_AO, (2l+1) x ncart(l)
+    int c2s_off[8];
+    mqc::DevicePool pool_main, pool_eri, pool_topo, pool_misc;
+    mqc::Stats stats;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    size_t hbm_budget_bytes = 0;
+};
+
+namespace mqc {
+
+// host-side pieces (basis_norm.cpp, boys_table.cpp, batch.cpp)
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+void build_boys_table(std::vector<double>& table);
+void build_c2s_tables(std::vector<double>& packed, int* offsets);
+int build_topology(const mqc_hip_molecule_t& mol, const mqc_hip_basis_t& bas, Topology& topo, std::string& err);
+std::string topology_key(const mqc_hip_molecule_t& mol, const mqc_hip_basis_t& bas);
+double nuclear_repulsion(const Topology& topo, const double* xyz);
+
+int run_batch(mqc_hip_context* ctx, const Topology& topo, const std::vector<const double*>& xyz,
+              const mqc_hip_scf_options_t& opts, std::vector<mqc_hip_scf_result_t*>& results);
+
+// kernel launchers (kern_*.hip)
+void launch_int1e(const BatchView& bv, const Topology& topo, hipStream_t s);
+void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, hipStream_t s);
+void launch_jk_incore(const BatchView& bv, bool only_active, hipStream_t s);
+void launch_orthogonalizer(const BatchView& bv, hipStream_t s);
+void launch_guess(const BatchView& bv, int guess_kind, hipStream_t s);
+void launch_scf_step(const BatchView& bv, hipStream_t s);
+void launch_syev(int n, double* dA, double* dw, double* dV, hipStream_t s);
+void launch_diis_coeff(int n_stored, const double* d_overlap, double* d_coef, int* d_ok, hipStream_t s);
+size_t scf_lds_bytes(int n);
+
+}  // namespace mqc
+
+#define HIP_CHECK_RET(expr)                                                                   \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return mqc::fail(MQC_HIP_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)

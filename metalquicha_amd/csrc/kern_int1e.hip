@@ -1,0 +1,175 @@
+// kern_int1e.hip -- overlap, kinetic and nuclear-attraction matrices for a whole batch.
+//
+// Replaces cuestOverlapCompute / KineticCompute / PotentialCompute as called from
+// backends/cuest/backend/mqc_cuest_integrals.f90:1525-1634 (CPU twin: one_electron,
+// backends/libcint/mqc_libcint_integrals.F90:843-911).  One thread per (shell pair,
+// fragment), fragment fastest, so a wave works on one shell pair of 64 different
+// fragments: identical control flow, contraction data fetched through the scalar cache.
+// Cost is O(n_pairs * n_atoms) per fragment and is paid once; the kernel is not a hot spot.
+#include "engine.hpp"
+#include "md_integrals.hpp"
+
+namespace mqc {
+
+template <int LA, int LB>
+__device__ void int1e_block(const BatchView& bv, int f, int A, int B)
+{
+    constexpr int NCA = ncart(LA), NCB = ncart(LB);
+    constexpr int L = LA + LB;
+    const TopologyDev& tp = bv.topo;
+    const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
+    const int atA = tp.sh_atom[A], atB = tp.sh_atom[B];
+    const double ax = xyz[3 * atA], ay = xyz[3 * atA + 1], az = xyz[3 * atA + 2];
+    const double bx = xyz[3 * atB], by = xyz[3 * atB + 1], bz = xyz[3 * atB + 2];
+    const double ab2 = (ax - bx) * (ax - bx) + (ay - by) * (ay - by) + (az - bz) * (az - bz);
+    double sc[NCA * NCB], tc[NCA * NCB], vc[NCA * NCB];
+#pragma unroll
+    for (int i = 0; i < NCA * NCB; ++i) { sc[i] = 0.0; tc[i] = 0.0; vc[i] = 0.0; }
+    const int npa = tp.sh_nprim[A], npb = tp.sh_nprim[B];
+    const double* ea = tp.exps + tp.sh_poff[A]; const double* ca = tp.coefs + tp.sh_poff[A];
+    const double* eb = tp.exps + tp.sh_poff[B]; const double* cb = tp.coefs + tp.sh_poff[B];
+    for (int ip = 0; ip < npa; ++ip)
+        for (int jp = 0; jp < npb; ++jp) {
+            const double a = ea[ip], b = eb[jp], p = a + b, ip_ = 1.0 / p;
+            const double kab = exp(-a * b * ip_ * ab2) * ca[ip] * cb[jp];
+            const double px = (a * ax + b * bx) * ip_, py = (a * ay + b * by) * ip_, pz = (a * az + b * bz) * ip_;
+            E1D<LA, LB + 2> ex, ey, ez;
+            ex.build(px - ax, px - bx, 0.5 * ip_);
+            ey.build(py - ay, py - by, 0.5 * ip_);
+            ez.build(pz - az, pz - bz, 0.5 * ip_);
+            const double s3 = kab * M_PI * ip_ * sqrt(M_PI * ip_);
+            int iab = 0;
+#pragma unroll
+            for (int i0 = LA; i0 >= 0; --i0)
+#pragma unroll
+                for (int i1 = LA - i0; i1 >= 0; --i1) {
+                    const int i2 = LA - i0 - i1;
+#pragma unroll
+                    for (int j0 = LB; j0 >= 0; --j0)
+#pragma unroll
+                        for (int j1 = LB - j0; j1 >= 0; --j1) {
+                            const int j2 = LB - j0 - j1;
+                            const double sx = ex.get(i0, j0, 0), sy = ey.get(i1, j1, 0), sz = ez.get(i2, j2, 0);
+                            double tx = -2.0 * b * (2 * j0 + 1) * sx + 4.0 * b * b * ex.get(i0, j0 + 2, 0);
+                            if (j0 >= 2) tx += j0 * (j0 - 1) * ex.get(i0, j0 - 2, 0);
+                            double ty = -2.0 * b * (2 * j1 + 1) * sy + 4.0 * b * b * ey.get(i1, j1 + 2, 0);
+                            if (j1 >= 2) ty += j1 * (j1 - 1) * ey.get(i1, j1 - 2, 0);
+                            double tz = -2.0 * b * (2 * j2 + 1) * sz + 4.0 * b * b * ez.get(i2, j2 + 2, 0);
+                            if (j2 >= 2) tz += j2 * (j2 - 1) * ez.get(i2, j2 - 2, 0);
+                            sc[iab] += s3 * sx * sy * sz;
+                            tc[iab] += -0.5 * s3 * (tx * sy * sz + sx * ty * sz + sx * sy * tz);
+                            ++iab;
+                        }
+                }
+            // nuclear attraction: sum over (non-ghost) centres
+            for (int at = 0; at < tp.natoms; ++at) {
+                const double zq = tp.zeff[at];
+                if (zq == 0.0) continue;
+                double R[nherm(L)];
+                hermite_r<L>(p, px - xyz[3 * at], py - xyz[3 * at + 1], pz - xyz[3 * at + 2], bv.boys, R);
+                const double pref = -zq * 2.0 * M_PI * ip_ * kab;
+                int k = 0;
+#pragma unroll
+                for (int i0 = LA; i0 >= 0; --i0)
+#pragma unroll
+                    for (int i1 = LA - i0; i1 >= 0; --i1) {
+                        const int i2 = LA - i0 - i1;
+#pragma unroll
+                        for (int j0 = LB; j0 >= 0; --j0)
+#pragma unroll
+                            for (int j1 = LB - j0; j1 >= 0; --j1) {
+                                const int j2 = LB - j0 - j1;
+                                double v = 0.0;
+#pragma unroll
+                                for (int t = 0; t <= i0 + j0; ++t)
+#pragma unroll
+                                    for (int u = 0; u <= i1 + j1; ++u)
+#pragma unroll
+                                        for (int w = 0; w <= i2 + j2; ++w)
+                                            v += ex.get(i0, j0, t) * ey.get(i1, j1, u) * ez.get(i2, j2, w) * R[hidx(t, u, w)];
+                                vc[k] += pref * v;
+                                ++k;
+                            }
+                    }
+            }
+        }
+    // cart -> sph (s and p carry their factor in the coefficients; l >= 2 uses the table)
+    constexpr int NSA = nsph(LA), NSB = nsph(LB);
+    const int n = bv.n;
+    double* S = bv.S + (size_t)f * n * n;
+    double* H = bv.H + (size_t)f * n * n;
+    double* T = bv.W + (size_t)f * 6 * n * n;   // W[0] receives T, W[1] receives V (for the stage-level API)
+    double* V = T + (size_t)n * n;
+    const int oa = tp.sh_aoff[A], ob = tp.sh_aoff[B];
+#pragma unroll
+    for (int i = 0; i < NSA; ++i)
+#pragma unroll
+        for (int j = 0; j < NSB; ++j) {
+            double s = 0.0, t = 0.0, v = 0.0;
+#pragma unroll
+            for (int ia = 0; ia < NCA; ++ia) {
+                double wa = 1.0;
+                if constexpr (LA >= 2) wa = c2s_coef<LA>(bv.c2s, i, ia); else wa = (i == ia) ? 1.0 : 0.0;
+                if (wa == 0.0) continue;
+#pragma unroll
+                for (int ib = 0; ib < NCB; ++ib) {
+                    double wb = 1.0;
+                    if constexpr (LB >= 2) wb = c2s_coef<LB>(bv.c2s, j, ib); else wb = (j == ib) ? 1.0 : 0.0;
+                    const double w = wa * wb;
+                    s += w * sc[ia * NCB + ib];
+                    t += w * tc[ia * NCB + ib];
+                    v += w * vc[ia * NCB + ib];
+                }
+            }
+            const size_t ij = (size_t)(oa + i) * n + ob + j, ji = (size_t)(ob + j) * n + oa + i;
+            S[ij] = s; S[ji] = s;
+            T[ij] = t; T[ji] = t;
+            V[ij] = v; V[ji] = v;
+            H[ij] = t + v; H[ji] = t + v;
+        }
+}
+
+template <int LA, int LB>
+__global__ void __launch_bounds__(64) int1e_kernel(BatchView bv, const int* __restrict__ pairs, int npairs)
+{
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)npairs * bv.nfrag;
+    if (tid >= total) return;
+    const int ip = (int)(tid / bv.nfrag), f = (int)(tid % bv.nfrag);
+    int1e_block<LA, LB>(bv, f, pairs[2 * ip], pairs[2 * ip + 1]);
+}
+
+template <int LA, int LB>
+static void launch_class(const BatchView& bv, const std::vector<int>& list, DevicePool& scratch, hipStream_t s)
+{
+    if (list.empty()) return;
+    int npairs = (int)list.size() / 2;
+    int* d = (int*)scratch.ensure(list.size() * sizeof(int));
+    (void)hipMemcpyAsync(d, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice, s);
+    long total = (long)npairs * bv.nfrag;
+    int blocks = (int)((total + 63) / 64);
+    hipLaunchKernelGGL((int1e_kernel<LA, LB>), dim3(blocks), dim3(64), 0, s, bv, d, npairs);
+    (void)hipStreamSynchronize(s);   // the scratch list is reused by the next class
+}
+
+void launch_int1e(const BatchView& bv, const Topology& topo, hipStream_t s)
+{
+    static DevicePool scratch;
+    // bucket the (A>=B) shell pairs by (la,lb) with la >= lb
+    std::vector<int> bucket[KERNEL_LMAX + 1][KERNEL_LMAX + 1];
+    for (size_t k = 0; k + 1 < topo.pairs.size(); k += 2) {
+        int A = topo.pairs[k], B = topo.pairs[k + 1];
+        int la = topo.shells[A].l, lb = topo.shells[B].l;
+        if (la < lb) { std::swap(A, B); std::swap(la, lb); }
+        bucket[la][lb].push_back(A);
+        bucket[la][lb].push_back(B);
+    }
+    launch_class<0, 0>(bv, bucket[0][0], scratch, s);
+    launch_class<1, 0>(bv, bucket[1][0], scratch, s);
+    launch_class<1, 1>(bv, bucket[1][1], scratch, s);
+    launch_class<2, 0>(bv, bucket[2][0], scratch, s);
+    launch_class<2, 1>(bv, bucket[2][1], scratch, s);
+    launch_class<2, 2>(bv, bucket[2][2], scratch, s);
+}
+
+}  // namespace mqc

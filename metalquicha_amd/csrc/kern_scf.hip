@@ -1,0 +1,620 @@
+// kern_scf.hip -- the linear algebra of one SCF iteration, one workgroup per fragment.
+//
+// What the cuEST loop does with ~25 cuBLAS/cuSOLVER launches and 3 blocking scalar
+// fetches per iteration per fragment (backends/cuest/backend/mqc_cuest_scf.f90:444-553,
+// mqc_cuest_integrals.f90:1841-1947, mqc_diis_device.f90:122-222), this file does in ONE
+// launch for the whole batch: each 256-thread workgroup owns a fragment and performs
+//   F = H + J - (exx/2) K,  E = 1/2 sum D (H + F)          (assemble_fock + matrix_dot)
+//   e = X^T (F D S - S D F) X                              (commutator_device)
+//   DIIS push / coefficients / extrapolation               (diis_device_t, mqc_diis.f90)
+//   F' = X^T F X, eigen-decomposition, C = X C', D = 2 C_o C_o^T   (diagonalize_fock_device)
+//   dE, rms dD, convergence state machine                  (mqc_libcint_rhf.f90:626-662)
+// with the reference CPU path's semantics (dE and rms(dD) test for iteration > 1, then a
+// final full rebuild of F and E from the converged density).
+//
+// The eigen-solver is a cyclic parallel Jacobi held in LDS (the matrices are 24..116 wide:
+// a LAPACK-style tridiagonalisation would be launch- and latency-bound here, whereas one CU
+// with the matrix in its 160 KB LDS does n/2 independent rotations per step).
+#include "engine.hpp"
+
+namespace mqc {
+
+constexpr int NT = 256;
+constexpr double OVERLAP_EIG_TOL = 1.0e-7;   // src/scf/mqc_scf_common.f90:33
+constexpr double GWH_K = 1.75;               // src/scf/mqc_scf_common.f90:39
+constexpr double PIVOT_FLOOR = 1.0e-14;      // src/methods/mqc_diis.f90:30
+constexpr double JACOBI_SKIP = 1.0e-15;      // rotation skipped when |a_pq| <= this * max|a_ii|
+constexpr int JACOBI_MAX_SWEEPS = 60;
+
+__device__ __forceinline__ double block_sum(double v, double* red)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < NT / 64; ++k) t += red[k];
+    return t;
+}
+
+__device__ __forceinline__ double block_max(double v, double* red)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double t = red[0];
+#pragma unroll
+    for (int k = 1; k < NT / 64; ++k) t = fmax(t, red[k]);
+    return t;
+}
+
+// C[M x N] (ldc) = op(A) * B;  A is [M x K] (lda) or, if TA, [K x M];  B is [K x N] (ldb).
+template <bool TA>
+__device__ void wg_gemm(int M, int N, int K, const double* __restrict__ A, int lda,
+                        const double* __restrict__ B, int ldb, double* __restrict__ C, int ldc)
+{
+    for (int idx = threadIdx.x; idx < M * N; idx += NT) {
+        const int i = idx / N, j = idx - i * N;
+        double s = 0.0;
+        if (TA) {
+            for (int k = 0; k < K; ++k) s += A[k * lda + i] * B[k * ldb + j];
+        } else {
+            for (int k = 0; k < K; ++k) s += A[i * lda + k] * B[k * ldb + j];
+        }
+        C[i * ldc + j] = s;
+    }
+    __syncthreads();
+}
+
+struct JacobiLds {
+    double* A;      // mp x lda
+    double* V;      // mp x lda (LDS) or global m x ldv
+    double* rc;     // mp/2
+    double* rs;     // mp/2
+    int* rp;        // mp/2
+    int* rq;        // mp/2
+    double* red;    // 8
+    int* flag;      // 2
+    int lda;
+};
+
+__host__ __device__ inline int even_up(int m) { return (m + 1) & ~1; }
+
+__host__ __device__ inline size_t jacobi_lds_doubles(int m, bool v_in_lds)
+{
+    const int mp = even_up(m), lda = mp + 1;
+    size_t d = (size_t)mp * lda;             // A
+    if (v_in_lds) d += (size_t)mp * lda;     // V
+    d += 2 * (mp / 2);                       // rc, rs
+    d += mp / 2 + 1;                         // rp, rq as ints packed in doubles
+    d += 8 + 2;                              // red, flag
+    return d;
+}
+
+__device__ inline JacobiLds carve_jacobi(double* lds, int m, bool v_in_lds, double* v_global)
+{
+    JacobiLds j;
+    const int mp = even_up(m);
+    j.lda = mp + 1;
+    j.A = lds; lds += (size_t)mp * j.lda;
+    if (v_in_lds) { j.V = lds; lds += (size_t)mp * j.lda; } else { j.V = v_global; }
+    j.rc = lds; lds += mp / 2;
+    j.rs = lds; lds += mp / 2;
+    j.rp = (int*)lds; j.rq = j.rp + mp / 2; lds += mp / 2 + 1;
+    j.red = lds; lds += 8;
+    j.flag = (int*)lds;
+    return j;
+}
+
+// Symmetric eigen-decomposition of the m x m matrix already stored in jl.A (padded to even mp
+// with a zero row/column).  On exit jl.A's diagonal holds the eigenvalues and V's columns the
+// eigenvectors (V addressed as V[row * ldv + col]).
+template <bool VLDS>
+__device__ void jacobi_eig(JacobiLds& jl, int m, int ldv)
+{
+    const int mp = even_up(m), lda = jl.lda, half = mp / 2;
+    const int tid = threadIdx.x;
+    double* A = jl.A;
+    double* V = jl.V;
+    // V = I
+    for (int idx = tid; idx < mp * mp; idx += NT) {
+        const int r = idx / mp, c = idx - r * mp;
+        if (VLDS || (r < m && c < m)) V[r * ldv + c] = (r == c) ? 1.0 : 0.0;
+    }
+    double dmax = 0.0;
+    for (int i = tid; i < m; i += NT) dmax = fmax(dmax, fabs(A[i * lda + i]));
+    double omax = 0.0;
+    for (int idx = tid; idx < m * m; idx += NT) {
+        const int r = idx / m, c = idx - r * m;
+        if (r != c) omax = fmax(omax, fabs(A[r * lda + c]));
+    }
+    dmax = block_max(fmax(dmax, omax), jl.red);
+    const double thresh = JACOBI_SKIP * dmax;
+    __syncthreads();
+
+    for (int sweep = 0; sweep < JACOBI_MAX_SWEEPS; ++sweep) {
+        if (tid == 0) jl.flag[0] = 0;
+        __syncthreads();
+        for (int r = 0; r < mp - 1; ++r) {
+            if (tid < half) {
+                int p, q;
+                if (tid == 0) { p = mp - 1; q = r; }
+                else { p = (r + tid) % (mp - 1); q = (r - tid + (mp - 1)) % (mp - 1); }
+                if (p > q) { const int t = p; p = q; q = t; }
+                const double apq = A[p * lda + q];
+                double c = 1.0, s = 0.0;
+                if (fabs(apq) > thresh) {
+                    const double app = A[p * lda + p], aqq = A[q * lda + q];
+                    const double theta = (aqq - app) / (2.0 * apq);
+                    const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    c = 1.0 / sqrt(t * t + 1.0);
+                    s = t * c;
+                    jl.flag[0] = 1;
+                }
+                jl.rc[tid] = c; jl.rs[tid] = s; jl.rp[tid] = p; jl.rq[tid] = q;
+            }
+            __syncthreads();
+            // rows: A <- J^T A
+            for (int idx = tid; idx < half * mp; idx += NT) {
+                const int k = idx / mp, col = idx - k * mp;
+                const double s = jl.rs[k];
+                if (s != 0.0) {
+                    const double c = jl.rc[k];
+                    const int p = jl.rp[k], q = jl.rq[k];
+                    const double ap = A[p * lda + col], aq = A[q * lda + col];
+                    A[p * lda + col] = c * ap - s * aq;
+                    A[q * lda + col] = s * ap + c * aq;
+                }
+            }
+            __syncthreads();
+            // columns: A <- A J, V <- V J
+            for (int idx = tid; idx < half * mp; idx += NT) {
+                const int k = idx / mp, row = idx - k * mp;
+                const double s = jl.rs[k];
+                if (s != 0.0) {
+                    const double c = jl.rc[k];
+                    const int p = jl.rp[k], q = jl.rq[k];
+                    const double ap = A[row * lda + p], aq = A[row * lda + q];
+                    A[row * lda + p] = c * ap - s * aq;
+                    A[row * lda + q] = s * ap + c * aq;
+                    if (VLDS || row < m) {
+                        const double vp = V[row * ldv + p], vq = V[row * ldv + q];
+                        V[row * ldv + p] = c * vp - s * vq;
+                        V[row * ldv + q] = s * vp + c * vq;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (jl.flag[0] == 0) break;
+        __syncthreads();
+    }
+    __syncthreads();
+}
+
+// rank of eigenvalue i among the first m diagonal entries (ascending, ties by index)
+__device__ __forceinline__ int eig_rank(const double* A, int lda, int m, int i)
+{
+    const double wi = A[i * lda + i];
+    int r = 0;
+    for (int j = 0; j < m; ++j) {
+        const double wj = A[j * lda + j];
+        r += (wj < wi || (wj == wi && j < i)) ? 1 : 0;
+    }
+    return r;
+}
+
+struct FragPtrs {
+    double *S, *H, *X, *F, *D, *C, *J, *K, *W, *eps, *scal;
+    double *diis_f, *diis_e, *diis_b;
+    int *diis_state, *istate;
+};
+
+__device__ __forceinline__ FragPtrs frag_ptrs(const BatchView& bv, int f)
+{
+    const size_t nn = (size_t)bv.n * bv.n;
+    FragPtrs p;
+    p.S = bv.S + f * nn; p.H = bv.H + f * nn; p.X = bv.X + f * nn; p.F = bv.F + f * nn;
+    p.D = bv.D + f * nn; p.C = bv.C + f * nn; p.J = bv.J + f * nn; p.K = bv.K + f * nn;
+    p.W = bv.W + f * 6 * nn; p.eps = bv.eps + (size_t)f * bv.n; p.scal = bv.scal + (size_t)f * 8;
+    p.diis_f = bv.diis_f + f * DIIS_MAX * nn; p.diis_e = bv.diis_e + f * DIIS_MAX * nn;
+    p.diis_b = bv.diis_b + (size_t)f * DIIS_MAX * DIIS_MAX;
+    p.diis_state = bv.diis_state + 2 * f; p.istate = bv.istate + 4 * f;
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------
+// X = U s^{-1/2} over overlap eigenvalues > 1e-7, ascending (build_orthogonalizer,
+// src/scf/mqc_scf_common.f90:43-83).  nmo goes to istate[2].
+template <bool VLDS>
+__global__ void __launch_bounds__(NT) orthogonalizer_kernel(BatchView bv)
+{
+    extern __shared__ double lds[];
+    const int f = blockIdx.x, n = bv.n, tid = threadIdx.x;
+    FragPtrs p = frag_ptrs(bv, f);
+    JacobiLds jl = carve_jacobi(lds, n, VLDS, p.W);
+    const int mp = even_up(n), lda = jl.lda;
+    const int ldv = VLDS ? lda : n;
+    for (int idx = tid; idx < mp * lda; idx += NT) jl.A[idx] = 0.0;
+    __syncthreads();
+    for (int idx = tid; idx < n * n; idx += NT) jl.A[(idx / n) * lda + (idx % n)] = p.S[idx];
+    __syncthreads();
+    jacobi_eig<VLDS>(jl, n, ldv);
+    // count dropped modes
+    int drop = 0;
+    for (int i = 0; i < n; ++i) drop += (jl.A[i * lda + i] > OVERLAP_EIG_TOL) ? 0 : 1;
+    const int nmo = n - drop;
+    for (int idx = tid; idx < n * n; idx += NT) p.X[idx] = 0.0;
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+        const double w = jl.A[i * lda + i];
+        if (!(w > OVERLAP_EIG_TOL)) continue;
+        const int col = eig_rank(jl.A, lda, n, i) - drop;
+        const double sc = 1.0 / sqrt(w);
+        for (int r = tid; r < n; r += NT) p.X[r * n + col] = jl.V[r * ldv + i] * sc;
+    }
+    if (tid == 0) p.istate[2] = nmo;
+}
+
+// F (n x n, global) -> eps, C, D.  Uses W[2] (n x m) as scratch and the Jacobi LDS block.
+template <bool VLDS>
+__device__ void diagonalize_and_density(const BatchView& bv, FragPtrs& p, JacobiLds& jl, int m)
+{
+    const int n = bv.n, tid = threadIdx.x;
+    const size_t nn = (size_t)n * n;
+    double* T = p.W + 2 * nn;       // F X  (n x m)
+    double* Vg = p.W + 3 * nn;      // global eigenvectors when they do not fit in LDS
+    const int mp = even_up(m), lda = jl.lda;
+    const int ldv = VLDS ? lda : m;
+    if (!VLDS) jl.V = Vg;
+    wg_gemm<false>(n, m, n, p.F, n, p.X, n, T, n);
+    for (int idx = tid; idx < mp * lda; idx += NT) jl.A[idx] = 0.0;
+    __syncthreads();
+    // F' = X^T (F X) straight into LDS
+    for (int idx = tid; idx < m * m; idx += NT) {
+        const int i = idx / m, j = idx - i * m;
+        double s = 0.0;
+        for (int k = 0; k < n; ++k) s += p.X[k * n + i] * T[k * n + j];
+        jl.A[i * lda + j] = s;
+    }
+    __syncthreads();
+    // symmetrise (F' is symmetric up to rounding; Jacobi assumes exact symmetry)
+    for (int idx = tid; idx < m * m; idx += NT) {
+        const int i = idx / m, j = idx - i * m;
+        if (i < j) {
+            const double a = 0.5 * (jl.A[i * lda + j] + jl.A[j * lda + i]);
+            jl.A[i * lda + j] = a; jl.A[j * lda + i] = a;
+        }
+    }
+    __syncthreads();
+    jacobi_eig<VLDS>(jl, m, ldv);
+    // sorted eigenvalues + C = X C'
+    int* rank = (int*)(p.W + 4 * nn);   // m ints
+    for (int i = tid; i < m; i += NT) {
+        const int r = eig_rank(jl.A, lda, m, i);
+        rank[i] = r;
+        p.eps[r] = jl.A[i * lda + i];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < n * m; idx += NT) {
+        const int r = idx / m, i = idx - r * m;    // C[r][rank[i]] = sum_k X[r][k] V[k][i]
+        double s = 0.0;
+        for (int k = 0; k < m; ++k) s += p.X[r * n + k] * jl.V[k * ldv + i];
+        p.C[r * n + rank[i]] = s;
+    }
+    __syncthreads();
+    // D = 2 C_occ C_occ^T
+    const int nocc = bv.nocc;
+    for (int idx = tid; idx < n * n; idx += NT) {
+        const int i = idx / n, j = idx - i * n;
+        if (j > i) continue;
+        double s = 0.0;
+        for (int o = 0; o < nocc; ++o) s += p.C[i * n + o] * p.C[j * n + o];
+        p.D[i * n + j] = 2.0 * s; p.D[j * n + i] = 2.0 * s;
+    }
+    __syncthreads();
+}
+
+// Starting Fock (core or GWH, guess_fock mqc_libcint_rhf.f90:1354-1380), then the first density.
+template <bool VLDS>
+__global__ void __launch_bounds__(NT) guess_kernel(BatchView bv, int guess_kind)
+{
+    extern __shared__ double lds[];
+    const int f = blockIdx.x, n = bv.n, tid = threadIdx.x;
+    FragPtrs p = frag_ptrs(bv, f);
+    const int m = p.istate[2];
+    JacobiLds jl = carve_jacobi(lds, m, VLDS, nullptr);
+    for (int idx = tid; idx < n * n; idx += NT) {
+        const int i = idx / n, j = idx - i * n;
+        double v = p.H[idx];
+        if (guess_kind == MQC_HIP_GUESS_GWH && i != j) v = 0.5 * GWH_K * p.S[idx] * (p.H[i * n + i] + p.H[j * n + j]);
+        p.F[idx] = v;
+    }
+    __syncthreads();
+    diagonalize_and_density<VLDS>(bv, p, jl, m);
+    if (tid == 0) {
+        p.istate[0] = ST_ITER; p.istate[1] = 0; p.istate[3] = 0;
+        p.diis_state[0] = 0; p.diis_state[1] = 0;
+        p.scal[0] = 0.0; p.scal[1] = 0.0; p.scal[2] = 0.0; p.scal[3] = 0.0; p.scal[4] = 0.0;
+    }
+}
+
+// slot (1-based) of the age-th oldest entry, age = 1..n_stored (diis_slot_of_age, mqc_diis.f90:89-103)
+__host__ __device__ inline int diis_slot_of_age(int newest, int n_stored, int max_vectors, int age)
+{
+    int v = (newest - n_stored + age - 1) % max_vectors;
+    if (v < 0) v += max_vectors;
+    return v + 1;
+}
+
+// DIIS weights, oldest first, from the slot-indexed overlap cache: the reference's
+// diis_coefficients + solve_diis (mqc_diis.f90:164-273) transcribed operation for operation.
+__host__ __device__ inline bool diis_solve(const double* overlap /* [maxv*maxv] slot coords */, int newest,
+                                           int n_stored, int max_vectors, double* coef /* n_stored+1 */)
+{
+    if (n_stored < 2) return false;
+    const int n = n_stored, N = n + 1;
+    double aug[(DIIS_MAX + 1) * (DIIS_MAX + 2)];
+    const int ld = N + 1;
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) aug[i * ld + j] = -1.0;
+    aug[n * ld + n] = 0.0;
+    double scale = 0.0;
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) {
+            const int si = diis_slot_of_age(newest, n_stored, max_vectors, i + 1) - 1;
+            const int sj = diis_slot_of_age(newest, n_stored, max_vectors, j + 1) - 1;
+            const double v = overlap[si * max_vectors + sj];
+            aug[i * ld + j] = v;
+            scale = fmax(scale, fabs(v));
+        }
+    if (scale > 0.0)
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) aug[i * ld + j] /= scale;
+    for (int i = 0; i < N; ++i) aug[i * ld + N] = 0.0;
+    aug[(N - 1) * ld + N] = -1.0;
+    for (int i = 0; i < N; ++i) {
+        int piv = i;
+        for (int j = i + 1; j < N; ++j)
+            if (fabs(aug[j * ld + i]) > fabs(aug[piv * ld + i])) piv = j;
+        if (piv != i)
+            for (int c = 0; c <= N; ++c) { const double t = aug[i * ld + c]; aug[i * ld + c] = aug[piv * ld + c]; aug[piv * ld + c] = t; }
+        const double pivot = aug[i * ld + i];
+        if (fabs(pivot) < PIVOT_FLOOR) return false;
+        for (int j = i + 1; j < N; ++j) {
+            const double factor = aug[j * ld + i] / pivot;
+            for (int c = i; c <= N; ++c) aug[j * ld + c] -= factor * aug[i * ld + c];
+        }
+    }
+    for (int i = N - 1; i >= 0; --i) {
+        double s = aug[i * ld + N];
+        for (int c = i + 1; c < N; ++c) s -= aug[i * ld + c] * coef[c];
+        coef[i] = s / aug[i * ld + i];
+    }
+    return true;
+}
+
+template <bool VLDS>
+__global__ void __launch_bounds__(NT) scf_step_kernel(BatchView bv)
+{
+    extern __shared__ double lds[];
+    const int f = blockIdx.x, n = bv.n, tid = threadIdx.x;
+    FragPtrs p = frag_ptrs(bv, f);
+    const int state = p.istate[0];
+    if (state == ST_DONE) return;
+    const int m = p.istate[2];
+    const size_t nn = (size_t)n * n;
+    JacobiLds jl = carve_jacobi(lds, m, VLDS, nullptr);
+
+    // ---- Fock assembly and energy (assemble_fock :985-990,1206-1228; electronic_energy :1691)
+    double e = 0.0;
+    for (int idx = tid; idx < n * n; idx += NT) {
+        const double h = p.H[idx];
+        const double fk = h + p.J[idx] - 0.5 * bv.exx * p.K[idx];
+        p.F[idx] = fk;
+        e += p.D[idx] * (h + fk);
+    }
+    e = 0.5 * block_sum(e, jl.red);
+    if (state == ST_FINAL) {
+        if (tid == 0) { p.scal[4] = e; p.istate[0] = ST_DONE; }
+        return;
+    }
+
+    // ---- DIIS error e = X^T (F D S - S D F) X   (commutator :1326-1352)
+    double* W0 = p.W; double* W1 = p.W + nn; double* W2 = p.W + 2 * nn; double* Err = p.W + 5 * nn;
+    wg_gemm<false>(n, n, n, p.F, n, p.D, n, W0, n);          // F D
+    wg_gemm<false>(n, n, n, W0, n, p.S, n, W1, n);           // F D S
+    for (int idx = tid; idx < n * n; idx += NT) {            // A - A^T  (S D F = (F D S)^T)
+        const int i = idx / n, j = idx - i * n;
+        W0[idx] = W1[idx] - W1[j * n + i];
+    }
+    __syncthreads();
+    wg_gemm<false>(n, m, n, W0, n, p.X, n, W2, n);           // (.) X      n x m
+    wg_gemm<true>(m, m, n, p.X, n, W2, n, Err, m);           // X^T (.)    m x m, ld m
+
+    // ---- DIIS push / extrapolate (mqc_diis.f90:113-162; RHF extrapolates from the first iteration)
+    const int maxv = bv.diis_size;
+    if (maxv > 0) {
+        int n_stored = p.diis_state[0], newest = p.diis_state[1];
+        newest = newest % maxv + 1;
+        if (n_stored < maxv) n_stored += 1;
+        const int slot = newest - 1;
+        double* fh = p.diis_f + (size_t)slot * nn;
+        double* eh = p.diis_e + (size_t)slot * nn;
+        for (int idx = tid; idx < n * n; idx += NT) fh[idx] = p.F[idx];
+        for (int idx = tid; idx < m * m; idx += NT) eh[idx] = Err[idx];
+        __syncthreads();
+        for (int age = 1; age <= n_stored; ++age) {
+            const int other = diis_slot_of_age(newest, n_stored, maxv, age) - 1;
+            const double* eo = p.diis_e + (size_t)other * nn;
+            double s = 0.0;
+            for (int idx = tid; idx < m * m; idx += NT) s += eh[idx] * eo[idx];
+            s = block_sum(s, jl.red);
+            if (tid == 0) { p.diis_b[slot * maxv + other] = s; p.diis_b[other * maxv + slot] = s; }
+        }
+        __syncthreads();
+        double* coef = jl.rc;     // reuse LDS (>= 9 doubles: mp/2 >= 9 needs m >= 18; fall back to red otherwise)
+        __shared__ double coef_s[DIIS_MAX + 2];
+        __shared__ int ok_s;
+        if (tid == 0) {
+            double cf[DIIS_MAX + 2];
+            const bool ok = diis_solve(p.diis_b, newest, n_stored, maxv, cf);
+            ok_s = ok ? 1 : 0;
+            for (int i = 0; i <= n_stored; ++i) coef_s[i] = cf[i];
+            p.diis_state[0] = n_stored; p.diis_state[1] = newest;
+        }
+        (void)coef;
+        __syncthreads();
+        if (ok_s) {
+            for (int idx = tid; idx < n * n; idx += NT) {
+                double s = 0.0;
+                for (int i = 0; i < n_stored; ++i) {
+                    const int sl = diis_slot_of_age(newest, n_stored, maxv, i + 1) - 1;
+                    s += coef_s[i] * p.diis_f[(size_t)sl * nn + idx];
+                }
+                p.F[idx] = s;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- keep the old density, diagonalise, new density
+    double* Dold = p.W + nn;    // W1 is free again
+    for (int idx = tid; idx < n * n; idx += NT) Dold[idx] = p.D[idx];
+    __syncthreads();
+    diagonalize_and_density<VLDS>(bv, p, jl, m);
+
+    double d2 = 0.0;
+    for (int idx = tid; idx < n * n; idx += NT) { const double d = p.D[idx] - Dold[idx]; d2 += d * d; }
+    d2 = block_sum(d2, jl.red);
+    if (tid == 0) {
+        const double e_old = p.scal[1];
+        const double de = fabs(e - e_old);
+        const double drms = sqrt(d2 / (double)(n * n));
+        const int iter = p.istate[1] + 1;
+        p.scal[0] = e; p.scal[1] = e; p.scal[2] = de; p.scal[3] = drms;
+        p.istate[1] = iter;
+        if (iter > 1 && de < bv.e_tol && drms < bv.d_tol) { p.istate[3] = 1; p.istate[0] = ST_FINAL; }
+        else if (iter >= bv.max_iter) { p.istate[3] = 0; p.istate[0] = ST_FINAL; }
+    }
+}
+
+__global__ void count_active_kernel(BatchView bv)
+{
+    int c = 0;
+    for (int f = threadIdx.x; f < bv.nfrag; f += blockDim.x) c += (bv.istate[4 * f] != ST_DONE) ? 1 : 0;
+    __shared__ int tot;
+    if (threadIdx.x == 0) tot = 0;
+    __syncthreads();
+    atomicAdd(&tot, c);
+    __syncthreads();
+    if (threadIdx.x == 0) bv.counters[0] = tot;
+}
+
+// ---------------------------------------------------------------------------------------
+size_t scf_lds_bytes(int n)
+{
+    size_t with_v = jacobi_lds_doubles(n, true) * sizeof(double);
+    if (with_v <= 150 * 1024) return with_v;
+    return jacobi_lds_doubles(n, false) * sizeof(double);
+}
+
+static bool v_in_lds(int n) { return jacobi_lds_doubles(n, true) * sizeof(double) <= 150 * 1024; }
+
+template <typename K, typename... Args>
+static void launch_wg(K kern, int nfrag, size_t lds, hipStream_t s, Args... args)
+{
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(nfrag), dim3(NT), lds, s, args...);
+}
+
+void launch_orthogonalizer(const BatchView& bv, hipStream_t s)
+{
+    const size_t lds = scf_lds_bytes(bv.n);
+    if (v_in_lds(bv.n)) launch_wg(orthogonalizer_kernel<true>, bv.nfrag, lds, s, bv);
+    else launch_wg(orthogonalizer_kernel<false>, bv.nfrag, lds, s, bv);
+}
+
+void launch_guess(const BatchView& bv, int guess_kind, hipStream_t s)
+{
+    const size_t lds = scf_lds_bytes(bv.n);
+    if (v_in_lds(bv.n)) launch_wg(guess_kernel<true>, bv.nfrag, lds, s, bv, guess_kind);
+    else launch_wg(guess_kernel<false>, bv.nfrag, lds, s, bv, guess_kind);
+}
+
+void launch_scf_step(const BatchView& bv, hipStream_t s)
+{
+    const size_t lds = scf_lds_bytes(bv.n);
+    if (v_in_lds(bv.n)) launch_wg(scf_step_kernel<true>, bv.nfrag, lds, s, bv);
+    else launch_wg(scf_step_kernel<false>, bv.nfrag, lds, s, bv);
+    hipLaunchKernelGGL(count_active_kernel, dim3(1), dim3(256), 0, s, bv);
+}
+
+// ---- stage-level entry points ---------------------------------------------------------
+template <bool VLDS>
+__global__ void __launch_bounds__(NT) syev_kernel(int n, const double* A, double* w, double* V)
+{
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x;
+    JacobiLds jl = carve_jacobi(lds, n, VLDS, V);
+    const int mp = even_up(n), lda = jl.lda, ldv = VLDS ? lda : n;
+    for (int idx = tid; idx < mp * lda; idx += NT) jl.A[idx] = 0.0;
+    __syncthreads();
+    for (int idx = tid; idx < n * n; idx += NT) jl.A[(idx / n) * lda + (idx % n)] = A[idx];
+    __syncthreads();
+    jacobi_eig<VLDS>(jl, n, ldv);
+    __shared__ int rank_s[256];
+    for (int i = tid; i < n; i += NT) { rank_s[i] = eig_rank(jl.A, lda, n, i); w[rank_s[i]] = jl.A[i * lda + i]; }
+    __syncthreads();
+    if (VLDS) {
+        for (int idx = tid; idx < n * n; idx += NT) {
+            const int r = idx / n, i = idx - r * n;
+            V[r * n + rank_s[i]] = jl.V[r * ldv + i];
+        }
+    } else {
+        // in-place column permutation of the global V through registers, one row at a time
+        for (int r = 0; r < n; ++r) {
+            double v = 0.0;
+            if (tid < n) v = V[r * n + tid];
+            __syncthreads();
+            if (tid < n) V[r * n + rank_s[tid]] = v;
+            __syncthreads();
+        }
+    }
+}
+
+void launch_syev(int n, double* dA, double* dw, double* dV, hipStream_t s)
+{
+    const size_t lds = scf_lds_bytes(n);
+    if (v_in_lds(n)) {
+        (void)hipFuncSetAttribute((const void*)syev_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(syev_kernel<true>, dim3(1), dim3(NT), lds, s, n, dA, dw, dV);
+    } else {
+        (void)hipFuncSetAttribute((const void*)syev_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(syev_kernel<false>, dim3(1), dim3(NT), lds, s, n, dA, dw, dV);
+    }
+}
+
+__global__ void diis_coeff_kernel(int n_stored, const double* overlap, double* coef, int* ok)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double cf[DIIS_MAX + 2];
+        // the caller's matrix is already age-ordered: newest = n_stored, max_vectors = n_stored
+        const bool good = diis_solve(overlap, n_stored, n_stored, n_stored, cf);
+        *ok = good ? 1 : 0;
+        for (int i = 0; i < n_stored; ++i) coef[i] = good ? cf[i] : 0.0;
+    }
+}
+
+void launch_diis_coeff(int n_stored, const double* d_overlap, double* d_coef, int* d_ok, hipStream_t s)
+{
+    hipLaunchKernelGGL(diis_coeff_kernel, dim3(1), dim3(64), 0, s, n_stored, d_overlap, d_coef, d_ok);
+}
+
+}  // namespace mqc

@@ -1,0 +1,385 @@
+// md_integrals.hpp -- McMurchie-Davidson integral arithmetic for the gfx950 kernels.
+//
+// Everything here is a `__host__ __device__` inline template so that (a) the HIP kernels
+// in kern_eri.hip / kern_int1e.hip instantiate it per angular-momentum class with all loop
+// bounds known at compile time (arrays become VGPRs after full unrolling), and (b) the
+// test-only harness tests/host/check_device_math.cpp can run the very same arithmetic on the
+// CPU against the oracle.  libmqc_hip.so itself contains no host execution path for these.
+//
+// Conventions restated from libcint (the reference's integral dependency, see
+// backends/libcint/mqc_libcint_ao_data.f90:28-125 and mqc_libcint_ao.f90:17-19,166-193):
+//   Cartesian component order of shell l:  x^(l-i) y^(i-j) z^j, i = 0..l, j = 0..i
+//   real solid harmonics r^l Y_lm, m = -l..l, except p which is (x, y, z)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+namespace mqc {
+
+#define MQC_HD __host__ __device__ __forceinline__
+
+constexpr int LMAX_AO = 4;                     // g functions, as the reference's c2s table
+constexpr int BOYS_MAX_ORDER = 4 * LMAX_AO;    // highest Boys order an ERI can ask for
+constexpr int BOYS_TAYLOR = 8;                 // terms k = 0..7 of the Taylor expansion
+constexpr int BOYS_COLS = BOYS_MAX_ORDER + BOYS_TAYLOR;   // table columns F_0..F_{max+7}
+constexpr double BOYS_STEP = 0.1;
+constexpr double BOYS_TMAX = 42.0;
+constexpr int BOYS_ROWS = 421;                 // T0 = 0, 0.1, ..., 42.0
+
+MQC_HD constexpr int ncart(int l) { return (l + 1) * (l + 2) / 2; }
+MQC_HD constexpr int nsph(int l) { return 2 * l + 1; }
+MQC_HD constexpr int nherm(int L) { return (L + 1) * (L + 2) * (L + 3) / 6; }
+
+// index of (t,u,v) inside the tetrahedron t+u+v <= L, ordered by total degree N, then t, then u
+MQC_HD constexpr int hidx(int t, int u, int v)
+{
+    int N = t + u + v;
+    int base = N * (N + 1) * (N + 2) / 6;     // entries of degree < N
+    // within degree N: t descending from N..0, u descending
+    int tt = N - t;                             // 0..N
+    return base + tt * (tt + 1) / 2 + (tt - u); // u runs N-t .. 0
+}
+
+// ---------------------------------------------------------------------------------------
+// Boys function F_0..F_L(T) from the pre-tabulated Taylor grid (table built on the host by
+// boys_table.cpp with a convergent series; row r holds F_0..F_{BOYS_COLS-1}(r*BOYS_STEP)).
+template <int L>
+MQC_HD void boys(double T, const double* __restrict__ table, double* F)
+{
+    if (T < BOYS_TMAX) {
+        int r = (int)(T * (1.0 / BOYS_STEP) + 0.5);
+        double dt = r * BOYS_STEP - T;            // |dt| <= 0.05
+        const double* row = table + r * BOYS_COLS + L;
+        // F_L(T) = sum_k F_{L+k}(T0) dt^k / k!
+        double acc = row[7] * (1.0 / 5040.0);
+        acc = acc * dt + row[6] * (1.0 / 720.0);
+        acc = acc * dt + row[5] * (1.0 / 120.0);
+        acc = acc * dt + row[4] * (1.0 / 24.0);
+        acc = acc * dt + row[3] * (1.0 / 6.0);
+        acc = acc * dt + row[2] * 0.5;
+        acc = acc * dt + row[1];
+        acc = acc * dt + row[0];
+        F[L] = acc;
+        if (L > 0) {
+            double et = exp(-T);
+#pragma unroll
+            for (int n = L; n > 0; --n) F[n - 1] = (2.0 * T * F[n] + et) * (1.0 / (2 * n - 1));
+        }
+    } else {
+        double inv = 1.0 / T;
+        F[0] = 0.886226925452758014 * sqrt(inv);   // sqrt(pi)/2 / sqrt(T); erfc(sqrt(42)) ~ 1e-20
+        if (L > 0) {
+            double et = exp(-T);
+#pragma unroll
+            for (int n = 0; n < L; ++n) F[n + 1] = ((2 * n + 1) * F[n] - et) * (0.5 * inv);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Hermite Coulomb integrals R_{tuv}(alpha, PQ) for t+u+v <= L, packed with hidx().
+// Level-by-level: Rn holds R^(n) for all (tuv) of degree <= L-n.
+template <int L>
+MQC_HD void hermite_r(double alpha, double X, double Y, double Z, const double* __restrict__ table, double* R)
+{
+    double F[L + 1];
+    boys<L>(alpha * (X * X + Y * Y + Z * Z), table, F);
+    // scale: R^n_000 = (-2 alpha)^n F_n
+    double s = 1.0;
+#pragma unroll
+    for (int n = 0; n <= L; ++n) { F[n] *= s; s *= -2.0 * alpha; }
+    if constexpr (L == 0) { R[0] = F[0]; return; }
+    // work[n] arrays, built from n = L down to 0.  cur = R^(n+1) (degree <= L-n-1)
+    double cur[nherm(L > 0 ? L - 1 : 0)];
+    double nxt[nherm(L)];
+    cur[0] = F[L];
+#pragma unroll
+    for (int n = L - 1; n >= 0; --n) {
+        const int deg = L - n;          // nxt gets degrees 0..deg
+        nxt[0] = F[n];
+#pragma unroll
+        for (int N = 1; N <= deg; ++N) {
+#pragma unroll
+            for (int t = N; t >= 0; --t) {
+#pragma unroll
+                for (int u = N - t; u >= 0; --u) {
+                    const int v = N - t - u;
+                    double val;
+                    if (t > 0) {
+                        val = X * cur[hidx(t - 1, u, v)];
+                        if (t > 1) val += (t - 1) * cur[hidx(t - 2, u, v)];
+                    } else if (u > 0) {
+                        val = Y * cur[hidx(t, u - 1, v)];
+                        if (u > 1) val += (u - 1) * cur[hidx(t, u - 2, v)];
+                    } else {
+                        val = Z * cur[hidx(t, u, v - 1)];
+                        if (v > 1) val += (v - 1) * cur[hidx(t, u, v - 2)];
+                    }
+                    nxt[hidx(t, u, v)] = val;
+                }
+            }
+        }
+        if (n > 0) {
+#pragma unroll
+            for (int i = 0; i < nherm(deg); ++i) cur[i] = nxt[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < nherm(L); ++i) R[i] = nxt[i];
+}
+
+// ---------------------------------------------------------------------------------------
+// 1-D Hermite expansion coefficients with E^{00}_0 = 1 (the Gaussian product factor is kept
+// as a scalar by the caller).  E[(i*(LB+1)+j)*(LA+LB+1)+t]
+template <int LA, int LB>
+struct E1D {
+    static constexpr int NT = LA + LB + 1;
+    double e[(LA + 1) * (LB + 1) * NT];
+    MQC_HD double& at(int i, int j, int t) { return e[(i * (LB + 1) + j) * NT + t]; }
+    MQC_HD double get(int i, int j, int t) const { return e[(i * (LB + 1) + j) * NT + t]; }
+    MQC_HD void build(double xpa, double xpb, double hp /* 1/(2p) */)
+    {
+#pragma unroll
+        for (int k = 0; k < (LA + 1) * (LB + 1) * NT; ++k) e[k] = 0.0;
+        at(0, 0, 0) = 1.0;
+#pragma unroll
+        for (int i = 0; i <= LA; ++i) {
+            if (i > 0) {
+#pragma unroll
+                for (int t = 0; t <= i; ++t) {
+                    double v = xpa * get(i - 1, 0, t);
+                    if (t > 0) v += hp * get(i - 1, 0, t - 1);
+                    if (t + 1 <= i - 1) v += (t + 1) * get(i - 1, 0, t + 1);
+                    at(i, 0, t) = v;
+                }
+            }
+#pragma unroll
+            for (int j = 1; j <= LB; ++j) {
+#pragma unroll
+                for (int t = 0; t <= i + j; ++t) {
+                    double v = xpb * get(i, j - 1, t);
+                    if (t > 0) v += hp * get(i, j - 1, t - 1);
+                    if (t + 1 <= i + j - 1) v += (t + 1) * get(i, j - 1, t + 1);
+                    at(i, j, t) = v;
+                }
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// Cartesian -> real solid harmonic coefficients.  s and p shells carry their constant
+// (0.28209479..., 0.48860251...) inside the contraction coefficients (basis_norm.cpp), so
+// their transform is the identity; d uses libcint's table (mqc_libcint_ao_data.f90:43-52),
+// compile-time so that the zeros fold away; l >= 3 reads the packed table built on the host.
+MQC_HD constexpr int c2s_table_offset(int l)
+{
+    int off = 0;
+    for (int k = 0; k < l; ++k) off += nsph(k) * ncart(k);
+    return off;
+}
+
+template <int L>
+MQC_HD double c2s_coef(const double* __restrict__ table, int s, int c)
+{
+    if constexpr (L < 2) {
+        return s == c ? 1.0 : 0.0;
+    } else if constexpr (L == 2) {
+        constexpr double XY = 1.0925484305920792, Z2A = -0.31539156525252005, Z2B = 0.6307831305050401,
+                         X2Y2 = 0.5462742152960396;
+        constexpr double T[5][6] = {{0, XY, 0, 0, 0, 0}, {0, 0, 0, 0, XY, 0}, {Z2A, 0, 0, Z2A, 0, Z2B},
+                                    {0, 0, XY, 0, 0, 0}, {X2Y2, 0, 0, -X2Y2, 0, 0}};
+        return T[s][c];
+    } else {
+        return table[c2s_table_offset(L) + s * ncart(L) + c];
+    }
+}
+
+struct ShellRef {
+    int nprim;
+    const double* exps;     // [nprim]
+    const double* coefs;    // [nprim] normalised radial coefficients
+    double x, y, z;
+};
+
+// decode Cartesian component k of shell l -> (lx, ly, lz), libcint order
+MQC_HD void cart_lmn(int l, int k, int& lx, int& ly, int& lz)
+{
+    int r = 0;
+    while ((r + 1) * (r + 2) / 2 <= k) ++r;
+    lz = k - r * (r + 1) / 2;
+    ly = r - lz;
+    lx = l - r;
+}
+
+// classes whose Cartesian block is at most this many numbers are fully unrolled into registers;
+// larger ones keep rolled component loops (tables addressed at run time) to bound code size
+constexpr int ERI_UNROLL_LIMIT = 108;
+
+// ---------------------------------------------------------------------------------------
+// Contracted Cartesian ERI block (ab|cd), out[((ia*NCB+ib)*NCC+ic)*NCD+id] (accumulated
+// into a zeroed buffer by this routine).
+template <int LA, int LB, int LC, int LD>
+MQC_HD void eri_cart_block(const ShellRef& A, const ShellRef& B, const ShellRef& C, const ShellRef& D,
+                           const double* __restrict__ boys_table, double* out)
+{
+    constexpr int NCA = ncart(LA), NCB = ncart(LB), NCC = ncart(LC), NCD = ncart(LD);
+    constexpr int LAB = LA + LB, LCD = LC + LD, L = LAB + LCD;
+    constexpr int NHAB = nherm(LAB);
+    constexpr bool UNROLLED = (NCA * NCB * NCC * NCD <= ERI_UNROLL_LIMIT);
+    (void)LCD;
+    if constexpr (UNROLLED) {
+#pragma unroll
+        for (int i = 0; i < NCA * NCB * NCC * NCD; ++i) out[i] = 0.0;
+    } else {
+        for (int i = 0; i < NCA * NCB * NCC * NCD; ++i) out[i] = 0.0;
+    }
+
+    const double abx = A.x - B.x, aby = A.y - B.y, abz = A.z - B.z;
+    const double ab2 = abx * abx + aby * aby + abz * abz;
+    const double cdx = C.x - D.x, cdy = C.y - D.y, cdz = C.z - D.z;
+    const double cd2 = cdx * cdx + cdy * cdy + cdz * cdz;
+    constexpr double TWO_PI_25 = 34.986836655249725693;   // 2 pi^(5/2)
+
+    for (int ip = 0; ip < A.nprim; ++ip) {
+        const double a = A.exps[ip], ca = A.coefs[ip];
+        for (int jp = 0; jp < B.nprim; ++jp) {
+            const double b = B.exps[jp];
+            const double p = a + b, ip_ = 1.0 / p;
+            const double kab = exp(-a * b * ip_ * ab2) * ca * B.coefs[jp];
+            const double px = (a * A.x + b * B.x) * ip_, py = (a * A.y + b * B.y) * ip_, pz = (a * A.z + b * B.z) * ip_;
+            E1D<LA, LB> ex, ey, ez;
+            ex.build(px - A.x, px - B.x, 0.5 * ip_);
+            ey.build(py - A.y, py - B.y, 0.5 * ip_);
+            ez.build(pz - A.z, pz - B.z, 0.5 * ip_);
+            for (int kp = 0; kp < C.nprim; ++kp) {
+                const double c = C.exps[kp], cc = C.coefs[kp];
+                for (int lp = 0; lp < D.nprim; ++lp) {
+                    const double d = D.exps[lp];
+                    const double q = c + d, iq = 1.0 / q;
+                    const double kcd = exp(-c * d * iq * cd2) * cc * D.coefs[lp];
+                    const double qx = (c * C.x + d * D.x) * iq, qy = (c * C.y + d * D.y) * iq, qz = (c * C.z + d * D.z) * iq;
+                    E1D<LC, LD> fx, fy, fz;
+                    fx.build(qx - C.x, qx - D.x, 0.5 * iq);
+                    fy.build(qy - C.y, qy - D.y, 0.5 * iq);
+                    fz.build(qz - C.z, qz - D.z, 0.5 * iq);
+                    const double alpha = p * q / (p + q);
+                    const double pref = TWO_PI_25 * ip_ * iq / sqrt(p + q) * kab * kcd;
+                    double R[nherm(L)];
+                    hermite_r<L>(alpha, px - qx, py - qy, pz - qz, boys_table, R);
+
+                    if constexpr (UNROLLED) {
+                        // loop over ket components; for each, G[h] over bra Hermite indices
+                        int icd = 0;
+#pragma unroll
+                        for (int cx = LC; cx >= 0; --cx) {
+#pragma unroll
+                            for (int cy = LC - cx; cy >= 0; --cy) {
+                                const int cz = LC - cx - cy;
+#pragma unroll
+                                for (int dx = LD; dx >= 0; --dx) {
+#pragma unroll
+                                    for (int dy = LD - dx; dy >= 0; --dy) {
+                                        const int dz = LD - dx - dy;
+                                        double G[NHAB];
+#pragma unroll
+                                        for (int h = 0; h < NHAB; ++h) G[h] = 0.0;
+#pragma unroll
+                                        for (int tt = 0; tt <= cx + dx; ++tt) {
+#pragma unroll
+                                            for (int uu = 0; uu <= cy + dy; ++uu) {
+#pragma unroll
+                                                for (int ww = 0; ww <= cz + dz; ++ww) {
+                                                    double f = fx.get(cx, dx, tt) * fy.get(cy, dy, uu) * fz.get(cz, dz, ww);
+                                                    if ((tt + uu + ww) & 1) f = -f;
+#pragma unroll
+                                                    for (int N = 0; N <= LAB; ++N) {
+#pragma unroll
+                                                        for (int t = N; t >= 0; --t) {
+#pragma unroll
+                                                            for (int u = N - t; u >= 0; --u) {
+                                                                const int v = N - t - u;
+                                                                G[hidx(t, u, v)] += f * R[hidx(t + tt, u + uu, v + ww)];
+                                                            }
+                                                        }
+                                                    }
+                                                }
+                                            }
+                                        }
+                                        // out[ab][cd] += pref * sum_h Eab[h] G[h]
+                                        int iab = 0;
+#pragma unroll
+                                        for (int ax = LA; ax >= 0; --ax) {
+#pragma unroll
+                                            for (int ay = LA - ax; ay >= 0; --ay) {
+                                                const int az = LA - ax - ay;
+#pragma unroll
+                                                for (int bx = LB; bx >= 0; --bx) {
+#pragma unroll
+                                                    for (int by = LB - bx; by >= 0; --by) {
+                                                        const int bz = LB - bx - by;
+                                                        double s = 0.0;
+#pragma unroll
+                                                        for (int t = 0; t <= ax + bx; ++t) {
+#pragma unroll
+                                                            for (int u = 0; u <= ay + by; ++u) {
+#pragma unroll
+                                                                for (int v = 0; v <= az + bz; ++v) {
+                                                                    s += ex.get(ax, bx, t) * ey.get(ay, by, u) * ez.get(az, bz, v) *
+                                                                         G[hidx(t, u, v)];
+                                                                }
+                                                            }
+                                                        }
+                                                        out[iab * (NCC * NCD) + icd] += pref * s;
+                                                        ++iab;
+                                                    }
+                                                }
+                                            }
+                                        }
+                                        ++icd;
+                                    }
+                                }
+                            }
+                        }
+                    } else {
+                        // rolled form for the large classes: same arithmetic, run-time component indices
+#pragma unroll 1
+                        for (int icd = 0; icd < NCC * NCD; ++icd) {
+                            int cx, cy, cz, dx, dy, dz;
+                            cart_lmn(LC, icd / NCD, cx, cy, cz);
+                            cart_lmn(LD, icd % NCD, dx, dy, dz);
+                            double G[NHAB];
+                            for (int h = 0; h < NHAB; ++h) G[h] = 0.0;
+                            for (int tt = 0; tt <= cx + dx; ++tt)
+                                for (int uu = 0; uu <= cy + dy; ++uu)
+                                    for (int ww = 0; ww <= cz + dz; ++ww) {
+                                        double f = fx.get(cx, dx, tt) * fy.get(cy, dy, uu) * fz.get(cz, dz, ww);
+                                        if ((tt + uu + ww) & 1) f = -f;
+                                        for (int N = 0; N <= LAB; ++N)
+                                            for (int t = N; t >= 0; --t)
+                                                for (int u = N - t; u >= 0; --u) {
+                                                    const int v = N - t - u;
+                                                    G[hidx(t, u, v)] += f * R[hidx(t + tt, u + uu, v + ww)];
+                                                }
+                                    }
+#pragma unroll 1
+                            for (int iab = 0; iab < NCA * NCB; ++iab) {
+                                int ax, ay, az, bx, by, bz;
+                                cart_lmn(LA, iab / NCB, ax, ay, az);
+                                cart_lmn(LB, iab % NCB, bx, by, bz);
+                                double s = 0.0;
+                                for (int t = 0; t <= ax + bx; ++t)
+                                    for (int u = 0; u <= ay + by; ++u)
+                                        for (int v = 0; v <= az + bz; ++v)
+                                            s += ex.get(ax, bx, t) * ey.get(ay, by, u) * ez.get(az, bz, v) * G[hidx(t, u, v)];
+                                out[iab * (NCC * NCD) + icd] += pref * s;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace mqc

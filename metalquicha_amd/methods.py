@@ -1,0 +1,282 @@
+"""Method layer: the host-side mirror of the reference's L3 boundary for the SCF hot path.
+
+  PhysicalFragment    <- physical_fragment_t   (src/fragmentation/common/mqc_physical_fragment.f90:45-94)
+  ScfSettings         <- cuest_scf_settings_t  (src/methods/mqc_cuest_iface.f90:35-142)
+  CalculationResult   <- calculation_result_t  (src/core/mqc_result_types.f90:92-196), the fields
+                         run_cuest_scf fills (backends/cuest/backend/mqc_cuest_driver.f90:211-275)
+  run_hip_scf         <- run_cuest_scf         (backends/cuest/backend/mqc_cuest_bridge.f90:32-39)
+  hip_backend_available <- cuest_backend_available (:20-30)
+  HFMethod.calc_energy  <- hf_calc_energy / hf_run (src/methods/mqc_method_hf.F90:113-217)
+  run_hip_scf_batch   <- the batch-submit entry the worker loop would use
+
+Same names, argument meaning and error behaviour; the numerics all happen in libmqc_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import capi
+from .basis import ANGSTROM_TO_BOHR, FlatBasis, build_flat_basis, BasisError, SYMBOL_TO_Z
+
+SCF_NOT_RUN, SCF_CONVERGED, SCF_NOT_CONVERGED = capi.SCF_NOT_RUN, capi.SCF_CONVERGED, capi.SCF_NOT_CONVERGED
+BACKEND_AUTO, BACKEND_HIP, BACKEND_LIBCINT = 0, 1, 2
+
+
+def parse_backend_name(name: str) -> int:
+    """auto|hip|gpu|cuest -> this engine; libcint|cpu -> the CPU backend (not part of this repo).
+    Mirrors parse_backend_name, src/methods/mqc_cuest_iface.f90:146-180."""
+    n = (name or "auto").strip().lower()
+    if n in ("auto",):
+        return BACKEND_AUTO
+    if n in ("hip", "gpu", "cuest", "mi355x"):
+        return BACKEND_HIP
+    if n in ("libcint", "cpu"):
+        return BACKEND_LIBCINT
+    raise ValueError("unknown backend '%s'" % name)
+
+
+@dataclass
+class PhysicalFragment:
+    element_numbers: np.ndarray           # (n_atoms,) int
+    coordinates: np.ndarray               # (3, n_atoms) Bohr, column per atom like the reference
+    charge: int = 0
+    multiplicity: int = 1
+    ghost: Optional[np.ndarray] = None    # (n_atoms,) bool
+    nelec: Optional[int] = None
+
+    def __post_init__(self):
+        self.element_numbers = np.asarray(self.element_numbers, dtype=np.int32)
+        self.coordinates = np.asarray(self.coordinates, dtype=np.float64)
+        if self.coordinates.shape != (3, len(self.element_numbers)):
+            raise ValueError("coordinates must be (3, n_atoms) in Bohr")
+        if self.ghost is not None:
+            self.ghost = np.asarray(self.ghost, dtype=bool)
+        if self.nelec is None:
+            real = self.element_numbers if self.ghost is None else self.element_numbers[~self.ghost]
+            self.nelec = int(np.sum(real)) - int(self.charge)     # compute_nelec, :73-83
+
+    @property
+    def n_atoms(self) -> int:
+        return int(len(self.element_numbers))
+
+    @classmethod
+    def from_angstrom(cls, symbols: Sequence[str], xyz_angstrom, **kw) -> "PhysicalFragment":
+        z = [SYMBOL_TO_Z[s.lower()] for s in symbols]
+        xyz = np.asarray(xyz_angstrom, dtype=np.float64).reshape(-1, 3) * ANGSTROM_TO_BOHR
+        return cls(np.array(z), xyz.T.copy(), **kw)
+
+
+@dataclass
+class ScfSettings:
+    basis_set: str = "sto-3g"
+    aux_basis_set: str = "def2-universal-jkfit"
+    density_fitting: bool = False
+    functional: str = ""
+    spherical: bool = True
+    verbose: bool = False
+    guess: str = "auto"
+    device_rank: int = 0
+    unrestricted: bool = False
+    allow_crap_scf: bool = False
+    max_iter: int = 100
+    energy_tol: float = 1.0e-8
+    density_tol: float = 1.0e-6
+    use_diis: bool = True
+    diis_size: int = 8
+    grid_level: int = 3
+    radial_points: int = 0
+    angular_points: int = 0
+    backend: int = BACKEND_AUTO
+    schwarz_tol: float = 0.0
+
+
+@dataclass
+class EnergyT:
+    scf: float = 0.0
+
+    def total(self) -> float:
+        return self.scf
+
+
+@dataclass
+class CalculationResult:
+    energy: EnergyT = field(default_factory=EnergyT)
+    has_energy: bool = False
+    scf_status: int = SCF_NOT_RUN
+    scf_iterations: int = 0
+    homo: float = 0.0
+    lumo: float = 0.0
+    has_orbitals: bool = False
+    has_error: bool = False
+    error_code: int = 0
+    error_message: str = ""
+    distance: float = 0.0
+    e_nuclear: float = 0.0
+    e_electronic: float = 0.0
+    orbital_energies: Optional[np.ndarray] = None
+
+
+_GUESS = {"auto": capi.GUESS_AUTO, "gwh": capi.GUESS_GWH, "core": capi.GUESS_CORE}
+
+
+def hip_backend_available() -> bool:
+    try:
+        return bool(capi.load_library().mqc_hip_backend_available())
+    except capi.HipBackendError:
+        return False
+
+
+def _options(settings: ScfSettings, want_gradient: bool) -> capi.ScfOptions:
+    o = capi.default_options()
+    o.functional = settings.functional.encode()[:31]
+    o.density_fitting = int(settings.density_fitting)
+    o.grid_level = settings.grid_level
+    o.radial_points = settings.radial_points
+    o.angular_points = settings.angular_points
+    o.max_iter = settings.max_iter
+    o.energy_tol = settings.energy_tol
+    o.density_tol = settings.density_tol
+    o.use_diis = int(settings.use_diis)
+    o.diis_size = settings.diis_size
+    g = settings.guess.strip().lower()
+    if g not in _GUESS:
+        # the cuEST path refuses guesses it does not implement rather than running another one
+        raise capi.HipBackendError(capi.ERR_UNSUPPORTED, "initial guess '%s' is not available on the HIP backend "
+                                                         "(core, gwh, auto)" % settings.guess)
+    o.guess = _GUESS[g]
+    o.unrestricted = int(settings.unrestricted)
+    o.want_gradient = int(want_gradient)
+    o.allow_crap_scf = int(settings.allow_crap_scf)
+    o.verbose = int(settings.verbose)
+    o.schwarz_tol = settings.schwarz_tol
+    return o
+
+
+class _Marshalled:
+    """Keeps the numpy arrays alive for as long as the C structs that point into them."""
+
+    def __init__(self, fragment: PhysicalFragment, fb: FlatBasis):
+        self.z = np.ascontiguousarray(fragment.element_numbers, dtype=np.int32)
+        self.xyz = np.ascontiguousarray(fragment.coordinates.T, dtype=np.float64)   # atom-major
+        self.ghost = None if fragment.ghost is None else np.ascontiguousarray(fragment.ghost, dtype=np.uint8)
+        self.fb = fb
+        self.mol = capi.Molecule(fragment.n_atoms, self.z.ctypes.data_as(capi.c_int32_p), capi.dptr(self.xyz),
+                                 None if self.ghost is None else self.ghost.ctypes.data_as(capi.c_uint8_p),
+                                 int(fragment.charge), int(fragment.multiplicity), int(fragment.nelec))
+        self.bas = capi.Basis(1 if fb.spherical else 0, fragment.n_atoms,
+                              fb.nshell_per_atom.ctypes.data_as(capi.c_int64_p), fb.nshell,
+                              fb.shell_l.ctypes.data_as(capi.c_int32_p), fb.shell_nprim.ctypes.data_as(capi.c_int32_p),
+                              capi.dptr(fb.exps), capi.dptr(fb.coefs))
+
+
+_BASIS_CACHE = {}
+
+
+def _flat_basis(name: str, fragment: PhysicalFragment) -> FlatBasis:
+    # flattened shells cached per (basis, element sequence): SURVEY.md 8f item 4
+    key = (name.lower(), tuple(int(z) for z in fragment.element_numbers))
+    if key not in _BASIS_CACHE:
+        _BASIS_CACHE[key] = build_flat_basis(name, fragment.element_numbers)
+    return _BASIS_CACHE[key]
+
+
+def _fill(result: CalculationResult, r: capi.ScfResult, eps: Optional[np.ndarray]) -> CalculationResult:
+    result.scf_status = int(r.scf_status)
+    result.scf_iterations = int(r.iterations)
+    if r.has_error:
+        # driver: result%error%set(...), has_error = .true., has_energy = .false. (:385-393)
+        result.has_error = True
+        result.error_code = capi.ERR_GENERIC
+        result.error_message = r.message.decode(errors="replace")
+        result.has_energy = False
+        return result
+    result.energy.scf = float(r.e_total)
+    result.e_nuclear = float(r.e_nuclear)
+    result.e_electronic = float(r.e_electronic)
+    result.has_energy = True
+    result.homo = float(r.homo)
+    result.lumo = float(r.lumo)
+    result.has_orbitals = bool(r.has_orbitals)
+    if eps is not None:
+        result.orbital_energies = eps[: int(r.n_mo)].copy()
+    return result
+
+
+def run_hip_scf(settings: ScfSettings, fragment: PhysicalFragment, result: Optional[CalculationResult] = None,
+                want_gradient: bool = False) -> CalculationResult:
+    """One fragment through the engine: the drop-in for run_cuest_scf."""
+    result = result if result is not None else CalculationResult()
+    try:
+        lib = capi.load_library()
+        ctx = capi.get_context(settings.device_rank)
+        opts = _options(settings, want_gradient)
+        fb = _flat_basis(settings.basis_set, fragment)
+        m = _Marshalled(fragment, fb)
+        eps = np.zeros(fb.nao)
+        r = capi.ScfResult()
+        r.orbital_energies = capi.dptr(eps)
+        rc = lib.mqc_hip_scf_run(ctx, C.byref(m.mol), C.byref(m.bas), None, C.byref(opts), C.byref(r))
+        if rc != capi.MQC_HIP_OK and not r.has_error:
+            capi.check(rc)
+        return _fill(result, r, eps)
+    except (capi.HipBackendError, BasisError) as e:
+        result.has_error = True
+        result.has_energy = False
+        result.error_code = getattr(e, "code", capi.ERR_VALIDATION)
+        result.error_message = str(getattr(e, "message", e))
+        return result
+
+
+def run_hip_scf_batch(settings: ScfSettings, fragments: Sequence[PhysicalFragment]) -> List[CalculationResult]:
+    """Many independent fragments in one call (mqc_hip_scf_run_batch)."""
+    n = len(fragments)
+    results = [CalculationResult() for _ in range(n)]
+    if n == 0:
+        return results
+    lib = capi.load_library()
+    ctx = capi.get_context(settings.device_rank)
+    opts = _options(settings, False)
+    ms = [_Marshalled(f, _flat_basis(settings.basis_set, f)) for f in fragments]
+    mols = (capi.Molecule * n)(*[m.mol for m in ms])
+    bass = (capi.Basis * n)(*[m.bas for m in ms])
+    res = (capi.ScfResult * n)()
+    rc = lib.mqc_hip_scf_run_batch(ctx, n, mols, bass, None, C.byref(opts), res)
+    if rc != capi.MQC_HIP_OK and not any(r.has_error for r in res):
+        capi.check(rc)
+    for out, r in zip(results, res):
+        _fill(out, r, None)
+    return results
+
+
+class HFMethod:
+    """qc_method_t for Hartree-Fock (src/methods/mqc_method_base.f90:13-60, mqc_method_hf.F90)."""
+
+    def __init__(self, settings: Optional[ScfSettings] = None, **kw):
+        self.settings = settings or ScfSettings(**kw)
+
+    def calc_energy(self, fragment: PhysicalFragment, result: Optional[CalculationResult] = None) -> CalculationResult:
+        backend = self.settings.backend
+        if backend == BACKEND_LIBCINT:
+            r = result or CalculationResult()
+            r.has_error = True
+            r.error_message = "the libcint CPU backend is not part of this build; use backend hip|auto"
+            return r
+        return run_hip_scf(self.settings, fragment, result)
+
+    def calc_gradient(self, fragment, result=None):
+        r = result or CalculationResult()
+        r.has_error = True
+        r.error_message = "analytic gradients are not available in this build of the HIP backend"
+        return r
+
+    calc_hessian = calc_gradient
+
+
+def get_stats() -> capi.Stats:
+    st = capi.Stats()
+    capi.check(capi.load_library().mqc_hip_get_stats(capi.get_context(), C.byref(st)))
+    return st

@@ -1,0 +1,163 @@
+"""GPU parity tests: every stage of the hot path through the C ABI against the CPU oracle.
+
+Tolerances: the reference's own direct-vs-in-core bound is 1e-11 elementwise
+(test/test_mqc_libcint_direct.f90:139); total energies must agree to <= 1e-8 Eh per fragment
+(BASELINE.json north_star) and the known-answer programs assert 1e-9.
+"""
+import numpy as np
+import pytest
+
+from metalquicha_amd import methods, stages
+from oracle import scf_oracle as so
+from tests.helpers import fragment_bohr, oracle_mol, water_at, synthetic_density
+
+pytestmark = pytest.mark.gpu
+
+WATER = ([8, 1, 1], [[0.0, 0.0, -0.1364652], [0.0, 1.4304924, 1.0826636], [0.0, -1.4304924, 1.0826636]])
+
+
+def test_backend_available():
+    assert methods.hip_backend_available()
+
+
+@pytest.mark.parametrize("basis", ["sto-3g-check_rhf", "cc-pvdz"])
+def test_int1e_matches_oracle(basis):
+    frag = fragment_bohr(*WATER)
+    S, T, V = stages.int1e(basis, frag)
+    So, To, Vo = so.int1e(oracle_mol(basis, frag))
+    assert np.max(np.abs(S - So)) < 1e-12
+    assert np.max(np.abs(T - To)) < 1e-11
+    assert np.max(np.abs(V - Vo)) < 1e-10
+    assert np.allclose(np.diag(S), 1.0, atol=1e-12)
+
+
+@pytest.mark.parametrize("basis", ["sto-3g-check_rhf", "cc-pvdz"])
+def test_eri_packed_matches_oracle(basis):
+    frag = fragment_bohr(*WATER)
+    M = stages.eri_packed(basis, frag)
+    ref = stages.pack_eri(so.eri4(oracle_mol(basis, frag)))
+    assert M.shape == ref.shape
+    assert np.max(np.abs(M - ref)) < 1e-11
+    assert np.max(np.abs(M - M.T)) == 0.0
+
+
+def test_eri_schwarz_screening_only_drops_small():
+    rng = np.random.default_rng(3)
+    xyz = np.vstack([water_at(rng, [0, 0, 0]), water_at(rng, [12.0, 0, 0])])
+    frag = fragment_bohr([8, 1, 1, 8, 1, 1], xyz)
+    full = stages.eri_packed("sto-3g", frag)
+    scr = stages.eri_packed("sto-3g", frag, schwarz_tol=1e-9)
+    assert np.max(np.abs(full - scr)) < 1e-9
+    assert np.count_nonzero(scr) < np.count_nonzero(full)
+
+
+@pytest.mark.parametrize("basis", ["sto-3g-check_rhf", "cc-pvdz"])
+def test_jk_incore_matches_oracle(basis):
+    frag = fragment_bohr(*WATER)
+    mol = oracle_mol(basis, frag)
+    D = synthetic_density(mol.nao)
+    J, K = stages.jk_incore(basis, frag, D)
+    Jo, Ko = so.build_jk_incore(so.eri4(mol), D)
+    assert np.max(np.abs(J - Jo)) < 1e-11
+    assert np.max(np.abs(K - Ko)) < 1e-11
+
+
+@pytest.mark.parametrize("n", [2, 7, 24, 25, 48, 86, 114])
+def test_syev_matches_lapack(n):
+    rng = np.random.default_rng(n)
+    A = rng.normal(size=(n, n)); A = 0.5 * (A + A.T)
+    w, V = stages.syev(A)
+    wr = np.linalg.eigvalsh(A)
+    assert np.max(np.abs(w - wr)) < 1e-12 * max(1.0, np.max(np.abs(wr)))
+    assert np.max(np.abs(V.T @ V - np.eye(n))) < 1e-12
+    assert np.max(np.abs(A @ V - V * w[None, :])) < 1e-11
+
+
+def test_diis_coefficients_match_reference_algorithm():
+    rng = np.random.default_rng(11)
+    for n in (2, 3, 5, 8):
+        E = rng.normal(size=(n, 40)) * 1e-4
+        B = E @ E.T
+        c, ok = stages.diis_coefficients(B)
+        d = so.Diis(n, 1, 40)
+        for k in range(n):
+            d.push(np.zeros(1), E[k])
+        ref = d.coefficients()
+        assert ok and ref is not None
+        assert abs(np.sum(c) - 1.0) < 1e-10
+        assert np.max(np.abs(c - ref[:n])) < 1e-9 * max(1.0, np.max(np.abs(ref[:n])))
+    c, ok = stages.diis_coefficients(np.array([[1.0]]))
+    assert not ok          # fewer than two vectors: no extrapolation
+
+
+def test_check_rhf_goldens():
+    """validation/check_rhf.f90:79-143: H2 -1.1167143251, H2O -74.9658162796 (1e-9)."""
+    st = methods.ScfSettings(basis_set="sto-3g-check_rhf", energy_tol=1e-10, density_tol=1e-8, guess="gwh")
+    h2 = methods.run_hip_scf(st, fragment_bohr([1, 1], [[0, 0, 0], [0, 0, 1.4]]))
+    assert not h2.has_error, h2.error_message
+    assert abs(h2.e_nuclear - 1.0 / 1.4) < 1e-12
+    assert abs(h2.energy.scf - (-1.1167143251)) < 1e-9
+    w = methods.run_hip_scf(st, fragment_bohr(*WATER))
+    assert not w.has_error, w.error_message
+    assert w.scf_status == methods.SCF_CONVERGED
+    assert abs(w.energy.scf - (-74.9658162796)) < 1e-9
+    # DIIS changes the iteration count and nothing else
+    st0 = methods.ScfSettings(basis_set="sto-3g-check_rhf", energy_tol=1e-10, density_tol=1e-8, guess="gwh",
+                              use_diis=False, max_iter=200)
+    w0 = methods.run_hip_scf(st0, fragment_bohr(*WATER))
+    assert abs(w0.energy.scf - w.energy.scf) < 1e-9
+    assert w.scf_iterations < w0.scf_iterations
+
+
+def test_check_df_exact_golden_and_oracle_iterations():
+    """validation/check_df.f90:55-57: H2O/cc-pVDZ exact-ERI RHF -76.0220988827 (1e-9)."""
+    st = methods.ScfSettings(basis_set="cc-pvdz", energy_tol=1e-11, density_tol=1e-9, guess="gwh", max_iter=200)
+    frag = fragment_bohr(*WATER)
+    r = methods.run_hip_scf(st, frag)
+    assert not r.has_error, r.error_message
+    assert abs(r.energy.scf - (-76.0220988827)) < 1e-9
+    o = so.run_rhf(oracle_mol("cc-pvdz", frag), 10, 200, 1e-11, 1e-9)
+    assert abs(r.energy.scf - o.energy) < 1e-10
+    assert r.scf_iterations == o.iterations
+    assert abs(r.homo - o.eps[4]) < 1e-8 and abs(r.lumo - o.eps[5]) < 1e-8
+
+
+def test_batch_of_mixed_fragments_matches_oracle():
+    """Monomers and dimers in ONE batch call; each fragment within 1e-8 Eh of the oracle."""
+    rng = np.random.default_rng(20260821)
+    ws = [water_at(rng, c) for c in ([0, 0, 0], [5.6, 0.3, 0.2], [0.1, 5.9, -0.4])]
+    frags = [fragment_bohr([8, 1, 1], w) for w in ws]
+    frags += [fragment_bohr([8, 1, 1, 8, 1, 1], np.vstack([ws[i], ws[j]])) for i, j in ((0, 1), (0, 2), (1, 2))]
+    st = methods.ScfSettings(basis_set="sto-3g", energy_tol=1e-10, density_tol=1e-8, guess="gwh")
+    res = methods.run_hip_scf_batch(st, frags)
+    for f, r in zip(frags, res):
+        assert not r.has_error, r.error_message
+        o = so.run_rhf(oracle_mol("sto-3g", f), int(f.nelec), 100, 1e-10, 1e-8)
+        assert abs(r.energy.scf - o.energy) < 1e-9, (r.energy.scf, o.energy)
+        assert r.scf_iterations == o.iterations
+
+
+def test_water_dimer_ccpvdz_matches_oracle():
+    rng = np.random.default_rng(5)
+    xyz = np.vstack([water_at(rng, [0, 0, 0]), water_at(rng, [5.5, 0.5, -0.3])])
+    frag = fragment_bohr([8, 1, 1, 8, 1, 1], xyz)
+    st = methods.ScfSettings(basis_set="cc-pvdz", energy_tol=1e-10, density_tol=1e-8, guess="gwh")
+    r = methods.run_hip_scf(st, frag)
+    assert not r.has_error, r.error_message
+    o = so.run_rhf(oracle_mol("cc-pvdz", frag), 20, 100, 1e-10, 1e-8)
+    assert abs(r.energy.scf - o.energy) < 1e-8
+    assert r.scf_iterations == o.iterations
+
+
+def test_refusals_match_reference_behaviour():
+    st = methods.ScfSettings(basis_set="sto-3g", unrestricted=True)
+    r = methods.run_hip_scf(st, fragment_bohr(*WATER))
+    assert r.has_error and not r.has_energy
+    st = methods.ScfSettings(basis_set="sto-3g", max_iter=2, energy_tol=1e-12, density_tol=1e-12)
+    r = methods.run_hip_scf(st, fragment_bohr(*WATER))
+    assert r.scf_status == methods.SCF_NOT_CONVERGED and r.has_error     # not converged is an error ...
+    st.allow_crap_scf = True
+    r = methods.run_hip_scf(st, fragment_bohr(*WATER))
+    assert r.scf_status == methods.SCF_NOT_CONVERGED and not r.has_error and r.has_energy   # ... unless allowed
+    oh = methods.run_hip_scf(methods.ScfSettings(basis_set="sto-3g"), fragment_bohr([8, 1], [[0, 0, 0], [0, 0, 1.8]]))
+    assert oh.has_error      # odd electron count
