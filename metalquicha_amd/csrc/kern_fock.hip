@@ -8,15 +8,19 @@
 // Roofline: HBM-bound.  Per fragment and iteration it streams the pair matrix
 // M[pair(i,j)][pair(k,l)] exactly once (npair^2 * 8 bytes; 11.06 MB for n = 48) and performs
 // 5 FMAs per element (1 for J, 4 for the two symmetric mat-vecs of K) = 1.25 flop/byte, far
-// below the FP64 ridge (~10 flop/byte), so the design goal is coalesced full-rate streaming:
-//   * a wave owns one row pair(i,j): 64 lanes read it contiguously from HBM into LDS
-//     (shell-pair-blocked data staged through LDS, as the north star asks);
-//   * J_ij is the dot product of that row with the packed density (2 - delta_kl) D_kl;
-//   * the row is the packed lower triangle of the symmetric n x n matrix V^{ij}_{kl} = (ij|kl);
+// below the FP64 ridge (~10 flop/byte), so the design goal is full-rate coalesced streaming
+// with enough bytes in flight per CU to cover HBM latency:
+//   * a wave owns one row pair(i,j); its 64 lanes read the row contiguously, ALL of the row's
+//     loads issued back to back into registers (up to 19 x 512 B in flight per wave), and the
+//     NEXT row's loads are issued before the current row is consumed (register double buffer);
+//   * the row is staged in the wave's private LDS buffer (shell-pair-blocked data staged through
+//     LDS, as the north star asks); no workgroup barrier is involved: a wave only ever reads
+//     its own buffer, and DS operations of one wave execute in order;
+//   * J_ij is the dot product of the row with the packed density (2 - delta_kl) D_kl;
+//   * the row is the packed lower triangle of the symmetric matrix V^{ij}_{kl} = (ij|kl);
 //     K[i,:] += V^{ij} D[:,j] and K[j,:] += V^{ij} D[:,i] are evaluated from LDS with lane <-> k,
 //     so the 2x expansion packed -> square never touches HBM;
 //   * K is accumulated per workgroup in LDS (ds_add_f64) and flushed once with global atomics.
-// A workgroup (4 waves) keeps D of its fragment in LDS and walks a strided set of rows.
 #include "engine.hpp"
 
 namespace mqc {
@@ -28,8 +32,59 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-// KCH = ceil(n / 64): how many k values a lane owns.  DLDS: D, packed D' and the K accumulator live in LDS.
-template <int KCH, bool DLDS, int NW>
+__device__ __forceinline__ void unpack_pair(int idx, int& k, int& l)
+{
+    k = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+    while ((k + 1) * (k + 2) / 2 <= idx) ++k;
+    while (k * (k + 1) / 2 > idx) --k;
+    l = idx - k * (k + 1) / 2;
+}
+
+__device__ __forceinline__ double readlane_f64(double x, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+    return __hiloint2double(hi, lo);
+}
+
+// One wave's K work for the row held in `rowbuf` (packed lower triangle of V^{ij}).
+// DREG (n <= 64): lane l holds D[i,l] and D[j,l] in registers and the loop broadcasts them with
+// v_readlane; otherwise the two density rows are read through the pointers Di, Dj.
+template <int KCH, bool DREG>
+__device__ __forceinline__ void row_exchange(const double* __restrict__ rowbuf, const double* __restrict__ Di,
+                                             const double* __restrict__ Dj, int n, int lane, double* acc_i, double* acc_j)
+{
+#pragma unroll
+    for (int c = 0; c < KCH; ++c) { acc_i[c] = 0.0; acc_j[c] = 0.0; }
+    double di_reg = 0.0, dj_reg = 0.0;
+    if (DREG) {
+        const int ll = lane < n ? lane : n - 1;
+        di_reg = Di[ll]; dj_reg = Dj[ll];
+    }
+    int lbase = 0;
+#pragma unroll 4
+    for (int l = 0; l < n; ++l) {
+        const double dil = DREG ? readlane_f64(di_reg, l) : Di[l];
+        const double djl = DREG ? readlane_f64(dj_reg, l) : Dj[l];
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            const int k = lane + 64 * c;
+            // lanes beyond n read a valid (clamped) address and are discarded at the flush
+            const int kk = k < n ? k : n - 1;
+            const int idx = kk >= l ? (kk * (kk + 1) / 2 + l) : (lbase + kk);
+            const double v = rowbuf[idx];
+            acc_i[c] += v * djl;
+            acc_j[c] += v * dil;
+        }
+        lbase += l + 1;
+    }
+}
+
+// MAXU > 0: register-prefetch variant, a row is at most MAXU*64 doubles.
+// MAXU == 0: generic variant, the row is loaded in chunks of 16 x 64.
+// KCH = ceil(n / 64).  KLDS: the K accumulator lives in LDS; DREG: density rows through registers
+// (n <= 64), else a copy of D sits in LDS next to K (KLDS) or is read from global memory.
+template <int KCH, bool KLDS, int NW, int MAXU, bool DREG>
 __global__ void __launch_bounds__(64 * NW) jk_incore_kernel(BatchView bv, int only_active)
 {
     extern __shared__ double lds[];
@@ -38,111 +93,129 @@ __global__ void __launch_bounds__(64 * NW) jk_incore_kernel(BatchView bv, int on
     const int n = bv.n, np = bv.npair;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NTH = 64 * NW;
     const double* __restrict__ Dg = bv.D + (size_t)f * n * n;
     double* __restrict__ Jg = bv.J + (size_t)f * n * n;
     double* __restrict__ Kg = bv.K + (size_t)f * n * n;
     const double* __restrict__ M = bv.eri + (size_t)f * np * np;
 
-    // LDS carve-up
-    constexpr int NTH = 64 * NW;
-    double* rowbuf = lds + (size_t)wave * np;        // NW row buffers
-    double* Dp = lds + (size_t)NW * np;               // packed (2 - delta) D, np
-    double* Dl = Dp + np;                            // n*n   (DLDS only)
-    double* Kl = Dl + (DLDS ? n * n : 0);            // n*n   (DLDS only)
+    double* rowbuf = lds + (size_t)wave * np;        // NW private row buffers
+    double* Dp = lds + (size_t)NW * np;               // packed (2 - delta) D
+    double* Dl = Dp + np;                             // n*n (KLDS && !DREG)
+    double* Kl = Dl + ((KLDS && !DREG) ? n * n : 0);  // n*n (KLDS)
 
     for (int idx = tid; idx < np; idx += NTH) {
-        // unpack idx -> (k,l), k >= l
-        int k = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
-        while ((k + 1) * (k + 2) / 2 <= idx) ++k;
-        while (k * (k + 1) / 2 > idx) --k;
-        const int l = idx - k * (k + 1) / 2;
+        int k, l;
+        unpack_pair(idx, k, l);
         const double d = Dg[k * n + l];
         Dp[idx] = (k == l) ? d : 2.0 * d;
     }
-    if (DLDS) {
-        for (int idx = tid; idx < n * n; idx += NTH) { Dl[idx] = Dg[idx]; Kl[idx] = 0.0; }
+    if (KLDS) {
+        for (int idx = tid; idx < n * n; idx += NTH) { if (!DREG) Dl[idx] = Dg[idx]; Kl[idx] = 0.0; }
     }
+    const double* Dsrc = (KLDS && !DREG) ? Dl : Dg;
     __syncthreads();
 
-    const int rows_per_iter = gridDim.x * NW;
-    const int iters = (np + rows_per_iter - 1) / rows_per_iter;
-    for (int it = 0; it < iters; ++it) {
-        const int row = it * rows_per_iter + blockIdx.x * NW + wave;
-        const bool active = row < np;
-        int i = 0, j = 0;
-        double accj = 0.0;
-        if (active) {
-            i = (int)((sqrt(8.0 * row + 1.0) - 1.0) * 0.5);
-            while ((i + 1) * (i + 2) / 2 <= row) ++i;
-            while (i * (i + 1) / 2 > row) --i;
-            j = row - i * (i + 1) / 2;
+    const int stride = gridDim.x * NW;
+    int row = blockIdx.x * NW + wave;
+
+    if constexpr (MAXU > 0) {
+        double v[MAXU];
+        if (row < np) {
             const double* __restrict__ src = M + (size_t)row * np;
-            for (int idx = lane; idx < np; idx += 64) {
-                const double v = src[idx];
-                rowbuf[idx] = v;
-                accj += v * Dp[idx];
-            }
+#pragma unroll
+            for (int u = 0; u < MAXU; ++u) { const int idx = lane + 64 * u; v[u] = idx < np ? src[idx] : 0.0; }
         }
-        __syncthreads();
-        if (active) {
+        while (row < np) {
+            int i, j;
+            unpack_pair(row, i, j);
+            double accj = 0.0;
+#pragma unroll
+            for (int u = 0; u < MAXU; ++u) {
+                const int idx = lane + 64 * u;
+                if (idx < np) { rowbuf[idx] = v[u]; accj += v[u] * Dp[idx]; }
+            }
+            // issue the next row's loads now; they complete while this row is being contracted
+            const int nrow = row + stride;
+            if (nrow < np) {
+                const double* __restrict__ src = M + (size_t)nrow * np;
+#pragma unroll
+                for (int u = 0; u < MAXU; ++u) { const int idx = lane + 64 * u; v[u] = idx < np ? src[idx] : 0.0; }
+            }
             accj = wave_sum(accj);
             if (lane == 0) { Jg[i * n + j] = accj; Jg[j * n + i] = accj; }
             double acc_i[KCH], acc_j[KCH];
-            int kbase[KCH];
-#pragma unroll
-            for (int c = 0; c < KCH; ++c) {
-                acc_i[c] = 0.0; acc_j[c] = 0.0;
-                const int k = lane + 64 * c;
-                kbase[c] = k * (k + 1) / 2;
-            }
-            const double* Di = DLDS ? (Dl + i * n) : (Dg + i * n);
-            const double* Dj = DLDS ? (Dl + j * n) : (Dg + j * n);
-            for (int l = 0; l < n; ++l) {
-                const double dil = Di[l], djl = Dj[l];
-                const int lbase = l * (l + 1) / 2;
-#pragma unroll
-                for (int c = 0; c < KCH; ++c) {
-                    const int k = lane + 64 * c;
-                    if (k < n) {
-                        const double v = rowbuf[k >= l ? kbase[c] + l : lbase + k];
-                        acc_i[c] += v * djl;
-                        acc_j[c] += v * dil;
-                    }
-                }
-            }
+            row_exchange<KCH, DREG>(rowbuf, Dsrc + i * n, Dsrc + j * n, n, lane, acc_i, acc_j);
 #pragma unroll
             for (int c = 0; c < KCH; ++c) {
                 const int k = lane + 64 * c;
                 if (k < n) {
-                    if (DLDS) {
-                        atomicAdd(&Kl[i * n + k], acc_i[c]);
-                        if (i != j) atomicAdd(&Kl[j * n + k], acc_j[c]);
-                    } else {
-                        atomicAdd(&Kg[i * n + k], acc_i[c]);
-                        if (i != j) atomicAdd(&Kg[j * n + k], acc_j[c]);
-                    }
+                    double* Kt = KLDS ? Kl : Kg;
+                    atomicAdd(&Kt[i * n + k], acc_i[c]);
+                    if (i != j) atomicAdd(&Kt[j * n + k], acc_j[c]);
+                }
+            }
+            row = nrow;
+        }
+    } else {
+        constexpr int CH = 16;
+        for (; row < np; row += stride) {
+            int i, j;
+            unpack_pair(row, i, j);
+            const double* __restrict__ src = M + (size_t)row * np;
+            double accj = 0.0;
+            for (int base = 0; base < np; base += 64 * CH) {
+                double v[CH];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) { const int idx = base + lane + 64 * u; v[u] = idx < np ? src[idx] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const int idx = base + lane + 64 * u;
+                    if (idx < np) { rowbuf[idx] = v[u]; accj += v[u] * Dp[idx]; }
+                }
+            }
+            accj = wave_sum(accj);
+            if (lane == 0) { Jg[i * n + j] = accj; Jg[j * n + i] = accj; }
+            double acc_i[KCH], acc_j[KCH];
+            row_exchange<KCH, DREG>(rowbuf, Dsrc + i * n, Dsrc + j * n, n, lane, acc_i, acc_j);
+#pragma unroll
+            for (int c = 0; c < KCH; ++c) {
+                const int k = lane + 64 * c;
+                if (k < n) {
+                    double* Kt = KLDS ? Kl : Kg;
+                    atomicAdd(&Kt[i * n + k], acc_i[c]);
+                    if (i != j) atomicAdd(&Kt[j * n + k], acc_j[c]);
                 }
             }
         }
-        __syncthreads();
     }
-    if (DLDS) {
+    if (KLDS) {
+        __syncthreads();
         for (int idx = tid; idx < n * n; idx += NTH) {
-            const double v = Kl[idx];
-            if (v != 0.0) atomicAdd(&Kg[idx], v);
+            const double kv = Kl[idx];
+            if (kv != 0.0) atomicAdd(&Kg[idx], kv);
         }
     }
 }
 
 static int jk_grid_x(const BatchView& bv, int nw)
 {
-    // enough workgroups to cover 256 CUs a few times over, but few enough that the per-workgroup
+    // enough workgroups to cover 256 CUs several times over, but few enough that the per-workgroup
     // D load and K flush stay amortised over many rows
-    int want = (2048 + bv.nfrag - 1) / bv.nfrag;
+    int want = (4096 + bv.nfrag - 1) / bv.nfrag;
     int maxx = (bv.npair + nw - 1) / nw;
     if (want < 1) want = 1;
     if (want > maxx) want = maxx;
     return want;
+}
+
+template <int KCH, bool KLDS, int NW, int MAXU, bool DREG>
+static void jk_launch(const BatchView& bv, int oa, size_t lds, hipStream_t s)
+{
+    auto kern = jk_incore_kernel<KCH, KLDS, NW, MAXU, DREG>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid(jk_grid_x(bv, NW), bv.nfrag), block(64 * NW);
+    hipLaunchKernelGGL(kern, grid, block, lds, s, bv, oa);
 }
 
 void launch_jk_incore(const BatchView& bv, bool only_active, hipStream_t s)
@@ -150,33 +223,29 @@ void launch_jk_incore(const BatchView& bv, bool only_active, hipStream_t s)
     const int n = bv.n, np = bv.npair;
     (void)hipMemsetAsync(bv.K, 0, sizeof(double) * (size_t)bv.nfrag * n * n, s);
     const int kch = (n + 63) / 64;
-    const size_t lds_small = sizeof(double) * ((size_t)5 * np + 2 * (size_t)n * n);
-    const size_t lds_mid = sizeof(double) * ((size_t)5 * np);     // 4 waves, D and K in global memory
-    const size_t lds_big = sizeof(double) * ((size_t)3 * np);     // 2 waves, D and K in global memory
-    const size_t LDS_MAX = 160 * 1024 - 512;
-    const int mode = lds_small <= 150 * 1024 ? 0 : (lds_mid <= LDS_MAX ? 1 : 2);
-    const size_t lds = mode == 0 ? lds_small : (mode == 1 ? lds_mid : lds_big);
-    const int nw = mode == 2 ? 2 : 4;
-    dim3 grid(jk_grid_x(bv, nw), bv.nfrag), block(64 * nw);
     const int oa = only_active ? 1 : 0;
-#define JK_LAUNCH(KC, DL, NWV)                                                                     \
-    do {                                                                                           \
-        auto kern = jk_incore_kernel<KC, DL, NWV>;                                                 \
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(kern, grid, block, lds, s, bv, oa);                                     \
-    } while (0)
-    if (mode == 0) {
-        if (kch == 1) JK_LAUNCH(1, true, 4);
-        else JK_LAUNCH(2, true, 4);
-    } else if (mode == 1) {
-        if (kch == 1) JK_LAUNCH(1, false, 4);
-        else JK_LAUNCH(2, false, 4);
+    const size_t LDS_MAX = 160 * 1024 - 1024;
+    const size_t lds_reg = sizeof(double) * ((size_t)5 * np + (size_t)n * n);      // 4 waves, K in LDS, D in registers
+    const size_t lds4k = sizeof(double) * ((size_t)5 * np + 2 * (size_t)n * n);   // 4 waves, D and K in LDS
+    const size_t lds4 = sizeof(double) * ((size_t)5 * np);                        // 4 waves, D and K global
+    const size_t lds2 = sizeof(double) * ((size_t)3 * np);                        // 2 waves, D and K global
+    if (n <= 64 && lds_reg <= LDS_MAX) {
+        // the fragment sizes of an MBE run (n = 48: 65.5 KB -> two workgroups per CU)
+        if (np <= 5 * 64) jk_launch<1, true, 4, 5, true>(bv, oa, lds_reg, s);
+        else if (np <= 10 * 64) jk_launch<1, true, 4, 10, true>(bv, oa, lds_reg, s);
+        else if (np <= 19 * 64) jk_launch<1, true, 4, 19, true>(bv, oa, lds_reg, s);
+        else jk_launch<1, true, 4, 0, true>(bv, oa, lds_reg, s);
+    } else if (lds4k <= LDS_MAX && kch <= 2) {
+        jk_launch<2, true, 4, 0, false>(bv, oa, lds4k, s);
+    } else if (lds4 <= LDS_MAX) {
+        if (kch <= 2) jk_launch<2, false, 4, 0, false>(bv, oa, lds4, s);
+        else if (kch == 3) jk_launch<3, false, 4, 0, false>(bv, oa, lds4, s);
+        else jk_launch<4, false, 4, 0, false>(bv, oa, lds4, s);
     } else {
-        if (kch <= 2) JK_LAUNCH(2, false, 2);
-        else if (kch == 3) JK_LAUNCH(3, false, 2);
-        else JK_LAUNCH(4, false, 2);
+        if (kch <= 2) jk_launch<2, false, 2, 0, false>(bv, oa, lds2, s);
+        else if (kch == 3) jk_launch<3, false, 2, 0, false>(bv, oa, lds2, s);
+        else jk_launch<4, false, 2, 0, false>(bv, oa, lds2, s);
     }
-#undef JK_LAUNCH
 }
 
 }  // namespace mqc

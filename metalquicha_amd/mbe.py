@@ -1,0 +1,212 @@
+"""The caller of the hot path: many-body-expansion fragment lists and energy assembly.
+
+Host-side mirror (numpy/ints only) of the pieces of src/fragmentation the engine is driven by,
+kept so that bench.py and the tests exercise the engine exactly the way metalquicha does:
+
+  generate_mbe_term_list   src/mqc_driver.f90:511 -> combinations + distance screening
+                           (src/fragmentation/common/mqc_frag_utils.f90:180-310) + largest-first
+                           ordering (sort_fragments_by_size, mqc_frag_utils.f90:312)
+  build_fragment           build_fragment_from_indices (no H-caps: monomers here are whole molecules)
+  compute_mbe              bottom-up deltas, src/fragmentation/mbe/mqc_mbe.f90:37-118,503
+  compute_mbe_coefficients src/fragmentation/mbe/mqc_mbe.f90:120-198
+  partition_terms          static round-robin over the cost-sorted list, the FMO code's choice
+                           (backends/libcint/mqc_libcint_fmo.f90:1806-1819); SURVEY.md 8e
+  run_mbe                  do_fragment_work over the owned terms (one engine batch), energies
+                           returned in a zero-padded vector ready for ONE all-reduce
+
+Nothing here touches the GPU; the SCFs are run by methods.run_hip_scf_batch.
+"""
+from __future__ import annotations
+
+import itertools
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .basis import ANGSTROM_TO_BOHR, SYMBOL_TO_Z
+from .methods import PhysicalFragment, ScfSettings, run_hip_scf_batch
+
+BOHR_TO_ANGSTROM = 1.0 / ANGSTROM_TO_BOHR
+
+
+@dataclass
+class FragmentedSystem:
+    element_numbers: np.ndarray                 # (n_atoms,)
+    coordinates: np.ndarray                     # (3, n_atoms) Bohr
+    monomers: List[np.ndarray]                  # atom indices of each monomer
+    charges: Optional[List[int]] = None
+    multiplicities: Optional[List[int]] = None
+
+    @property
+    def n_monomers(self) -> int:
+        return len(self.monomers)
+
+
+def read_xyz(path: str):
+    with open(path) as f:
+        lines = f.read().splitlines()
+    n = int(lines[0].split()[0])
+    sym, xyz = [], []
+    for ln in lines[2:2 + n]:
+        p = ln.split()
+        sym.append(p[0]); xyz.append([float(p[1]), float(p[2]), float(p[3])])
+    return sym, np.array(xyz)
+
+
+def system_from_xyz(symbols: Sequence[str], xyz_angstrom: np.ndarray, monomers: Sequence[Sequence[int]]) -> FragmentedSystem:
+    z = np.array([SYMBOL_TO_Z[s.lower()] for s in symbols], dtype=np.int32)
+    return FragmentedSystem(z, (np.asarray(xyz_angstrom, dtype=float) * ANGSTROM_TO_BOHR).T.copy(),
+                            [np.asarray(m, dtype=np.int64) for m in monomers])
+
+
+def min_intermonomer_distance(system: FragmentedSystem, a: int, b: int) -> float:
+    """Minimum interatomic distance between two monomers, in Angstrom."""
+    xa = system.coordinates[:, system.monomers[a]].T
+    xb = system.coordinates[:, system.monomers[b]].T
+    d = np.linalg.norm(xa[:, None, :] - xb[None, :, :], axis=2)
+    return float(d.min()) * BOHR_TO_ANGSTROM
+
+
+def generate_mbe_term_list(system: FragmentedSystem, level: int, cutoffs: Optional[Dict[int, float]] = None) -> List[Tuple[int, ...]]:
+    """All k-mers up to `level`; a term is dropped if it, or any of its k-subsets, exceeds the k-mer
+    cutoff (minimum inter-monomer atomic distance, Angstrom).  Largest terms first."""
+    n = system.n_monomers
+    cutoffs = cutoffs or {}
+    dist_cache: Dict[Tuple[int, int], float] = {}
+
+    def dist(a, b):
+        key = (a, b) if a < b else (b, a)
+        if key not in dist_cache:
+            dist_cache[key] = min_intermonomer_distance(system, *key)
+        return dist_cache[key]
+
+    def spread(term):
+        return max(dist(a, b) for a, b in itertools.combinations(term, 2))
+
+    terms: List[Tuple[int, ...]] = []
+    for k in range(1, level + 1):
+        for term in itertools.combinations(range(n), k):
+            ok = True
+            if k >= 2:
+                for kk in range(2, k + 1):
+                    cut = cutoffs.get(kk)
+                    if cut is None:
+                        continue
+                    if any(spread(sub) > cut for sub in itertools.combinations(term, kk)):
+                        ok = False
+                        break
+            if ok:
+                terms.append(term)
+    terms.sort(key=lambda t: -sum(len(system.monomers[m]) for m in t))     # stable: largest first
+    return terms
+
+
+def build_fragment(system: FragmentedSystem, term: Sequence[int]) -> PhysicalFragment:
+    atoms = np.concatenate([system.monomers[m] for m in term])
+    charge = 0 if system.charges is None else int(sum(system.charges[m] for m in term))
+    return PhysicalFragment(system.element_numbers[atoms], system.coordinates[:, atoms].copy(), charge=charge)
+
+
+def compute_mbe(terms: Sequence[Tuple[int, ...]], energies: Sequence[float]):
+    """Bottom-up many-body deltas; returns (total, per-order sums, delta per term)."""
+    lookup = {tuple(t): i for i, t in enumerate(terms)}
+    order = sorted(range(len(terms)), key=lambda i: len(terms[i]))
+    delta = np.zeros(len(terms))
+    for i in order:
+        t = terms[i]
+        d = energies[i]
+        for k in range(1, len(t)):
+            for sub in itertools.combinations(t, k):
+                j = lookup.get(sub)
+                if j is None:
+                    raise KeyError("Subset not found in bottom-up MBE: %s of %s" % (sub, t))
+                d -= delta[j]
+        delta[i] = d
+    by_order: Dict[int, float] = {}
+    for i, t in enumerate(terms):
+        by_order[len(t)] = by_order.get(len(t), 0.0) + delta[i]
+    return float(np.sum(delta)), by_order, delta
+
+
+def compute_mbe_coefficients(terms: Sequence[Tuple[int, ...]]) -> np.ndarray:
+    """E_total = sum_i c_i E_i.  For unscreened MBE-2 of N monomers: c_dimer = 1, c_monomer = 2 - N."""
+    lookup = {tuple(t): i for i, t in enumerate(terms)}
+    coef = np.zeros(len(terms))
+    for t in terms:
+        k = len(t)
+        # E_total = sum over terms of delta(t); delta(t) = sum_{s subseteq t} (-1)^{|t|-|s|} E(s)
+        for kk in range(1, k + 1):
+            for sub in itertools.combinations(t, kk):
+                coef[lookup[sub]] += (-1.0) ** (k - kk)
+    return coef
+
+
+def partition_terms(n_terms: int, rank: int, world: int) -> np.ndarray:
+    """Static round-robin over the cost-sorted list: rank r owns terms r, r+world, ..."""
+    return np.arange(rank, n_terms, world, dtype=np.int64)
+
+
+@dataclass
+class MbeRun:
+    terms: List[Tuple[int, ...]]
+    energies: np.ndarray          # zero for terms this rank does not own
+    iterations: np.ndarray
+    owned: np.ndarray
+    errors: List[str]
+
+
+def run_mbe(system: FragmentedSystem, settings: ScfSettings, level: int = 2,
+            cutoffs: Optional[Dict[int, float]] = None, rank: int = 0, world: int = 1,
+            terms: Optional[List[Tuple[int, ...]]] = None) -> MbeRun:
+    terms = terms if terms is not None else generate_mbe_term_list(system, level, cutoffs)
+    owned = partition_terms(len(terms), rank, world)
+    frags = [build_fragment(system, terms[i]) for i in owned]
+    results = run_hip_scf_batch(settings, frags)
+    energies = np.zeros(len(terms))
+    iters = np.zeros(len(terms), dtype=np.int64)
+    errors = []
+    for i, r in zip(owned, results):
+        if r.has_error:
+            errors.append("term %s: %s" % (terms[i], r.error_message))
+            continue
+        energies[i] = r.energy.scf
+        iters[i] = r.scf_iterations
+    return MbeRun(terms, energies, iters, owned, errors)
+
+
+# ---------------------------------------------------------------------------------------------
+W1_ANGSTROM = np.array([[0.0, 0.00000000009155, 0.10077199490609],
+                        [0.0, 0.77250895271063, -0.46780199741728],
+                        [0.0, -0.77250895280218, -0.46780199748881]])   # validation/inputs/sample_inputs/w1.xyz
+
+
+def water_cluster(n_side: int = 4, spacing: float = 3.1, seed: int = 20260821) -> FragmentedSystem:
+    """(H2O)_{n^3}: cubic lattice, `spacing` Angstrom, one rigid water (w1.xyz internal geometry) per
+    site, uniformly random orientation from a seeded generator (the (H2O)64
+    workload of BASELINE.json configs[2]; no such file exists in the reference)."""
+    rng = np.random.default_rng(seed)
+    mol = W1_ANGSTROM - W1_ANGSTROM.mean(axis=0)
+    sym, xyz, monomers = [], [], []
+    for ix in range(n_side):
+        for iy in range(n_side):
+            for iz in range(n_side):
+                q = rng.normal(size=4); q /= np.linalg.norm(q)
+                a, b, c, d = q
+                R = np.array([[a*a+b*b-c*c-d*d, 2*(b*c-a*d), 2*(b*d+a*c)],
+                              [2*(b*c+a*d), a*a-b*b+c*c-d*d, 2*(c*d-a*b)],
+                              [2*(b*d-a*c), 2*(c*d+a*b), a*a-b*b-c*c+d*d]])
+                pos = mol @ R.T + spacing * np.array([ix, iy, iz], dtype=float)
+                base = len(sym)
+                sym += ["O", "H", "H"]
+                xyz.append(pos)
+                monomers.append([base, base + 1, base + 2])
+    return system_from_xyz(sym, np.vstack(xyz), monomers)
+
+
+def write_xyz(path: str, system: FragmentedSystem, comment: str = ""):
+    from .basis import SYMBOLS
+    with open(path, "w") as f:
+        f.write("%d\n%s\n" % (len(system.element_numbers), comment))
+        for z, r in zip(system.element_numbers, system.coordinates.T * BOHR_TO_ANGSTROM):
+            f.write("%-2s %18.12f %18.12f %18.12f\n" % (SYMBOLS[z], r[0], r[1], r[2]))

@@ -1,0 +1,9 @@
+#!/bin/bash
+# test-only: host build of the __host__ __device__ integral templates (see check_device_math.cpp)
+set -e
+cd "$(dirname "$0")"
+SRC=check_device_math.cpp
+if [ ! -f libhostcheck.so ] || [ $SRC -nt libhostcheck.so ] || [ ../../metalquicha_amd/csrc/md_integrals.hpp -nt libhostcheck.so ] || [ ../../metalquicha_amd/csrc/host_setup.cpp -nt libhostcheck.so ]; then
+  hipcc -O2 -std=c++17 -fPIC -shared -x hip --offload-arch=gfx950 -Wno-pass-failed $SRC ../../metalquicha_amd/csrc/host_setup.cpp -o libhostcheck.so
+fi
+echo "built tests/host/libhostcheck.so"

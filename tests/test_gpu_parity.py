@@ -161,3 +161,36 @@ def test_refusals_match_reference_behaviour():
     assert r.scf_status == methods.SCF_NOT_CONVERGED and not r.has_error and r.has_energy   # ... unless allowed
     oh = methods.run_hip_scf(methods.ScfSettings(basis_set="sto-3g"), fragment_bohr([8, 1], [[0, 0, 0], [0, 0, 1.8]]))
     assert oh.has_error      # odd electron count
+
+
+def _jk_from_packed(M, D):
+    """numpy contraction of the engine's own packed tensor (size-independent property check)."""
+    n = D.shape[0]
+    idx = [(i, j) for i in range(n) for j in range(i + 1)]
+    ii = np.array([p[0] for p in idx]); jj = np.array([p[1] for p in idx])
+    full = np.zeros((n, n, n, n))
+    full[ii[:, None], jj[:, None], ii[None, :], jj[None, :]] = M
+    full[jj[:, None], ii[:, None], ii[None, :], jj[None, :]] = M
+    full[ii[:, None], jj[:, None], jj[None, :], ii[None, :]] = M
+    full[jj[:, None], ii[:, None], jj[None, :], ii[None, :]] = M
+    return so.build_jk_incore(full, D)
+
+
+def test_jk_incore_larger_fragments_all_kernel_variants():
+    """n = 72 (water trimer, two k-chunks, D/K in global memory) against the packed tensor itself."""
+    rng = np.random.default_rng(9)
+    xyz = np.vstack([water_at(rng, c) for c in ([0, 0, 0], [5.6, 0.3, 0.2], [0.1, 5.9, -0.4])])
+    frag = fragment_bohr([8, 1, 1] * 3, xyz)
+    M = stages.eri_packed("cc-pvdz", frag)
+    n = 72
+    D = synthetic_density(n)
+    J, K = stages.jk_incore("cc-pvdz", frag, D)
+    Jr, Kr = _jk_from_packed(M, D)
+    assert np.max(np.abs(J - Jr)) < 1e-10
+    assert np.max(np.abs(K - Kr)) < 1e-10
+    # linearity in the density: J[a D1 + b D2] = a J[D1] + b J[D2]
+    D2 = synthetic_density(n)[::-1, ::-1].copy()
+    J2, K2 = stages.jk_incore("cc-pvdz", frag, D2)
+    J3, K3 = stages.jk_incore("cc-pvdz", frag, 0.3 * D - 1.7 * D2)
+    assert np.max(np.abs(J3 - (0.3 * J - 1.7 * J2))) < 1e-10
+    assert np.max(np.abs(K3 - (0.3 * K - 1.7 * K2))) < 1e-10
