@@ -27,7 +27,7 @@ SYMBOLS = ["X", "H", "He", "Li", "Be", "B", "C", "N", "O", "F", "Ne", "Na", "Mg"
            "Ga", "Ge", "As", "Se", "Br", "Kr"]
 SYMBOL_TO_Z = {s.lower(): z for z, s in enumerate(SYMBOLS)}
 
-ANGSTROM_TO_BOHR = 1.0 / 0.52917721092   # the reference's to_bohr (src/core/mqc_physical_constants.F90)
+ANGSTROM_TO_BOHR = 1.0 / 0.529177210903   # CODATA 2018, the reference default (src/core/mqc_physical_constants.F90:33-37)
 
 
 class BasisError(ValueError):

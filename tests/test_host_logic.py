@@ -1,0 +1,190 @@
+"""Host logic that needs no GPU: basis reader, topology plumbing, MBE assembly, C-ABI exports,
+the host build of the device integral templates, and the 2-rank gloo rehearsal of the N>1 path."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from metalquicha_amd import basis as basis_mod
+from metalquicha_amd import capi, mbe, methods
+from oracle import scf_oracle as so
+from tests.helpers import fragment_bohr, oracle_mol
+
+
+def test_basis_reader_splits_general_contractions_and_sp():
+    o = basis_mod.read_element(basis_mod.find_basis_file("cc-pvdz"), 8)
+    assert [s.l for s in o.shells] == [0, 0, 0, 1, 1, 2]          # 3s2p1d, one shell per row
+    assert all(s.nprim == 9 for s in o.shells[:3])
+    sto = basis_mod.read_element(basis_mod.find_basis_file("sto-3g"), 8)
+    assert [s.l for s in sto.shells] == [0, 0, 1]                  # SP shell split on shared exponents
+    assert np.array_equal(sto.shells[1].exps, sto.shells[2].exps)
+    fb = basis_mod.build_flat_basis("cc-pvdz", [8, 1, 1])
+    assert fb.nao == 24 and fb.nshell == 12 and list(fb.nshell_per_atom) == [6, 3, 3]
+    with pytest.raises(basis_mod.BasisError):
+        basis_mod.build_flat_basis("cc-pvdz", [3])                 # element not in the file
+    with pytest.raises(basis_mod.BasisError):
+        basis_mod.find_basis_file("no-such-basis")
+
+
+def test_nelec_excludes_ghosts():
+    f = methods.PhysicalFragment(np.array([8, 1, 1, 8, 1, 1]), np.zeros((3, 6)), ghost=[0, 0, 0, 1, 1, 1])
+    assert f.nelec == 10
+
+
+def test_capi_exports_every_declared_symbol():
+    lib = capi.load_library()
+    header = open(os.path.join(ROOT, "include", "mqc_hip.h")).read()
+    declared = set(re.findall(r"\b(mqc_hip_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(capi.DECLARED_SYMBOLS)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert lib.mqc_hip_abi_version() == 1
+
+
+def test_engine_fails_loudly_without_a_device():
+    lib = capi.load_library()
+    if lib.mqc_hip_backend_available():
+        pytest.skip("a HIP device is present")
+    h = ctypes.c_void_p()
+    rc = lib.mqc_hip_context_get(0, ctypes.byref(h))
+    assert rc == capi.ERR_NO_DEVICE
+    assert b"no CPU fallback" in lib.mqc_hip_last_error()
+    r = methods.run_hip_scf(methods.ScfSettings(), fragment_bohr([1, 1], [[0, 0, 0], [0, 0, 1.4]]))
+    assert r.has_error and not r.has_energy
+
+
+def test_struct_layouts_match_the_header():
+    # sizes computed by the C compiler for the same declarations
+    src = '#include "include/mqc_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu\\n",' \
+          'sizeof(mqc_hip_molecule_t),sizeof(mqc_hip_basis_t),sizeof(mqc_hip_scf_options_t),' \
+          'sizeof(mqc_hip_scf_result_t),sizeof(mqc_hip_stats_t));return 0;}'
+    exe = os.path.join(ROOT, "tests", "host", "_sizes")
+    subprocess.run(["gcc", "-x", "c", "-", "-I", ROOT, "-o", exe], input=src.encode(), cwd=ROOT, check=True)
+    sizes = [int(x) for x in subprocess.check_output([exe]).split()]
+    os.remove(exe)
+    assert sizes == [ctypes.sizeof(capi.Molecule), ctypes.sizeof(capi.Basis), ctypes.sizeof(capi.ScfOptions),
+                     ctypes.sizeof(capi.ScfResult), ctypes.sizeof(capi.Stats)]
+
+
+# ---- the gfx950 integral templates, compiled for the host by tests/host/build.sh --------------
+CLASSES = [(0, 0, 0, 0), (1, 0, 0, 0), (1, 0, 1, 0), (1, 1, 0, 0), (1, 1, 1, 0), (1, 1, 1, 1), (2, 0, 0, 0),
+           (2, 0, 1, 0), (2, 0, 1, 1), (2, 0, 2, 0), (2, 1, 0, 0), (2, 1, 1, 0), (2, 1, 1, 1), (2, 1, 2, 0),
+           (2, 1, 2, 1), (2, 2, 0, 0), (2, 2, 1, 0), (2, 2, 1, 1), (2, 2, 2, 0), (2, 2, 2, 1), (2, 2, 2, 2)]
+
+
+@pytest.fixture(scope="module")
+def hostcheck():
+    subprocess.check_call(["bash", os.path.join(ROOT, "tests", "host", "build.sh")], stdout=subprocess.DEVNULL)
+    return ctypes.CDLL(os.path.join(ROOT, "tests", "host", "libhostcheck.so"))
+
+
+def test_device_boys_function_matches_oracle(hostcheck):
+    dp = ctypes.POINTER(ctypes.c_double)
+    for L in (0, 4, 8, 16):
+        for T in (0.0, 1e-9, 0.03, 0.049999, 0.05, 0.77, 5.12345, 19.99, 33.3, 41.97, 42.0, 55.5, 300.0, 5000.0):
+            F, G = np.zeros(L + 1), np.zeros(L + 1)
+            hostcheck.hostcheck_boys(L, ctypes.c_double(T), F.ctypes.data_as(dp))
+            so.lib().orc_boys(L, ctypes.c_double(T), G.ctypes.data_as(dp))
+            assert np.max(np.abs(F - G) / np.maximum(np.abs(G), 1e-300)) < 2e-13, (L, T)
+
+
+@pytest.mark.parametrize("cls", CLASSES)
+def test_device_eri_class_matches_oracle(hostcheck, cls):
+    dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
+    rng = np.random.default_rng(sum(c * 7 ** k for k, c in enumerate(cls)) + 1)
+    l = np.array(cls, dtype=np.int32)
+    nprim = rng.integers(1, 4, size=4).astype(np.int32)
+    exps = rng.uniform(0.2, 4.0, size=int(nprim.sum())); exps[0] = 30.0
+    coefs = rng.uniform(-1, 1, size=int(nprim.sum()))
+    xyz = rng.uniform(-1.5, 1.5, size=(4, 3))
+    mol = so.make_mol([1, 1, 1, 1], xyz, [1, 1, 1, 1], l, nprim, exps, coefs)
+    eri = so.eri4(mol)
+    off, ns = mol.sh_aoff, 2 * l + 1
+    ref = eri[off[0]:off[0] + ns[0], off[1]:off[1] + ns[1], off[2]:off[2] + ns[2], off[3]:off[3] + ns[3]]
+    fac = np.array([0.282094791773878143, 0.488602511902919921, 1.0, 1.0, 1.0])
+    co = mol.coefs.copy(); o = 0
+    for k in range(4):
+        co[o:o + nprim[k]] *= fac[l[k]]; o += nprim[k]
+    out = np.zeros(int(np.prod(ns)))
+    rc = hostcheck.hostcheck_eri_block(l.ctypes.data_as(ip), nprim.ctypes.data_as(ip), exps.ctypes.data_as(dp),
+                                       co.ctypes.data_as(dp), np.ascontiguousarray(xyz).ctypes.data_as(dp), out.ctypes.data_as(dp))
+    assert rc == 0
+    assert np.max(np.abs(out.reshape(ref.shape) - ref)) < 1e-13 * max(1.0, np.max(np.abs(ref)))
+
+
+# ---- MBE assembly ----------------------------------------------------------------------------
+def test_mbe_term_list_and_coefficients():
+    system = mbe.water_cluster(2)
+    assert system.n_monomers == 8
+    terms = mbe.generate_mbe_term_list(system, 2)
+    assert len(terms) == 8 + 28
+    assert all(len(t) == 2 for t in terms[:28])                   # largest first
+    c = mbe.compute_mbe_coefficients(terms)
+    for t, ci in zip(terms, c):
+        assert ci == (1.0 if len(t) == 2 else 2.0 - 8)            # c_dimer = 1, c_monomer = 2 - N
+    rng = np.random.default_rng(1)
+    e = rng.normal(size=len(terms))
+    total, by_order, delta = mbe.compute_mbe(terms, e)
+    assert abs(total - float(np.dot(c, e))) < 1e-12               # delta form == coefficient form
+    perm = rng.permutation(len(terms))                            # order independence (test_mqc_mbe.f90:18-22)
+    total2, _, _ = mbe.compute_mbe([terms[i] for i in perm], e[perm])
+    assert abs(total - total2) < 1e-12
+
+
+def test_mbe_distance_screening():
+    system = mbe.water_cluster(3)
+    all_terms = mbe.generate_mbe_term_list(system, 2)
+    cut = mbe.generate_mbe_term_list(system, 2, cutoffs={2: 3.0})
+    assert len(all_terms) == 27 + 27 * 26 // 2
+    assert 27 < len(cut) < len(all_terms)
+    for t in cut:
+        if len(t) == 2:
+            assert mbe.min_intermonomer_distance(system, *t) <= 3.0
+
+
+def test_water_cluster_is_reproducible():
+    a, b = mbe.water_cluster(4), mbe.water_cluster(4)
+    assert a.n_monomers == 64 and np.array_equal(a.coordinates, b.coordinates)
+    roh = np.linalg.norm(a.coordinates[:, 0] - a.coordinates[:, 1]) * mbe.BOHR_TO_ANGSTROM
+    assert abs(roh - 0.9592) < 1e-3                               # rigid w1.xyz geometry
+
+
+def test_partition_covers_every_term_once():
+    for world in (1, 2, 3, 8):
+        owned = np.concatenate([mbe.partition_terms(2080, r, world) for r in range(world)])
+        assert sorted(owned.tolist()) == list(range(2080))
+
+
+def test_two_rank_gloo_rehearsal_of_the_energy_reduction(tmp_path):
+    """world_size = 2 over gloo: each rank fills the energies of ITS terms (stand-in values), one
+    all-reduce of the zero-padded vector, MBE assembly on every rank; must equal the serial result."""
+    script = tmp_path / "rank.py"
+    script.write_text(
+        "import os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import numpy as np, torch, torch.distributed as dist\n"
+        "from metalquicha_amd import mbe\n"
+        "dist.init_process_group('gloo', init_method='env://')\n"
+        "r, w = dist.get_rank(), dist.get_world_size()\n"
+        "system = mbe.water_cluster(2)\n"
+        "terms = mbe.generate_mbe_term_list(system, 2)\n"
+        "ref = np.array([-76.0 * len(t) - 1e-3 * sum(t) for t in terms])\n"
+        "e = np.zeros(len(terms)); own = mbe.partition_terms(len(terms), r, w); e[own] = ref[own]\n"
+        "buf = torch.from_numpy(e); dist.all_reduce(buf)\n"
+        "tot, _, _ = mbe.compute_mbe(terms, buf.numpy())\n"
+        "ser, _, _ = mbe.compute_mbe(terms, ref)\n"
+        "assert abs(tot - ser) < 1e-10, (tot, ser)\n"
+        "print('rank', r, 'ok', tot)\n"
+        "dist.destroy_process_group()\n" % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("ok") == 2

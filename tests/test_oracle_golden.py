@@ -1,0 +1,110 @@
+"""The oracle against every known-answer number the reference holds for the exact-ERI RHF path
+(SURVEY.md section 8c).  CPU only; this is what pins the oracle before it is used as a checker."""
+import numpy as np
+import pytest
+
+from oracle import scf_oracle as so
+from tests.helpers import fragment_bohr, oracle_mol, W1_ANGSTROM
+from metalquicha_amd.basis import ANGSTROM_TO_BOHR
+
+WATER = ([8, 1, 1], [[0.0, 0.0, -0.1364652], [0.0, 1.4304924, 1.0826636], [0.0, -1.4304924, 1.0826636]])
+
+
+def test_h2_sto3g_check_rhf():
+    # validation/check_rhf.f90:79-83: -1.1167143251, E_nuc = 1/1.4, nao = 2
+    mol = oracle_mol("sto-3g-check_rhf", fragment_bohr([1, 1], [[0, 0, 0], [0, 0, 1.4]]))
+    assert mol.nao == 2
+    r = so.run_rhf(mol, 2, 100, 1e-10, 1e-8)
+    assert r.converged
+    assert abs(r.nuclear - 1.0 / 1.4) < 1e-12
+    assert abs(r.energy - (-1.1167143251)) < 1e-9
+
+
+def test_h2_overlap_check_libcint():
+    # validation/check_libcint.f90:33,123-127: S12(H2/STO-3G, R = 1.4) = 0.6593 +- 5e-5, diagonal 1
+    S, _, _ = so.int1e(oracle_mol("sto-3g-check_rhf", fragment_bohr([1, 1], [[0, 0, 0], [0, 0, 1.4]])))
+    assert abs(S[0, 1] - 0.6593) < 5e-5
+    assert np.allclose(np.diag(S), 1.0, atol=1e-12)
+
+
+def test_water_sto3g_check_rhf_and_diis_invariance():
+    # validation/check_rhf.f90:102-143: nao = 7, -74.9658162796, DIIS == no DIIS to 1e-9, fewer iterations
+    mol = oracle_mol("sto-3g-check_rhf", fragment_bohr(*WATER))
+    assert mol.nao == 7
+    r = so.run_rhf(mol, 10, 100, 1e-10, 1e-8)
+    plain = so.run_rhf(mol, 10, 200, 1e-10, 1e-8, diis_vectors=0)
+    assert r.converged and plain.converged
+    assert abs(r.energy - (-74.9658162796)) < 1e-9
+    assert abs(r.energy - plain.energy) < 1e-9
+    assert r.iterations < plain.iterations
+
+
+def test_water_ccpvdz_check_df_exact():
+    # validation/check_df.f90:55-57: exact-ERI RHF/cc-pVDZ -76.0220988827 (1e-9); also pins the
+    # cc-pVDZ H and O tables typed into metalquicha_amd/basis_data/make_basis_json.py
+    mol = oracle_mol("cc-pvdz", fragment_bohr(*WATER))
+    assert mol.nao == 24
+    r = so.run_rhf(mol, 10, 200, 1e-11, 1e-9)
+    assert r.converged
+    assert abs(r.energy - (-76.0220988827)) < 1e-9
+
+
+def test_water_sto3g_backends_example():
+    # python/examples/backends.py:28-54: H2O STO-3G (8-decimal geometry) RHF -74.962005687948,
+    # and the 4 A-separated dimer -149.922856255009 (the number an MBE(2) of it must reproduce)
+    w = np.array([[0.0, 0.0, 0.10077199], [0.0, 0.77250895, -0.46780200], [0.0, -0.77250895, -0.46780200]])
+    # (PySCF's built-in STO-3G = the 8-digit table of check_rhf.f90; the 10-digit BSE table moves
+    #  this energy by 2.4e-8, which is how the two are told apart)
+    bas = "sto-3g-check_rhf"
+    r = so.run_rhf(oracle_mol(bas, fragment_bohr([8, 1, 1], w * ANGSTROM_TO_BOHR)), 10, 100, 1e-10, 1e-8)
+    assert abs(r.energy - (-74.962005687948)) < 1e-9
+    d = np.vstack([w, w + np.array([4.0, 0.0, 0.0])])
+    r2 = so.run_rhf(oracle_mol(bas, fragment_bohr([8, 1, 1, 8, 1, 1], d * ANGSTROM_TO_BOHR)), 20, 100, 1e-10, 1e-8)
+    assert abs(r2.energy - (-149.922856255009)) < 2e-9
+
+
+def test_h2_manifest_first_case():
+    # validation/validation_tests_cpu.json first case: H2 STO-3G r = 0.7414 A, -1.1166843872
+    xyz = np.array([[0, 0, 0], [0, 0, 0.7414]]) * ANGSTROM_TO_BOHR
+    r = so.run_rhf(oracle_mol("sto-3g", fragment_bohr([1, 1], xyz)), 2, 100, 1e-12, 1e-8)
+    assert abs(r.energy - (-1.1166843872)) < 1e-9
+
+
+def test_diis_reference_properties():
+    # test/test_mqc_diis.f90:21-26: coefficients sum to 1, ring eviction, cached overlap = direct
+    rng = np.random.default_rng(0)
+    d = so.Diis(4, 9, 6)
+    focks, errs = [], []
+    for k in range(7):
+        f, e = rng.normal(size=9), rng.normal(size=6) * 10.0 ** (-k)
+        focks.append(f); errs.append(e)
+        d.push(f, e)
+        c = d.coefficients()
+        if k == 0:
+            assert c is None
+            continue
+        n = d.n_stored
+        assert n == min(k + 1, 4)
+        assert abs(np.sum(c[:n]) - 1.0) < 1e-10
+        kept = errs[-n:]
+        for a in range(n):
+            for b in range(n):
+                direct = float(np.dot(kept[a], kept[b]))
+                cached = d.overlap[d.slot_of_age(a + 1) - 1, d.slot_of_age(b + 1) - 1]
+                assert abs(direct - cached) < 1e-15 * max(1.0, abs(direct))
+        ex, ok = d.extrapolate(focks[-1].copy())
+        assert ok
+        assert np.allclose(ex, sum(c[i] * focks[len(focks) - n + i] for i in range(n)), atol=1e-12)
+
+
+def test_schwarz_bounds_bound_the_tensor():
+    mol = oracle_mol("sto-3g", fragment_bohr(*WATER))
+    eri = so.eri4(mol)
+    q = so.schwarz(mol)
+    off = list(mol.sh_aoff) + [mol.nao]
+    for a in range(mol.nshell):
+        for b in range(mol.nshell):
+            for c in range(mol.nshell):
+                for d in range(mol.nshell):
+                    blk = eri[off[a]:off[a + 1], off[b]:off[b + 1], off[c]:off[c + 1], off[d]:off[d + 1]]
+                    assert np.max(np.abs(blk)) <= q[a, b] * q[c, d] * (1 + 1e-10) + 1e-14
