@@ -188,3 +188,13 @@ def test_two_rank_gloo_rehearsal_of_the_energy_reduction(tmp_path):
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("ok") == 2
+
+
+def test_fortran_iso_c_binding_module_links():
+    """fortran/mqc_hip_c.f90 compiled with AMD flang and linked against libmqc_hip.so."""
+    flang = "/opt/rocm/lib/llvm/bin/flang"
+    if not os.path.isfile(flang):
+        pytest.skip("no flang in this image")
+    out = subprocess.run(["bash", os.path.join(ROOT, "fortran", "check_link.sh")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "abi version 1" in out.stdout
