@@ -85,7 +85,7 @@ ccpvdz = {
         shell([1], [0.727], [[1.0]], S),
     ],
     6: [
-        shell([0], [6665.0, 1000.0, 228.0, 62.71, 18.25, 5.453, 1.675, 0.5193, 0.1596],
+        shell([0], [6665.0, 1000.0, 228.0, 64.71, 21.06, 7.495, 2.797, 0.5215, 0.1596],
               [[0.000692, 0.005329, 0.027077, 0.101718, 0.27474, 0.448564, 0.285074, 0.015204, -0.003191],
                [-0.000146, -0.001154, -0.005725, -0.023312, -0.063955, -0.149981, -0.127262, 0.544529, 0.580496],
                [0, 0, 0, 0, 0, 0, 0, 0, 1.0]], S),
