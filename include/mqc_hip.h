@@ -185,6 +185,8 @@ typedef struct {
     double fock_kernel_seconds;   /* HIP-event time of the in-core J/K kernel, last batch */
     double fock_bytes;            /* algorithmic bytes it streamed */
     double eri_kernel_seconds;
+    double xc_kernel_seconds;     /* HIP-event time of the XC quadrature kernel, last batch */
+    double xc_points;             /* grid points it integrated (fragments x points, summed over launches) */
 } mqc_hip_stats_t;
 int mqc_hip_get_stats(mqc_hip_context *ctx, mqc_hip_stats_t *stats);
 int mqc_hip_device_name(mqc_hip_context *ctx, char *buf, int32_t len);

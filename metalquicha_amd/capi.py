@@ -62,7 +62,8 @@ class Stats(C.Structure):
                 ("t_fock", C.c_double), ("t_scf_step", C.c_double), ("t_total", C.c_double),
                 ("fock_launches", C.c_int64), ("eri_quartets", C.c_int64),
                 ("scf_iterations_total", C.c_int64), ("fock_kernel_seconds", C.c_double),
-                ("fock_bytes", C.c_double), ("eri_kernel_seconds", C.c_double)]
+                ("fock_bytes", C.c_double), ("eri_kernel_seconds", C.c_double),
+                ("xc_kernel_seconds", C.c_double), ("xc_points", C.c_double)]
 
 
 DECLARED_SYMBOLS = [

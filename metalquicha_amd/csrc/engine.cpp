@@ -112,7 +112,11 @@ static bool incore_supported(int n)
 
 static int validate_options(const mqc_hip_scf_options_t& o, const Topology& topo, std::string& msg)
 {
-    if (o.functional[0] != '\0') { msg = "Kohn-Sham functionals are not available in this build of the HIP backend (Hartree-Fock only)"; return MQC_HIP_ERR_UNSUPPORTED; }
+    {
+        XcSpec tmp; std::string e;
+        if (!parse_functional(o.functional, tmp, e)) { msg = e; return MQC_HIP_ERR_UNSUPPORTED; }
+        if (tmp.ncomp > 0 && topo.natoms > 64) { msg = "XC grid: fragments above 64 atoms are not supported yet"; return MQC_HIP_ERR_UNSUPPORTED; }
+    }
     if (o.density_fitting) { msg = "density fitting is not available in this build of the HIP backend"; return MQC_HIP_ERR_UNSUPPORTED; }
     if (o.want_gradient) { msg = "analytic gradients are not available in this build of the HIP backend"; return MQC_HIP_ERR_UNSUPPORTED; }
     if (o.unrestricted || topo.multiplicity != 1 || (topo.nelec % 2) != 0) {
@@ -149,9 +153,56 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const std::vector<cons
     rc = upload_topology(ctx, topo, td);
     if (rc != MQC_HIP_OK) return rc;
 
+    // ---- exchange-correlation: functional, per-element grid templates, per-topology point list
+    XcSpec xc;
+    {
+        std::string e;
+        parse_functional(opts.functional, xc, e);
+    }
+    GridDev grid;
+    if (xc.ncomp > 0) {
+        std::map<int, std::pair<int, int>> tmpl_of_z;     // Z -> (offset, count) in the packed template arrays
+        std::vector<double> txyz, tw, sb(topo.natoms);
+        std::vector<int> pt_atom, pt_tmpl;
+        for (int a = 0; a < topo.natoms; ++a) {
+            const int z = topo.Z[a];
+            sb[a] = std::sqrt(bragg_radius_bohr((topo.zeff[a] == 0.0) ? 0 : z)) + 1e-200;
+            // ghost atoms still own grid points in the reference (atomic_numbers are passed unchanged)
+            sb[a] = std::sqrt(bragg_radius_bohr(z)) + 1e-200;
+            if (!tmpl_of_z.count(z)) {
+                std::vector<double> x, w; std::string e;
+                if (!build_atom_template(z, opts.grid_level, opts.radial_points, opts.angular_points, x, w, e)) {
+                    for (auto* r : results) { fill_error(r, e); r->scf_status = MQC_HIP_SCF_NOT_RUN; }
+                    return fail(MQC_HIP_ERR_UNSUPPORTED, e);
+                }
+                tmpl_of_z[z] = {(int)tw.size(), (int)w.size()};
+                txyz.insert(txyz.end(), x.begin(), x.end());
+                tw.insert(tw.end(), w.begin(), w.end());
+            }
+            const auto oc = tmpl_of_z[z];
+            for (int k = 0; k < oc.second; ++k) { pt_atom.push_back(a); pt_tmpl.push_back(oc.first + k); }
+        }
+        grid.npts = (int)pt_atom.size();
+        const size_t b_int = (sizeof(int) * pt_atom.size() + 255) & ~size_t(255);
+        const size_t b_xyz = (sizeof(double) * txyz.size() + 255) & ~size_t(255);
+        const size_t b_w = (sizeof(double) * tw.size() + 255) & ~size_t(255);
+        const size_t b_sb = (sizeof(double) * sb.size() + 255) & ~size_t(255);
+        char* gb = (char*)ctx->pool_grid.ensure(2 * b_int + b_xyz + b_w + b_sb + 1024);
+        if (!gb) return fail(MQC_HIP_ERR_DEVICE, "out of device memory (grid templates)");
+        int* d_pa = (int*)gb; int* d_pt = (int*)(gb + b_int);
+        double* d_x = (double*)(gb + 2 * b_int); double* d_w = (double*)(gb + 2 * b_int + b_xyz);
+        double* d_sb = (double*)(gb + 2 * b_int + b_xyz + b_w);
+        HIP_CHECK_RET(hipMemcpy(d_pa, pt_atom.data(), sizeof(int) * pt_atom.size(), hipMemcpyHostToDevice));
+        HIP_CHECK_RET(hipMemcpy(d_pt, pt_tmpl.data(), sizeof(int) * pt_tmpl.size(), hipMemcpyHostToDevice));
+        HIP_CHECK_RET(hipMemcpy(d_x, txyz.data(), sizeof(double) * txyz.size(), hipMemcpyHostToDevice));
+        HIP_CHECK_RET(hipMemcpy(d_w, tw.data(), sizeof(double) * tw.size(), hipMemcpyHostToDevice));
+        HIP_CHECK_RET(hipMemcpy(d_sb, sb.data(), sizeof(double) * sb.size(), hipMemcpyHostToDevice));
+        grid.pt_atom = d_pa; grid.pt_tmpl = d_pt; grid.tmpl_xyz = d_x; grid.tmpl_w = d_w; grid.sqrt_bragg = d_sb;
+    }
+
     const int n = topo.nao;
     const size_t np = (size_t)topo.npair;
-    const size_t per_frag = sizeof(double) * (per_fragment_main_doubles(n, topo.natoms) + np * np);
+    const size_t per_frag = sizeof(double) * (per_fragment_main_doubles(n, topo.natoms) + np * np + (xc.ncomp > 0 ? (size_t)n * n + grid.npts : 0));
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     free_b += ctx->pool_main.capacity() + ctx->pool_eri.capacity();
@@ -172,7 +223,14 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const std::vector<cons
         BatchView bv{};
         rc = carve_batch(ctx, topo, td, nf, true, bv);
         if (rc != MQC_HIP_OK) { (void)hipHostFree(h_counter); return rc; }
-        bv.nocc = nocc; bv.exx = 1.0; bv.e_tol = opts.energy_tol; bv.d_tol = opts.density_tol;
+        bv.nocc = nocc; bv.exx = xc.exx; bv.e_tol = opts.energy_tol; bv.d_tol = opts.density_tol;
+        bv.xc = xc; bv.grid = grid; bv.Vxc = nullptr;
+        if (xc.ncomp > 0) {
+            char* gw = (char*)ctx->pool_gridw.ensure(sizeof(double) * (size_t)nf * ((size_t)grid.npts + (size_t)n * n) + 512);
+            if (!gw) { (void)hipHostFree(h_counter); return fail(MQC_HIP_ERR_DEVICE, "out of device memory (grid weights)"); }
+            bv.grid.weights = (double*)gw;
+            bv.Vxc = (double*)(gw + ((sizeof(double) * (size_t)nf * grid.npts + 255) & ~size_t(255)));
+        }
         bv.max_iter = opts.max_iter; bv.diis_size = opts.use_diis ? opts.diis_size : 0;
         std::vector<double> hx((size_t)nf * topo.natoms * 3);
         for (int f = 0; f < nf; ++f) std::memcpy(&hx[(size_t)f * topo.natoms * 3], xyz[start + f], sizeof(double) * topo.natoms * 3);
@@ -184,6 +242,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const std::vector<cons
 
         launch_int1e(bv, topo, s);
         launch_orthogonalizer(bv, s);
+        if (xc.ncomp > 0) launch_becke_weights(bv, s);
         HIP_CHECK_RET(hipStreamSynchronize(s));
         const double t2 = now_s();
         ctx->stats.t_int1e += t2 - t1;
@@ -214,6 +273,11 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const std::vector<cons
             HIP_CHECK_RET(hipEventRecord(ctx->ev0, s));
             launch_jk_incore(bv, true, s);
             HIP_CHECK_RET(hipEventRecord(ctx->ev1, s));
+            if (xc.ncomp > 0) {
+                HIP_CHECK_RET(hipEventRecord(ctx->ev2, s));
+                launch_xc(bv, true, s);
+                HIP_CHECK_RET(hipEventRecord(ctx->ev3, s));
+            }
             launch_scf_step(bv, s);
             HIP_CHECK_RET(hipMemcpyAsync(h_counter, bv.counters, sizeof(int), hipMemcpyDeviceToHost, s));
             HIP_CHECK_RET(hipStreamSynchronize(s));
@@ -222,6 +286,12 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const std::vector<cons
             ctx->stats.fock_kernel_seconds += ms * 1e-3;
             ctx->stats.fock_bytes += (double)remaining * (double)np * (double)np * 8.0;
             ctx->stats.fock_launches += 1;
+            if (xc.ncomp > 0) {
+                float mx = 0.f;
+                (void)hipEventElapsedTime(&mx, ctx->ev2, ctx->ev3);
+                ctx->stats.xc_kernel_seconds += mx * 1e-3;
+                ctx->stats.xc_points += (double)remaining * grid.npts;
+            }
             remaining = h_counter[0];
             ++guard;
         }
@@ -247,7 +317,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const std::vector<cons
             r->e_nuclear = nuclear_repulsion(topo, xyz[start + f]);
             r->e_electronic = scal[8 * f + 4];
             r->e_total = r->e_electronic + r->e_nuclear;
-            r->e_xc = 0.0;
+            r->e_xc = xc.ncomp > 0 ? scal[8 * f + 5] : 0.0;
             r->iterations = ist[4 * f + 1];
             const bool conv = ist[4 * f + 3] != 0 && ist[4 * f] == ST_DONE;
             r->scf_status = conv ? MQC_HIP_SCF_CONVERGED : MQC_HIP_SCF_NOT_CONVERGED;
@@ -317,6 +387,8 @@ int mqc_hip_context_get(int32_t local_rank, mqc_hip_context** out)
     HIP_CHECK_RET(hipStreamCreate(&ctx->stream));
     HIP_CHECK_RET(hipEventCreate(&ctx->ev0));
     HIP_CHECK_RET(hipEventCreate(&ctx->ev1));
+    HIP_CHECK_RET(hipEventCreate(&ctx->ev2));
+    HIP_CHECK_RET(hipEventCreate(&ctx->ev3));
     std::vector<double> boys;
     build_boys_table(boys);
     HIP_CHECK_RET(hipMalloc((void**)&ctx->d_boys, sizeof(double) * boys.size()));
@@ -337,6 +409,7 @@ int mqc_hip_finalize(void)
     (void)hipSetDevice(g_ctx->device);
     (void)hipStreamSynchronize(g_ctx->stream);
     g_ctx->pool_main.release(); g_ctx->pool_eri.release(); g_ctx->pool_topo.release(); g_ctx->pool_misc.release();
+    g_ctx->pool_grid.release(); g_ctx->pool_gridw.release();
     if (g_ctx->d_boys) (void)hipFree(g_ctx->d_boys);
     if (g_ctx->d_c2s) (void)hipFree(g_ctx->d_c2s);
     (void)hipEventDestroy(g_ctx->ev0); (void)hipEventDestroy(g_ctx->ev1);
@@ -362,6 +435,7 @@ int mqc_hip_get_stats(mqc_hip_context* ctx, mqc_hip_stats_t* st)
     st->scf_iterations_total = ctx->stats.scf_iterations_total;
     st->fock_kernel_seconds = ctx->stats.fock_kernel_seconds; st->fock_bytes = ctx->stats.fock_bytes;
     st->eri_kernel_seconds = ctx->stats.eri_kernel_seconds;
+    st->xc_kernel_seconds = ctx->stats.xc_kernel_seconds; st->xc_points = ctx->stats.xc_points;
     ctx->stats = Stats();
     return MQC_HIP_OK;
 }
@@ -447,7 +521,7 @@ static int stage_setup(mqc_hip_context* ctx, const mqc_hip_molecule_t* mol, cons
     if (rc != MQC_HIP_OK) return rc;
     rc = carve_batch(ctx, sb.topo, sb.td, 1, with_eri, sb.bv);
     if (rc != MQC_HIP_OK) return rc;
-    sb.bv.nocc = std::max(1, sb.topo.nelec / 2); sb.bv.exx = 1.0;
+    sb.bv.nocc = std::max(1, sb.topo.nelec / 2); sb.bv.exx = 1.0; sb.bv.Vxc = nullptr; sb.bv.xc = XcSpec(); sb.bv.xc.ncomp = 0;
     HIP_CHECK_RET(hipMemcpy(sb.bv.xyz, mol->xyz, sizeof(double) * 3 * mol->n_atoms, hipMemcpyHostToDevice));
     HIP_CHECK_RET(hipMemset(sb.bv.istate, 0, sizeof(int) * 4));
     return MQC_HIP_OK;

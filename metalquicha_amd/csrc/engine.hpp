@@ -62,6 +62,27 @@ private:
     size_t cap_ = 0;
 };
 
+// exchange-correlation components (libxc-equivalent ids, unpolarised)
+enum : int { XC_LDA_X = 1, XC_LDA_C_VWN, XC_LDA_C_VWN_RPA, XC_GGA_X_B88, XC_GGA_C_LYP, XC_GGA_X_PBE, XC_GGA_C_PBE };
+struct XcSpec {
+    int ncomp = 0;
+    int id[6] = {0, 0, 0, 0, 0, 0};
+    double w[6] = {0, 0, 0, 0, 0, 0};
+    double exx = 1.0;     // exact-exchange fraction
+    int gga = 0;
+};
+
+// quadrature grid of a batch: per-topology point list (atom, template point) + per-fragment weights
+struct GridDev {
+    int npts = 0;
+    const int* pt_atom = nullptr;       // [npts]
+    const int* pt_tmpl = nullptr;       // [npts] index into tmpl_xyz / tmpl_w
+    const double* tmpl_xyz = nullptr;   // [ntmpl][3] relative to the nucleus
+    const double* tmpl_w = nullptr;     // [ntmpl] 4 pi r^2 dr w_leb
+    const double* sqrt_bragg = nullptr; // [natoms] sqrt(Bragg radius), Treutler size adjustment
+    double* weights = nullptr;          // [nfrag][npts] product weight x Becke cell weight
+};
+
 struct TopologyDev {
     int *sh_l, *sh_nprim, *sh_poff, *sh_atom, *sh_aoff;
     double *exps, *coefs, *zeff;
@@ -84,15 +105,18 @@ struct BatchView {      // plain pointers handed to kernels
     double* eri;                  // [nfrag][npair*npair]
     double *diis_f, *diis_e, *diis_b;   // [nfrag][8][n*n], [nfrag][8][n*n], [nfrag][8*8]
     int* diis_state;              // [nfrag][2] = n_stored, newest
-    double* scal;                 // [nfrag][8]: e_elec, e_old, de, drms, e_final, enuc(unused), -, -
+    double* scal;                 // [nfrag][8]: e_elec, e_old, de, drms, e_final, E_xc, N_electrons, -
     int* istate;                  // [nfrag][4]: state, iterations, nmo, converged
     int* counters;                // [4]: n_not_done, ...
+    XcSpec xc;                    // ncomp == 0: no XC term
+    GridDev grid;
+    double* Vxc;                  // [nfrag][n*n] un-symmetrised accumulator A (V_xc = A + A^T), or nullptr
 };
 
 struct Stats {
     double t_setup = 0, t_int1e = 0, t_eri = 0, t_fock = 0, t_scf_step = 0, t_total = 0;
     int64_t fock_launches = 0, eri_quartets = 0, scf_iterations_total = 0;
-    double fock_kernel_seconds = 0, fock_bytes = 0, eri_kernel_seconds = 0;
+    double fock_kernel_seconds = 0, fock_bytes = 0, eri_kernel_seconds = 0, xc_kernel_seconds = 0, xc_points = 0;
 };
 
 }  // namespace mqc
@@ -105,9 +129,9 @@ struct mqc_hip_context {
     double* d_c2s = nullptr;
     std::vector<double> h_c2s;                 // packed l = 0..LMAX_AO, (2l+1) x ncart(l)
     int c2s_off[8];
-    mqc::DevicePool pool_main, pool_eri, pool_topo, pool_misc;
+    mqc::DevicePool pool_main, pool_eri, pool_topo, pool_misc, pool_grid, pool_gridw;
     mqc::Stats stats;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     size_t hbm_budget_bytes = 0;
 };
 
@@ -134,6 +158,11 @@ void launch_guess(const BatchView& bv, int guess_kind, hipStream_t s);
 void launch_scf_step(const BatchView& bv, hipStream_t s);
 void launch_syev(int n, double* dA, double* dw, double* dV, hipStream_t s);
 void launch_diis_coeff(int n_stored, const double* d_overlap, double* d_coef, int* d_ok, hipStream_t s);
+void launch_becke_weights(const BatchView& bv, hipStream_t s);
+void launch_xc(const BatchView& bv, bool only_active, hipStream_t s);
+bool build_atom_template(int z, int level, int n_radial, int n_angular, std::vector<double>& xyz, std::vector<double>& w, std::string& err);
+bool parse_functional(const char* name, XcSpec& spec, std::string& err);
+double bragg_radius_bohr(int z);
 size_t scf_lds_bytes(int n);
 
 }  // namespace mqc

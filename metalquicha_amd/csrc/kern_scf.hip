@@ -413,14 +413,19 @@ __global__ void __launch_bounds__(NT) scf_step_kernel(BatchView bv)
     JacobiLds jl = carve_jacobi(lds, m, VLDS, nullptr);
 
     // ---- Fock assembly and energy (assemble_fock :985-990,1206-1228; electronic_energy :1691)
+    // The energy is taken from the Fock matrix BEFORE V_xc is added, plus E_xc
+    // (mqc_libcint_rhf.f90:985-990,1206-1228).
     double e = 0.0;
+    const double* Ax = bv.Vxc ? bv.Vxc + (size_t)f * nn : nullptr;
     for (int idx = tid; idx < n * n; idx += NT) {
         const double h = p.H[idx];
-        const double fk = h + p.J[idx] - 0.5 * bv.exx * p.K[idx];
-        p.F[idx] = fk;
+        double fk = h + p.J[idx] - 0.5 * bv.exx * p.K[idx];
         e += p.D[idx] * (h + fk);
+        if (Ax) { const int i = idx / n, j = idx - i * n; fk += Ax[idx] + Ax[j * n + i]; }
+        p.F[idx] = fk;
     }
     e = 0.5 * block_sum(e, jl.red);
+    if (Ax) e += p.scal[5];
     if (state == ST_FINAL) {
         if (tid == 0) { p.scal[4] = e; p.istate[0] = ST_DONE; }
         return;

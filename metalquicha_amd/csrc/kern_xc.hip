@@ -1,0 +1,423 @@
+// kern_xc.hip -- exchange-correlation quadrature on the Becke-partitioned Lebedev/Treutler grid.
+//
+// Replaces cuestMolecularGridCreate + cuestXCPotentialRKSCompute as called from
+// backends/cuest/backend/mqc_cuest_integrals.f90:917-953,1368-1421; numerics follow the CPU path
+// the goldens were produced with (backends/libcint/mqc_libcint_xc.F90:796-927, :1379-1455;
+// backends/libcint/mqc_libcint_ao.f90:69-448; src/methods/mqc_dft_partition.f90:82-179,324-375):
+//     rho = rowdot(chi D, chi), grad rho = 2 rowdot(chi D, grad chi), sigma = |grad rho|^2
+//     E_xc = sum w f(rho, sigma),  V += A + A^T,
+//     A = (w (v_rho/2 chi + 2 v_sigma grad rho . grad chi))^T chi
+// The functionals are this repo's own implementation of the published closed forms libxc 7.1.2
+// evaluates (lda_x, lda_c_vwn, lda_c_vwn_rpa, gga_x_b88, gga_c_lyp, gga_x_pbe, gga_c_pbe with
+// lda_c_pw_mod), unpolarised, with first derivatives by forward-mode dual numbers.
+//
+// Mapping: a workgroup walks tiles of PT grid points of ONE fragment.  Per tile: AO values (and
+// gradients) for all n functions go to LDS as [function][point]; X = D chi is formed from LDS;
+// the density, the functional and the per-point coefficient vector a follow; the n x n update
+// A += a chi^T accumulates in REGISTERS across all tiles of the workgroup and is flushed once.
+#include "engine.hpp"
+#include "md_integrals.hpp"
+
+namespace mqc {
+
+constexpr double XC_DENS_THRESHOLD = 1.0e-20;
+
+// ------------------------------------------------------------------ dual numbers (value, d/drho, d/dsigma)
+struct Dual {
+    double v, r, s;
+};
+__device__ __forceinline__ Dual mk(double v) { return {v, 0.0, 0.0}; }
+__device__ __forceinline__ Dual operator+(Dual a, Dual b) { return {a.v + b.v, a.r + b.r, a.s + b.s}; }
+__device__ __forceinline__ Dual operator-(Dual a, Dual b) { return {a.v - b.v, a.r - b.r, a.s - b.s}; }
+__device__ __forceinline__ Dual operator-(Dual a) { return {-a.v, -a.r, -a.s}; }
+__device__ __forceinline__ Dual operator*(Dual a, Dual b) { return {a.v * b.v, a.r * b.v + a.v * b.r, a.s * b.v + a.v * b.s}; }
+__device__ __forceinline__ Dual operator/(Dual a, Dual b)
+{
+    const double inv = 1.0 / b.v, q = a.v * inv;
+    return {q, (a.r - q * b.r) * inv, (a.s - q * b.s) * inv};
+}
+__device__ __forceinline__ Dual operator+(Dual a, double b) { return {a.v + b, a.r, a.s}; }
+__device__ __forceinline__ Dual operator+(double b, Dual a) { return {a.v + b, a.r, a.s}; }
+__device__ __forceinline__ Dual operator-(Dual a, double b) { return {a.v - b, a.r, a.s}; }
+__device__ __forceinline__ Dual operator-(double b, Dual a) { return {b - a.v, -a.r, -a.s}; }
+__device__ __forceinline__ Dual operator*(Dual a, double b) { return {a.v * b, a.r * b, a.s * b}; }
+__device__ __forceinline__ Dual operator*(double b, Dual a) { return {a.v * b, a.r * b, a.s * b}; }
+__device__ __forceinline__ Dual operator/(Dual a, double b) { const double i = 1.0 / b; return {a.v * i, a.r * i, a.s * i}; }
+__device__ __forceinline__ Dual operator/(double b, Dual a) { return mk(b) / a; }
+__device__ __forceinline__ Dual chain(Dual x, double f, double df) { return {f, df * x.r, df * x.s}; }
+__device__ __forceinline__ Dual dexp(Dual x) { const double f = exp(x.v); return chain(x, f, f); }
+__device__ __forceinline__ Dual dlog(Dual x) { return chain(x, log(x.v), 1.0 / x.v); }
+__device__ __forceinline__ Dual dsqrt(Dual x) { const double f = sqrt(x.v); return chain(x, f, 0.5 / f); }
+__device__ __forceinline__ Dual datan(Dual x) { return chain(x, atan(x.v), 1.0 / (1.0 + x.v * x.v)); }
+__device__ __forceinline__ Dual dasinh(Dual x) { return chain(x, asinh(x.v), 1.0 / sqrt(1.0 + x.v * x.v)); }
+__device__ __forceinline__ Dual dpow(Dual x, double p) { const double f = pow(x.v, p); return chain(x, f, p * f / x.v); }
+__device__ __forceinline__ Dual dcbrt(Dual x) { const double f = cbrt(x.v); return chain(x, f, f / (3.0 * x.v)); }
+
+// ------------------------------------------------------------------ functionals: energy per volume
+__device__ __forceinline__ Dual f_lda_x(Dual rho)
+{
+    const Dual r13 = dcbrt(rho);
+    return -0.7385587663820224 * (rho * r13);                   // -(3/4)(3/pi)^(1/3) rho^(4/3)
+}
+
+__device__ __forceinline__ Dual f_vwn(Dual rho, double A, double x0, double b, double c)
+{
+    const Dual rs = 0.6203504908994001 / dcbrt(rho);            // (3/(4 pi))^(1/3) rho^(-1/3)
+    const Dual x = dsqrt(rs);
+    const Dual X = x * x + b * x + c;
+    const double X0 = x0 * x0 + b * x0 + c;
+    const double Q = sqrt(4.0 * c - b * b);
+    const Dual at = datan(Q / (2.0 * x + b));
+    const Dual xm = x - x0;
+    const Dual ec = A * (dlog(x * x / X) + (2.0 * b / Q) * at
+                         - (b * x0 / X0) * (dlog(xm * xm / X) + (2.0 * (b + 2.0 * x0) / Q) * at));
+    return rho * ec;
+}
+
+__device__ __forceinline__ Dual f_b88(Dual rho, Dual sigma)
+{
+    const double beta = 0.0042, cx = 0.9305257363491;             // (3/2)(3/(4 pi))^(1/3)
+    const Dual rh = 0.5 * rho;
+    const Dual r43 = rh * dcbrt(rh);
+    const Dual x = dsqrt(0.25 * sigma) / r43;
+    const Dual e = -cx * r43 - beta * r43 * x * x / (1.0 + 6.0 * beta * x * dasinh(x));
+    return 2.0 * e;
+}
+
+__device__ __forceinline__ Dual f_lyp(Dual rho, Dual sigma)
+{
+    const double a = 0.04918, b = 0.132, c = 0.2533, d = 0.349;
+    const double cf = 2.871234000188191;                          // (3/10)(3 pi^2)^(2/3)
+    const Dual rm13 = 1.0 / dcbrt(rho);
+    const Dual den = 1.0 + d * rm13;
+    const Dual delta = c * rm13 + d * rm13 / den;
+    const Dual rm53 = rm13 * rm13 * rm13 * rm13 * rm13;
+    return -a * rho / den - a * b * dexp(-c * rm13) / den * (cf * rho - rm53 * sigma * ((3.0 + 7.0 * delta) * (1.0 / 72.0)));
+}
+
+constexpr double PBE_BETA = 0.06672455060314922;
+constexpr double PBE_GAMMA = 0.031090690869654895;                // (1 - ln 2)/pi^2
+constexpr double PBE_MU = 0.2195149727645171;
+constexpr double PBE_KAPPA = 0.804;
+
+__device__ __forceinline__ Dual f_pbe_x(Dual rho, Dual sigma)
+{
+    const Dual r13 = dcbrt(rho);
+    const Dual kf = 3.0936677262801355 * r13;                     // (3 pi^2)^(1/3) rho^(1/3)
+    const Dual s2 = sigma / (4.0 * kf * kf * rho * rho);
+    const Dual fx = (1.0 + PBE_KAPPA) - PBE_KAPPA / (1.0 + (PBE_MU / PBE_KAPPA) * s2);
+    return f_lda_x(rho) * fx;
+}
+
+__device__ __forceinline__ Dual f_pbe_c(Dual rho, Dual sigma)
+{
+    const double A = 0.0310907, a1 = 0.21370, b1 = 7.5957, b2 = 3.5876, b3 = 1.6382, b4 = 0.49294;   // lda_c_pw_mod
+    const Dual r13 = dcbrt(rho);
+    const Dual rs = 0.6203504908994001 / r13;
+    const Dual srs = dsqrt(rs);
+    const Dual q = 2.0 * A * (b1 * srs + b2 * rs + b3 * rs * srs + b4 * rs * rs);
+    const Dual ec = -2.0 * A * (1.0 + a1 * rs) * dlog(1.0 + 1.0 / q);
+    const Dual kf = 3.0936677262801355 * r13;
+    const Dual ks2 = (4.0 / M_PI) * kf;
+    const Dual t2 = sigma / (4.0 * ks2 * rho * rho);
+    const Dual Aa = (PBE_BETA / PBE_GAMMA) / (dexp(-ec / PBE_GAMMA) - 1.0);
+    const Dual at2 = Aa * t2;
+    const Dual H = PBE_GAMMA * dlog(1.0 + (PBE_BETA / PBE_GAMMA) * t2 * (1.0 + at2) / (1.0 + at2 + at2 * at2));
+    return rho * (ec + H);
+}
+
+// f = rho * eps_xc per volume and its derivatives, zero below the density threshold
+__device__ __forceinline__ void eval_functional(const XcSpec& xc, double rho, double sigma, double& f, double& vr, double& vs)
+{
+    f = 0.0; vr = 0.0; vs = 0.0;
+    if (!(rho > XC_DENS_THRESHOLD)) return;
+    const Dual R = {rho, 1.0, 0.0};
+    const Dual S = {fmax(sigma, 1.0e-40), 0.0, 1.0};
+    for (int k = 0; k < xc.ncomp; ++k) {
+        Dual d;
+        switch (xc.id[k]) {
+            case XC_LDA_X: d = f_lda_x(R); break;
+            case XC_LDA_C_VWN: d = f_vwn(R, 0.0310907, -0.10498, 3.72744, 12.9352); break;
+            case XC_LDA_C_VWN_RPA: d = f_vwn(R, 0.0310907, -0.409286, 13.0720, 42.7198); break;
+            case XC_GGA_X_B88: d = f_b88(R, S); break;
+            case XC_GGA_C_LYP: d = f_lyp(R, S); break;
+            case XC_GGA_X_PBE: d = f_pbe_x(R, S); break;
+            case XC_GGA_C_PBE: d = f_pbe_c(R, S); break;
+            default: d = mk(0.0);
+        }
+        f += xc.w[k] * d.v; vr += xc.w[k] * d.r; vs += xc.w[k] * d.s;
+    }
+}
+
+// ------------------------------------------------------------------ Becke / Treutler partition weights
+__device__ __forceinline__ double becke_cutoff(double nu)
+{
+    double f = nu;
+    f = 0.5 * f * (3.0 - f * f);
+    f = 0.5 * f * (3.0 - f * f);
+    f = 0.5 * f * (3.0 - f * f);
+    return 0.5 * (1.0 - f);
+}
+
+constexpr int BECKE_MAX_ATOMS = 64;
+
+__global__ void __launch_bounds__(256) becke_weights_kernel(BatchView bv)
+{
+    const int f = blockIdx.y;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const GridDev& gd = bv.grid;
+    if (g >= gd.npts) return;
+    const int na = bv.topo.natoms;
+    const double* xyz = bv.xyz + (size_t)f * na * 3;
+    const int owner = gd.pt_atom[g], it = gd.pt_tmpl[g];
+    const double px = xyz[3 * owner] + gd.tmpl_xyz[3 * it], py = xyz[3 * owner + 1] + gd.tmpl_xyz[3 * it + 1],
+                 pz = xyz[3 * owner + 2] + gd.tmpl_xyz[3 * it + 2];
+    double w = gd.tmpl_w[it];
+    if (na > 1) {
+        double dist[BECKE_MAX_ATOMS], cell[BECKE_MAX_ATOMS];
+        for (int i = 0; i < na; ++i) {
+            const double dx = px - xyz[3 * i], dy = py - xyz[3 * i + 1], dz = pz - xyz[3 * i + 2];
+            dist[i] = sqrt(dx * dx + dy * dy + dz * dz);
+            cell[i] = 1.0;
+        }
+        for (int i = 0; i < na; ++i)
+            for (int j = i + 1; j < na; ++j) {
+                const double dx = xyz[3 * i] - xyz[3 * j], dy = xyz[3 * i + 1] - xyz[3 * j + 1], dz = xyz[3 * i + 2] - xyz[3 * j + 2];
+                const double mu = (dist[i] - dist[j]) / sqrt(dx * dx + dy * dy + dz * dz);
+                const double chi = gd.sqrt_bragg[i] / gd.sqrt_bragg[j];
+                double a = 0.25 * (1.0 / chi - chi);
+                a = fmax(-0.5, fmin(0.5, a));
+                const double nu = mu + a * (1.0 - mu * mu);
+                const double s = becke_cutoff(nu);
+                cell[i] *= s;
+                cell[j] *= (1.0 - s);
+            }
+        double tot = 0.0;
+        for (int i = 0; i < na; ++i) tot += cell[i];
+        w = tot > 0.0 ? w * cell[owner] / tot : 0.0;
+    }
+    gd.weights[(size_t)f * gd.npts + g] = w;
+}
+
+void launch_becke_weights(const BatchView& bv, hipStream_t s)
+{
+    dim3 grid((bv.grid.npts + 255) / 256, bv.nfrag), block(256);
+    hipLaunchKernelGGL(becke_weights_kernel, grid, block, 0, s, bv);
+}
+
+// ------------------------------------------------------------------ the per-iteration quadrature kernel
+constexpr int XC_NT = 256;
+
+// one (point, shell) work item: values (and gradients) of the shell's spherical functions
+template <bool GGA>
+__device__ __forceinline__ void eval_shell(const TopologyDev& tp, const double* __restrict__ xyz, int sh, double px, double py, double pz,
+                                           double* __restrict__ chi, double* __restrict__ gx, double* __restrict__ gy,
+                                           double* __restrict__ gz, int ptp, int p)
+{
+    const int l = tp.sh_l[sh], at = tp.sh_atom[sh], ao = tp.sh_aoff[sh];
+    const double dx = px - xyz[3 * at], dy = py - xyz[3 * at + 1], dz = pz - xyz[3 * at + 2];
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    const double* e = tp.exps + tp.sh_poff[sh];
+    const double* c = tp.coefs + tp.sh_poff[sh];
+    double rad = 0.0, drad = 0.0;
+    const int np = tp.sh_nprim[sh];
+    for (int i = 0; i < np; ++i) {
+        const double t = c[i] * exp(-e[i] * r2);
+        rad += t; drad -= 2.0 * e[i] * t;
+    }
+    if (l == 0) {
+        chi[ao * ptp + p] = rad;
+        if (GGA) { gx[ao * ptp + p] = dx * drad; gy[ao * ptp + p] = dy * drad; gz[ao * ptp + p] = dz * drad; }
+    } else if (l == 1) {
+        chi[ao * ptp + p] = dx * rad; chi[(ao + 1) * ptp + p] = dy * rad; chi[(ao + 2) * ptp + p] = dz * rad;
+        if (GGA) {
+            gx[ao * ptp + p] = rad + dx * dx * drad; gy[ao * ptp + p] = dx * dy * drad; gz[ao * ptp + p] = dx * dz * drad;
+            gx[(ao + 1) * ptp + p] = dy * dx * drad; gy[(ao + 1) * ptp + p] = rad + dy * dy * drad; gz[(ao + 1) * ptp + p] = dy * dz * drad;
+            gx[(ao + 2) * ptp + p] = dz * dx * drad; gy[(ao + 2) * ptp + p] = dz * dy * drad; gz[(ao + 2) * ptp + p] = rad + dz * dz * drad;
+        }
+    } else {
+        // l = 2: Cartesian xx,xy,xz,yy,yz,zz -> libcint's xy,yz,z2,xz,x2-y2
+        const double cv[6] = {dx * dx, dx * dy, dx * dz, dy * dy, dy * dz, dz * dz};
+        const double cgx[6] = {2.0 * dx, dy, dz, 0.0, 0.0, 0.0};
+        const double cgy[6] = {0.0, dx, 0.0, 2.0 * dy, dz, 0.0};
+        const double cgz[6] = {0.0, 0.0, dx, 0.0, dy, 2.0 * dz};
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            double v = 0.0, ax = 0.0, ay = 0.0, az = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const double w = c2s_coef<2>(nullptr, m, k);
+                v += w * cv[k]; ax += w * cgx[k]; ay += w * cgy[k]; az += w * cgz[k];
+            }
+            chi[(ao + m) * ptp + p] = v * rad;
+            if (GGA) {
+                gx[(ao + m) * ptp + p] = ax * rad + v * dx * drad;
+                gy[(ao + m) * ptp + p] = ay * rad + v * dy * drad;
+                gz[(ao + m) * ptp + p] = az * rad + v * dz * drad;
+            }
+        }
+    }
+}
+
+// PT points per tile; NV = ceil(n*n / 256) register accumulators per thread
+template <bool GGA, int PT, int NV>
+__global__ void __launch_bounds__(XC_NT) xc_kernel(BatchView bv, int only_active)
+{
+    extern __shared__ double lds[];
+    const int f = blockIdx.y;
+    if (only_active && bv.istate[4 * f] == ST_DONE) return;
+    const int n = bv.n, tid = threadIdx.x;
+    const TopologyDev& tp = bv.topo;
+    const GridDev& gd = bv.grid;
+    constexpr int PTP = PT + 1;                       // padded row: bank-conflict-free column walks
+    double* chi = lds;
+    double* gx = chi + (size_t)n * PTP;
+    double* gy = gx + (GGA ? (size_t)n * PTP : 0);
+    double* gz = gy + (GGA ? (size_t)n * PTP : 0);
+    double* X = gz + (GGA ? (size_t)n * PTP : 0);
+    double* A = X + (size_t)n * PTP;
+    double* pw = A + (size_t)n * PTP;                 // [PT] weight, then reused: w*vrho/2, 2 w vsigma grho_x,y,z
+    double* pvr = pw + PT;
+    double* pgx = pvr + PT;
+    double* pgy = pgx + PT;
+    double* pgz = pgy + PT;
+    double* red = pgz + PT;                           // 2 * 4 reduction slots
+
+    const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
+    const double* __restrict__ D = bv.D + (size_t)f * n * n;
+    const double* __restrict__ wts = gd.weights + (size_t)f * gd.npts;
+
+    double acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = 0.0;
+    double e_acc = 0.0, n_acc = 0.0;
+
+    const int ntiles = (gd.npts + PT - 1) / PT;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int g0 = tile * PT;
+        // 1. AO values for (point, shell) items, point fastest
+        for (int idx = tid; idx < tp.nshell * PT; idx += XC_NT) {
+            const int sh = idx / PT, p = idx - sh * PT;
+            const int g = g0 + p;
+            if (g < gd.npts) {
+                const int oa = gd.pt_atom[g], it = gd.pt_tmpl[g];
+                eval_shell<GGA>(tp, xyz, sh, xyz[3 * oa] + gd.tmpl_xyz[3 * it], xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1],
+                                xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2], chi, gx, gy, gz, PTP, p);
+            } else {
+                const int l = tp.sh_l[sh], ao = tp.sh_aoff[sh];
+                for (int m = 0; m < 2 * l + 1; ++m) {
+                    chi[(ao + m) * PTP + p] = 0.0;
+                    if (GGA) { gx[(ao + m) * PTP + p] = 0.0; gy[(ao + m) * PTP + p] = 0.0; gz[(ao + m) * PTP + p] = 0.0; }
+                }
+            }
+        }
+        if (tid < PT) pw[tid] = (g0 + tid < gd.npts) ? wts[g0 + tid] : 0.0;
+        __syncthreads();
+        // 2. X = D chi
+        for (int idx = tid; idx < n * PT; idx += XC_NT) {
+            const int mu = idx / PT, p = idx - mu * PT;
+            const double* __restrict__ drow = D + (size_t)mu * n;
+            double s = 0.0;
+            for (int nu = 0; nu < n; ++nu) s += drow[nu] * chi[nu * PTP + p];
+            X[mu * PTP + p] = s;
+        }
+        __syncthreads();
+        // 3. density, functional, per-point coefficients
+        if (tid < PT) {
+            const int p = tid;
+            double rho = 0.0, rx = 0.0, ry = 0.0, rz = 0.0;
+            for (int mu = 0; mu < n; ++mu) {
+                const double x = X[mu * PTP + p];
+                rho += x * chi[mu * PTP + p];
+                if (GGA) { rx += x * gx[mu * PTP + p]; ry += x * gy[mu * PTP + p]; rz += x * gz[mu * PTP + p]; }
+            }
+            rx *= 2.0; ry *= 2.0; rz *= 2.0;
+            const double sigma = GGA ? rx * rx + ry * ry + rz * rz : 0.0;
+            double fx, vr, vs;
+            eval_functional(bv.xc, rho, sigma, fx, vr, vs);
+            const double w = pw[p];
+            e_acc += w * fx;
+            n_acc += w * rho;
+            pvr[p] = 0.5 * w * vr;
+            if (GGA) { const double t = 2.0 * w * vs; pgx[p] = t * rx; pgy[p] = t * ry; pgz[p] = t * rz; }
+        }
+        __syncthreads();
+        // 4. a[mu][p]
+        for (int idx = tid; idx < n * PT; idx += XC_NT) {
+            const int mu = idx / PT, p = idx - mu * PT;
+            double a = pvr[p] * chi[mu * PTP + p];
+            if (GGA) a += pgx[p] * gx[mu * PTP + p] + pgy[p] * gy[mu * PTP + p] + pgz[p] * gz[mu * PTP + p];
+            A[mu * PTP + p] = a;
+        }
+        __syncthreads();
+        // 5. A[mu][nu] += sum_p a[mu][p] chi[nu][p]   (registers)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int idx = tid + XC_NT * k;
+            if (idx < n * n) {
+                const int mu = idx / n, nu = idx - mu * n;
+                const double* __restrict__ ar = A + mu * PTP;
+                const double* __restrict__ cr = chi + nu * PTP;
+                double s = 0.0;
+#pragma unroll 8
+                for (int p = 0; p < PT; ++p) s += ar[p] * cr[p];
+                acc[k] += s;
+            }
+        }
+        __syncthreads();
+    }
+    // flush
+    double* Vx = bv.Vxc + (size_t)f * n * n;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int idx = tid + XC_NT * k;
+        if (idx < n * n && acc[k] != 0.0) atomicAdd(&Vx[idx], acc[k]);
+    }
+    // E_xc and N_e: lanes < PT of wave 0 hold the partial sums
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { e_acc += __shfl_down(e_acc, off, 64); n_acc += __shfl_down(n_acc, off, 64); }
+    if (tid == 0) {
+        atomicAdd(&bv.scal[(size_t)f * 8 + 5], e_acc);
+        atomicAdd(&bv.scal[(size_t)f * 8 + 6], n_acc);
+    }
+    (void)red;
+}
+
+__global__ void xc_reset_kernel(BatchView bv)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < bv.nfrag) { bv.scal[(size_t)f * 8 + 5] = 0.0; bv.scal[(size_t)f * 8 + 6] = 0.0; }
+}
+
+template <bool GGA, int PT, int NV>
+static void xc_launch(const BatchView& bv, int oa, hipStream_t s)
+{
+    const int n = bv.n;
+    const size_t lds = sizeof(double) * ((size_t)(GGA ? 6 : 3) * n * (PT + 1) + 5 * PT + 16);
+    auto kern = xc_kernel<GGA, PT, NV>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int ntiles = (bv.grid.npts + PT - 1) / PT;
+    int gx = (8192 + bv.nfrag - 1) / bv.nfrag;       // a few workgroups per CU overall; many tiles per workgroup
+    if (gx > ntiles) gx = ntiles;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(kern, dim3(gx, bv.nfrag), dim3(XC_NT), lds, s, bv, oa);
+}
+
+void launch_xc(const BatchView& bv, bool only_active, hipStream_t s)
+{
+    const int n = bv.n, oa = only_active ? 1 : 0;
+    (void)hipMemsetAsync(bv.Vxc, 0, sizeof(double) * (size_t)bv.nfrag * n * n, s);
+    hipLaunchKernelGGL(xc_reset_kernel, dim3((bv.nfrag + 255) / 256), dim3(256), 0, s, bv);
+    const bool gga = bv.xc.gga != 0;
+    const int nv = (n * n + XC_NT - 1) / XC_NT;
+    // LDS: (6 or 3) * n * (PT+1) doubles: n = 48 GGA PT = 32 -> 76 KB (two workgroups per CU)
+    if (nv <= 10) {
+        if (gga) xc_launch<true, 32, 10>(bv, oa, s); else xc_launch<false, 32, 10>(bv, oa, s);
+    } else if (nv <= 29) {
+        if (gga) xc_launch<true, 16, 29>(bv, oa, s); else xc_launch<false, 32, 29>(bv, oa, s);
+    } else {
+        if (gga) xc_launch<true, 16, 54>(bv, oa, s); else xc_launch<false, 16, 54>(bv, oa, s);
+    }
+}
+
+}  // namespace mqc

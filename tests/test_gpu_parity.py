@@ -194,3 +194,62 @@ def test_jk_incore_larger_fragments_all_kernel_variants():
     J3, K3 = stages.jk_incore("cc-pvdz", frag, 0.3 * D - 1.7 * D2)
     assert np.max(np.abs(J3 - (0.3 * J - 1.7 * J2))) < 1e-10
     assert np.max(np.abs(K3 - (0.3 * K - 1.7 * K2))) < 1e-10
+
+
+# ---- Kohn-Sham: XC quadrature kernel -----------------------------------------------------------
+import json
+import os
+
+from metalquicha_amd.basis import ANGSTROM_TO_BOHR, SYMBOL_TO_Z
+from oracle import xc_oracle
+
+_CASES = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "manifest_subset.json")))["cases"]
+_KS = [c for c in _CASES if c["method"] == "dft" and c["functional"] in xc_oracle.FUNCTIONALS and "grid 3" in c["name"]]
+_RHF = [c for c in _CASES if c["method"] == "hf" and "mbe_level" not in c and "gradient" not in c["name"]]
+
+
+def _frag(c):
+    z = [SYMBOL_TO_Z[s.lower()] for s in c["symbols"]]
+    return fragment_bohr(z, np.array(c["xyz_angstrom"]) * ANGSTROM_TO_BOHR)
+
+
+@pytest.mark.parametrize("case", _RHF, ids=[c["name"] for c in _RHF])
+def test_manifest_rhf_goldens(case):
+    st = methods.ScfSettings(basis_set=case["basis"], energy_tol=1e-10, density_tol=1e-7, guess="gwh", max_iter=case["maxiter"])
+    r = methods.run_hip_scf(st, _frag(case))
+    assert not r.has_error, r.error_message
+    assert abs(r.energy.scf - case["expected_energy"]) < 1e-9
+
+
+@pytest.mark.parametrize("case", _KS, ids=[c["name"] for c in _KS])
+def test_manifest_kohn_sham_goldens(case):
+    """SVWN / PBE / B3LYP / PBE0 on H2O and PBE on CH4, cc-pVDZ, grid level 3: reference tolerance 1e-9."""
+    st = methods.ScfSettings(basis_set=case["basis"], functional=case["functional"], grid_level=case["grid_level"],
+                             energy_tol=1e-10, density_tol=1e-7, guess="gwh", max_iter=case["maxiter"])
+    frag = _frag(case)
+    r = methods.run_hip_scf(st, frag)
+    assert not r.has_error, r.error_message
+    assert r.scf_status == methods.SCF_CONVERGED
+    assert abs(r.energy.scf - case["expected_energy"]) < 1e-8          # north-star bound
+    mol = oracle_mol(case["basis"], frag)
+    o = so.run_rhf(mol, int(frag.nelec), case["maxiter"], 1e-10, 1e-7, xc=xc_oracle.XCOracle(mol, case["functional"], case["grid_level"]))
+    assert abs(r.energy.scf - o.energy) < 1e-9
+    assert r.scf_iterations == o.iterations
+
+
+def test_b3lyp_water_dimer_batch_matches_oracle():
+    rng = np.random.default_rng(77)
+    ws = [water_at(rng, c) for c in ([0, 0, 0], [5.4, 0.4, -0.2])]
+    frags = [fragment_bohr([8, 1, 1], ws[0]), fragment_bohr([8, 1, 1], ws[1]), fragment_bohr([8, 1, 1, 8, 1, 1], np.vstack(ws))]
+    st = methods.ScfSettings(basis_set="cc-pvdz", functional="b3lyp", energy_tol=1e-9, density_tol=1e-7, guess="gwh")
+    res = methods.run_hip_scf_batch(st, frags)
+    for f, r in zip(frags, res):
+        assert not r.has_error, r.error_message
+        mol = oracle_mol("cc-pvdz", f)
+        o = so.run_rhf(mol, int(f.nelec), 100, 1e-9, 1e-7, xc=xc_oracle.XCOracle(mol, "b3lyp", 3))
+        assert abs(r.energy.scf - o.energy) < 1e-8, (r.energy.scf, o.energy)
+
+
+def test_unknown_functional_is_refused():
+    r = methods.run_hip_scf(methods.ScfSettings(basis_set="sto-3g", functional="m06-l"), fragment_bohr(*WATER))
+    assert r.has_error and "not available" in r.error_message

@@ -174,4 +174,9 @@ def test_functional_derivatives_by_finite_differences():
         assert np.max(np.abs((fp - fm) / (2 * h * rho) - vr) / (np.abs(vr) + 1e-8)) < 1e-6
         fp, _, _ = xc_oracle.eval_functional(name, rho, sigma * (1 + h))
         fm, _, _ = xc_oracle.eval_functional(name, rho, sigma * (1 - h))
-        assert np.max(np.abs((fp - fm) / (2 * h * sigma) - vs) / (np.abs(vs) + 1e-8)) < 1e-5
+        if name == "svwn":
+            assert np.all(vs == 0.0)
+            continue
+        sig = np.abs(vs) * sigma > 1e-5 * np.abs(f)          # where the sigma derivative is resolvable by differences
+        assert sig.sum() > 50
+        assert np.max((np.abs((fp - fm) / (2 * h * sigma) - vs) / np.abs(vs))[sig]) < 1e-4
