@@ -42,6 +42,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--side", type=int, default=4, help="water lattice side (4 -> 64 waters)")
     ap.add_argument("--basis", default="cc-pvdz")
+    ap.add_argument("--functional", default="", help="empty = RHF (configs[2]); e.g. b3lyp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=6, help="dimers in the CPU-baseline sample")
     return ap.parse_args()
@@ -86,8 +87,8 @@ def main():
     capi.get_context(local_rank)
     system = mbe.water_cluster(args.side)
     terms = mbe.generate_mbe_term_list(system, 2)
-    settings = methods.ScfSettings(basis_set=args.basis, guess="gwh", energy_tol=1e-8, density_tol=1e-6,
-                                   device_rank=local_rank)
+    settings = methods.ScfSettings(basis_set=args.basis, functional=args.functional, guess="gwh", energy_tol=1e-8,
+                                   density_tol=1e-6, device_rank=local_rank)
 
     def barrier():
         if world > 1:
@@ -134,7 +135,8 @@ def main():
         roof = {"bound": "hbm", "kernel": "jk_incore_kernel", "achieved": (st.fock_bytes / fock_s / 1e9) if fock_s > 0 else None,
                 "peak": 8000.0, "unit": "GB/s", "frac": (st.fock_bytes / fock_s / 1e9 / 8000.0) if fock_s > 0 else None,
                 "traffic": None, "kernel_seconds": fock_s, "launches": int(st.fock_launches),
-                "algorithmic_bytes": st.fock_bytes, "other_kernel_seconds": {"eri_kernels": eri_s}}
+                "algorithmic_bytes": st.fock_bytes,
+                "other_kernel_seconds": {"eri_kernels": eri_s, "xc_kernel": st.xc_kernel_seconds}, "xc_points": st.xc_points}
         line = {
             "metric": "SCF iterations/s (whole job); MBE-2 wall time @64 fragments",
             "value": tot_iters / elapsed,
@@ -148,9 +150,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "(H2O)%d MBE-2 RHF/%s, exact in-core ERIs, %d SCFs (%d monomers + %d dimers), GWH guess, "
-                                   "e_tol 1e-8 d_tol 1e-6" % (system.n_monomers, args.basis, len(terms), system.n_monomers,
-                                                               len(terms) - system.n_monomers),
+            "config": {"workload": "(H2O)%d MBE-2 %s/%s, exact in-core ERIs, %d SCFs (%d monomers + %d dimers), GWH guess, "
+                                   "e_tol 1e-8 d_tol 1e-6%s" % (system.n_monomers, (args.functional.upper() or "RHF"), args.basis,
+                                                                 len(terms), system.n_monomers, len(terms) - system.n_monomers,
+                                                                 ", grid level 3 (pruned)" if args.functional else ""),
                        "fragments": len(terms), "parallelism": "fragments round-robin over %d GPU(s)" % world},
             "mbe2_wall_s": elapsed / n_steps,
             "mbe2_energy_hartree": e_total,

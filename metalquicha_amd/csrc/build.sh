@@ -7,7 +7,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused
 mkdir -p _obj
 pids=()
 [ -f lebedev_tables.inc ] || python3 gen_lebedev.py
-for f in kern_int1e.hip kern_eri.hip kern_fock.hip kern_scf.hip kern_xc.hip host_setup.cpp grid_host.cpp engine.cpp; do
+for f in kern_int1e.hip kern_eri.hip kern_fock.hip kern_scf.hip kern_xc.hip kern_df.hip host_setup.cpp grid_host.cpp engine.cpp; do
   o=_obj/${f%.*}.o
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ md_integrals.hpp -nt "$o" ] || [ engine.hpp -nt "$o" ] || [ ../../include/mqc_hip.h -nt "$o" ]; then
     ( hipcc $FLAGS -x hip -c "$f" -o "$o" $EXTRA ) &

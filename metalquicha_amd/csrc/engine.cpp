@@ -27,8 +27,9 @@ struct TopoDevHolder {
     TopologyDev dev;
 };
 
-static int upload_topology(mqc_hip_context* ctx, const Topology& topo, TopologyDev& td)
+static int upload_topology(mqc_hip_context* ctx, const Topology& topo, TopologyDev& td, DevicePool* pool = nullptr)
 {
+    if (!pool) pool = &ctx->pool_topo;
     const int ns = (int)topo.shells.size();
     std::vector<int> l(ns), np(ns), po(ns), at(ns), ao(ns);
     for (int s = 0; s < ns; ++s) {
@@ -38,7 +39,7 @@ static int upload_topology(mqc_hip_context* ctx, const Topology& topo, TopologyD
     const size_t ib = sizeof(int) * (size_t)ns;
     const size_t nprim = topo.exps.size();
     const size_t bytes = 5 * ((ib + 255) & ~size_t(255)) + 3 * ((sizeof(double) * (nprim + topo.natoms) + 255) & ~size_t(255)) + 1024;
-    char* base = (char*)ctx->pool_topo.ensure(bytes);
+    char* base = (char*)pool->ensure(bytes);
     if (!base) return fail(MQC_HIP_ERR_DEVICE, "out of device memory (topology)");
     auto take = [&base](size_t b) { char* p = base; base += (b + 255) & ~size_t(255); return p; };
     td.sh_l = (int*)take(ib); td.sh_nprim = (int*)take(ib); td.sh_poff = (int*)take(ib);
@@ -117,7 +118,6 @@ static int validate_options(const mqc_hip_scf_options_t& o, const Topology& topo
         if (!parse_functional(o.functional, tmp, e)) { msg = e; return MQC_HIP_ERR_UNSUPPORTED; }
         if (tmp.ncomp > 0 && topo.natoms > 64) { msg = "XC grid: fragments above 64 atoms are not supported yet"; return MQC_HIP_ERR_UNSUPPORTED; }
     }
-    if (o.density_fitting) { msg = "density fitting is not available in this build of the HIP backend"; return MQC_HIP_ERR_UNSUPPORTED; }
     if (o.want_gradient) { msg = "analytic gradients are not available in this build of the HIP backend"; return MQC_HIP_ERR_UNSUPPORTED; }
     if (o.unrestricted || topo.multiplicity != 1 || (topo.nelec % 2) != 0) {
         msg = "the HIP backend runs restricted closed-shell SCF only (multiplicity 1, even electron count)";
@@ -127,7 +127,8 @@ static int validate_options(const mqc_hip_scf_options_t& o, const Topology& topo
     if (o.max_iter < 1) { msg = "max_iter must be positive"; return MQC_HIP_ERR_VALIDATION; }
     if (o.use_diis && (o.diis_size < 0 || o.diis_size > DIIS_MAX)) { msg = "diis_size must be within 0..8"; return MQC_HIP_ERR_VALIDATION; }
     if (o.eri_mode == MQC_HIP_ERI_DIRECT) { msg = "the direct (integral-recomputing) Fock build is not available in this build; use in-core"; return MQC_HIP_ERR_UNSUPPORTED; }
-    if (!incore_supported(topo.nao)) { msg = "fragment too large for the in-core ERI path (n_ao <= 116) and no other path is built"; return MQC_HIP_ERR_UNSUPPORTED; }
+    if (!o.density_fitting && !incore_supported(topo.nao)) { msg = "fragment too large for the in-core exact-ERI path (n_ao <= 116); use density fitting"; return MQC_HIP_ERR_UNSUPPORTED; }
+    if (topo.nao > 140) { msg = "fragment too large for the LDS eigen-solver (n_ao <= 140)"; return MQC_HIP_ERR_UNSUPPORTED; }
     return MQC_HIP_OK;
 }
 
@@ -137,7 +138,7 @@ static void fill_error(mqc_hip_scf_result_t* r, const std::string& msg)
     std::snprintf(r->message, sizeof(r->message), "%s", msg.c_str());
 }
 
-int run_batch(mqc_hip_context* ctx, const Topology& topo, const std::vector<const double*>& xyz,
+int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, const std::vector<const double*>& xyz,
               const mqc_hip_scf_options_t& opts, std::vector<mqc_hip_scf_result_t*>& results)
 {
     const double t_begin = now_s();
@@ -152,6 +153,19 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const std::vector<cons
     TopologyDev td;
     rc = upload_topology(ctx, topo, td);
     if (rc != MQC_HIP_OK) return rc;
+    const bool use_df = opts.density_fitting != 0;
+    TopologyDev tdx{};
+    int naux = 0;
+    if (use_df) {
+        if (!aux) {
+            const std::string m = "density fitting needs an auxiliary basis";
+            for (auto* r : results) { fill_error(r, m); r->scf_status = MQC_HIP_SCF_NOT_RUN; }
+            return fail(MQC_HIP_ERR_VALIDATION, m);
+        }
+        rc = upload_topology(ctx, *aux, tdx, &ctx->pool_aux);
+        if (rc != MQC_HIP_OK) return rc;
+        naux = aux->nao;
+    }
 
     // ---- exchange-correlation: functional, per-element grid templates, per-topology point list
     XcSpec xc;
@@ -202,7 +216,8 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const std::vector<cons
 
     const int n = topo.nao;
     const size_t np = (size_t)topo.npair;
-    const size_t per_frag = sizeof(double) * (per_fragment_main_doubles(n, topo.natoms) + np * np + (xc.ncomp > 0 ? (size_t)n * n + grid.npts : 0));
+    const size_t two_e = use_df ? (2 * (size_t)naux * np + 2 * (size_t)naux * naux) : np * np;
+    const size_t per_frag = sizeof(double) * (per_fragment_main_doubles(n, topo.natoms) + two_e + (xc.ncomp > 0 ? (size_t)n * n + grid.npts : 0));
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     free_b += ctx->pool_main.capacity() + ctx->pool_eri.capacity();
@@ -221,8 +236,16 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const std::vector<cons
         const int nf = std::min<long>(chunk, ntot - start);
         const double t0 = now_s();
         BatchView bv{};
-        rc = carve_batch(ctx, topo, td, nf, true, bv);
+        rc = carve_batch(ctx, topo, td, nf, !use_df, bv);
         if (rc != MQC_HIP_OK) { (void)hipHostFree(h_counter); return rc; }
+        bv.naux = naux; bv.aux = tdx; bv.unit = ctx->d_unit;
+        if (use_df) {
+            const size_t a3 = (size_t)nf * naux * np, mm = (size_t)nf * naux * naux;
+            double* base = (double*)ctx->pool_df.ensure(sizeof(double) * (2 * a3 + 2 * mm) + 1024);
+            if (!base) { (void)hipHostFree(h_counter); return fail(MQC_HIP_ERR_DEVICE, "out of device memory (fitted tensor)"); }
+            bv.df_a3 = base; bv.df_b = base + a3; bv.df_metric = base + 2 * a3; bv.df_linv = base + 2 * a3 + mm;
+            HIP_CHECK_RET(hipMemsetAsync(bv.scal, 0, sizeof(double) * (size_t)nf * 8, s));
+        }
         bv.nocc = nocc; bv.exx = xc.exx; bv.e_tol = opts.energy_tol; bv.d_tol = opts.density_tol;
         bv.xc = xc; bv.grid = grid; bv.Vxc = nullptr;
         if (xc.ncomp > 0) {
@@ -249,7 +272,8 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const std::vector<cons
 
         const double stol = opts.schwarz_tol > 0.0 ? opts.schwarz_tol : 0.0;
         HIP_CHECK_RET(hipEventRecord(ctx->ev0, s));
-        launch_eri(bv, topo, stol, s);
+        if (use_df) launch_df_build(bv, topo, *aux, s);
+        else launch_eri(bv, topo, stol, s);
         HIP_CHECK_RET(hipEventRecord(ctx->ev1, s));
         HIP_CHECK_RET(hipStreamSynchronize(s));
         {
@@ -271,7 +295,8 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const std::vector<cons
         int guard = 0;
         while (remaining > 0 && guard < opts.max_iter + 2) {
             HIP_CHECK_RET(hipEventRecord(ctx->ev0, s));
-            launch_jk_incore(bv, true, s);
+            if (use_df) launch_df_jk(bv, true, s);
+            else launch_jk_incore(bv, true, s);
             HIP_CHECK_RET(hipEventRecord(ctx->ev1, s));
             if (xc.ncomp > 0) {
                 HIP_CHECK_RET(hipEventRecord(ctx->ev2, s));
@@ -284,7 +309,8 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const std::vector<cons
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
             ctx->stats.fock_kernel_seconds += ms * 1e-3;
-            ctx->stats.fock_bytes += (double)remaining * (double)np * (double)np * 8.0;
+            ctx->stats.fock_bytes += use_df ? (double)remaining * 2.0 * (double)naux * (double)np * 8.0
+                                            : (double)remaining * (double)np * (double)np * 8.0;
             ctx->stats.fock_launches += 1;
             if (xc.ncomp > 0) {
                 float mx = 0.f;
@@ -327,7 +353,10 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const std::vector<cons
             if (r->orbital_energies) std::memcpy(r->orbital_energies, &eps[(size_t)f * n], sizeof(double) * nmo);
             if (r->density) HIP_CHECK_RET(hipMemcpy(r->density, bv.D + (size_t)f * n * n, sizeof(double) * n * n, hipMemcpyDeviceToHost));
             r->has_error = 0; r->message[0] = '\0';
-            if (!std::isfinite(r->e_total)) fill_error(r, "SCF produced a non-finite energy");
+            if (use_df && scal[8 * f + 7] != 0.0)
+                fill_error(r, "density fitting: the auxiliary metric (P|Q) is near-singular (pivot below 1e-10); "
+                              "the reference would drop those modes, this backend refuses instead");
+            else if (!std::isfinite(r->e_total)) fill_error(r, "SCF produced a non-finite energy");
             else if (!conv && !opts.allow_crap_scf)
                 fill_error(r, "SCF did not converge in " + std::to_string(r->iterations) + " iterations");
             ctx->stats.scf_iterations_total += r->iterations;
@@ -393,6 +422,11 @@ int mqc_hip_context_get(int32_t local_rank, mqc_hip_context** out)
     build_boys_table(boys);
     HIP_CHECK_RET(hipMalloc((void**)&ctx->d_boys, sizeof(double) * boys.size()));
     HIP_CHECK_RET(hipMemcpy(ctx->d_boys, boys.data(), sizeof(double) * boys.size(), hipMemcpyHostToDevice));
+    {
+        const double unit[2] = {0.0, 1.0};
+        HIP_CHECK_RET(hipMalloc((void**)&ctx->d_unit, sizeof(unit)));
+        HIP_CHECK_RET(hipMemcpy(ctx->d_unit, unit, sizeof(unit), hipMemcpyHostToDevice));
+    }
     build_c2s_tables(ctx->h_c2s, ctx->c2s_off);
     HIP_CHECK_RET(hipMalloc((void**)&ctx->d_c2s, sizeof(double) * ctx->h_c2s.size()));
     HIP_CHECK_RET(hipMemcpy(ctx->d_c2s, ctx->h_c2s.data(), sizeof(double) * ctx->h_c2s.size(), hipMemcpyHostToDevice));
@@ -409,7 +443,8 @@ int mqc_hip_finalize(void)
     (void)hipSetDevice(g_ctx->device);
     (void)hipStreamSynchronize(g_ctx->stream);
     g_ctx->pool_main.release(); g_ctx->pool_eri.release(); g_ctx->pool_topo.release(); g_ctx->pool_misc.release();
-    g_ctx->pool_grid.release(); g_ctx->pool_gridw.release();
+    g_ctx->pool_grid.release(); g_ctx->pool_gridw.release(); g_ctx->pool_aux.release(); g_ctx->pool_df.release();
+    if (g_ctx->d_unit) (void)hipFree(g_ctx->d_unit);
     if (g_ctx->d_boys) (void)hipFree(g_ctx->d_boys);
     if (g_ctx->d_c2s) (void)hipFree(g_ctx->d_c2s);
     (void)hipEventDestroy(g_ctx->ev0); (void)hipEventDestroy(g_ctx->ev1);
@@ -452,7 +487,6 @@ int mqc_hip_scf_run_batch(mqc_hip_context* ctx, int64_t nfrag, const mqc_hip_mol
                           const mqc_hip_basis_t* orbitals, const mqc_hip_basis_t* auxes,
                           const mqc_hip_scf_options_t* opts, mqc_hip_scf_result_t* results)
 {
-    (void)auxes;
     if (!ctx) return fail(MQC_HIP_ERR_VALIDATION, "null context (call mqc_hip_context_get first)");
     if (nfrag < 0 || (nfrag > 0 && (!mols || !orbitals || !opts || !results)))
         return fail(MQC_HIP_ERR_VALIDATION, "null argument");
@@ -467,7 +501,9 @@ int mqc_hip_scf_run_batch(mqc_hip_context* ctx, int64_t nfrag, const mqc_hip_mol
             std::snprintf(results[i].message, sizeof(results[i].message), "fragment has no geometry or basis");
             continue;
         }
-        groups[topology_key(mols[i], orbitals[i])].push_back(i);
+        std::string key = topology_key(mols[i], orbitals[i]);
+        if (opts->density_fitting && auxes) key += "//" + topology_key(mols[i], auxes[i]);
+        groups[key].push_back(i);
     }
     int worst = MQC_HIP_OK;
     for (auto& kv : groups) {
@@ -481,10 +517,22 @@ int mqc_hip_scf_run_batch(mqc_hip_context* ctx, int64_t nfrag, const mqc_hip_mol
             worst = rc;
             continue;
         }
+        Topology auxt;
+        const Topology* auxp = nullptr;
+        if (opts->density_fitting && auxes) {
+            rc = build_topology(mols[idx[0]], auxes[idx[0]], auxt, err, AUX_LMAX);
+            if (rc != MQC_HIP_OK) {
+                for (auto i : idx) { results[i].has_error = 1; std::snprintf(results[i].message, sizeof(results[i].message), "auxiliary basis: %s", err.c_str()); }
+                set_error(err);
+                worst = rc;
+                continue;
+            }
+            auxp = &auxt;
+        }
         std::vector<const double*> xyz;
         std::vector<mqc_hip_scf_result_t*> res;
         for (auto i : idx) { xyz.push_back(mols[i].xyz); res.push_back(&results[i]); }
-        rc = run_batch(ctx, topo, xyz, *opts, res);
+        rc = run_batch(ctx, topo, auxp, xyz, *opts, res);
         if (rc != MQC_HIP_OK) {
             worst = rc;
             for (auto* r : res)
@@ -522,6 +570,7 @@ static int stage_setup(mqc_hip_context* ctx, const mqc_hip_molecule_t* mol, cons
     rc = carve_batch(ctx, sb.topo, sb.td, 1, with_eri, sb.bv);
     if (rc != MQC_HIP_OK) return rc;
     sb.bv.nocc = std::max(1, sb.topo.nelec / 2); sb.bv.exx = 1.0; sb.bv.Vxc = nullptr; sb.bv.xc = XcSpec(); sb.bv.xc.ncomp = 0;
+    sb.bv.naux = 0; sb.bv.unit = ctx->d_unit;
     HIP_CHECK_RET(hipMemcpy(sb.bv.xyz, mol->xyz, sizeof(double) * 3 * mol->n_atoms, hipMemcpyHostToDevice));
     HIP_CHECK_RET(hipMemset(sb.bv.istate, 0, sizeof(int) * 4));
     return MQC_HIP_OK;

@@ -20,6 +20,7 @@
 namespace mqc {
 
 constexpr int KERNEL_LMAX = 2;      // highest AO angular momentum the compiled kernel classes cover
+constexpr int AUX_LMAX = 3;         // highest angular momentum of an auxiliary (fitting) shell
 constexpr int DIIS_MAX = 8;         // subspace size the device ring buffers are laid out for
 
 // fragment state machine driven by the scf_step kernel
@@ -111,6 +112,12 @@ struct BatchView {      // plain pointers handed to kernels
     XcSpec xc;                    // ncomp == 0: no XC term
     GridDev grid;
     double* Vxc;                  // [nfrag][n*n] un-symmetrised accumulator A (V_xc = A + A^T), or nullptr
+    // density fitting (naux == 0: exact-ERI path)
+    TopologyDev aux;
+    int naux;
+    const double* unit;           // {0.0, 1.0}: exponent and coefficient of the unit shell
+    double *df_a3, *df_b;         // [nfrag][naux][npair]: (P|mu nu) and the fitted tensor
+    double *df_metric, *df_linv;  // [nfrag][naux][naux]
 };
 
 struct Stats {
@@ -129,7 +136,8 @@ struct mqc_hip_context {
     double* d_c2s = nullptr;
     std::vector<double> h_c2s;                 // packed l = 0..LMAX_AO, (2l+1) x ncart(l)
     int c2s_off[8];
-    mqc::DevicePool pool_main, pool_eri, pool_topo, pool_misc, pool_grid, pool_gridw;
+    mqc::DevicePool pool_main, pool_eri, pool_topo, pool_misc, pool_grid, pool_gridw, pool_aux, pool_df;
+    double* d_unit = nullptr;
     mqc::Stats stats;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     size_t hbm_budget_bytes = 0;
@@ -142,11 +150,11 @@ void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);
 void build_boys_table(std::vector<double>& table);
 void build_c2s_tables(std::vector<double>& packed, int* offsets);
-int build_topology(const mqc_hip_molecule_t& mol, const mqc_hip_basis_t& bas, Topology& topo, std::string& err);
+int build_topology(const mqc_hip_molecule_t& mol, const mqc_hip_basis_t& bas, Topology& topo, std::string& err, int max_l = KERNEL_LMAX);
 std::string topology_key(const mqc_hip_molecule_t& mol, const mqc_hip_basis_t& bas);
 double nuclear_repulsion(const Topology& topo, const double* xyz);
 
-int run_batch(mqc_hip_context* ctx, const Topology& topo, const std::vector<const double*>& xyz,
+int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, const std::vector<const double*>& xyz,
               const mqc_hip_scf_options_t& opts, std::vector<mqc_hip_scf_result_t*>& results);
 
 // kernel launchers (kern_*.hip)
@@ -159,6 +167,8 @@ void launch_scf_step(const BatchView& bv, hipStream_t s);
 void launch_syev(int n, double* dA, double* dw, double* dV, hipStream_t s);
 void launch_diis_coeff(int n_stored, const double* d_overlap, double* d_coef, int* d_ok, hipStream_t s);
 void launch_becke_weights(const BatchView& bv, hipStream_t s);
+void launch_df_build(const BatchView& bv, const Topology& topo, const Topology& aux, hipStream_t s);
+void launch_df_jk(const BatchView& bv, bool only_active, hipStream_t s);
 void launch_xc(const BatchView& bv, bool only_active, hipStream_t s);
 bool build_atom_template(int z, int level, int n_radial, int n_angular, std::vector<double>& xyz, std::vector<double>& w, std::string& err);
 bool parse_functional(const char* name, XcSpec& spec, std::string& err);

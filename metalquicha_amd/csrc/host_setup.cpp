@@ -142,7 +142,7 @@ std::string topology_key(const mqc_hip_molecule_t& mol, const mqc_hip_basis_t& b
     return os.str();
 }
 
-int build_topology(const mqc_hip_molecule_t& mol, const mqc_hip_basis_t& bas, Topology& topo, std::string& err)
+int build_topology(const mqc_hip_molecule_t& mol, const mqc_hip_basis_t& bas, Topology& topo, std::string& err, int max_l)
 {
     if (mol.n_atoms <= 0) { err = "fragment has no atoms"; return MQC_HIP_ERR_VALIDATION; }
     if (bas.n_atoms != mol.n_atoms) { err = "the basis covers a different number of atoms than the geometry has"; return MQC_HIP_ERR_VALIDATION; }
@@ -166,8 +166,9 @@ int build_topology(const mqc_hip_molecule_t& mol, const mqc_hip_basis_t& bas, To
             if (sh >= bas.n_shells) { err = "nshell_per_atom does not sum to n_shells"; return MQC_HIP_ERR_VALIDATION; }
             const int l = bas.shell_l[sh], np = bas.shell_nprim[sh];
             if (l < 0 || l > LMAX_AO) { err = "angular momentum above g is not supported"; return MQC_HIP_ERR_UNSUPPORTED; }
-            if (l > KERNEL_LMAX) {
-                err = "this build of the HIP backend covers angular momentum up to l = " + std::to_string(KERNEL_LMAX);
+            if (l > max_l) {
+                err = "this build of the HIP backend covers angular momentum up to l = " + std::to_string(max_l) +
+                      (max_l == KERNEL_LMAX ? " for orbital shells" : " for auxiliary shells");
                 return MQC_HIP_ERR_UNSUPPORTED;
             }
             if (np <= 0) { err = "shell without primitives"; return MQC_HIP_ERR_VALIDATION; }

@@ -1,0 +1,373 @@
+// kern_df.hip -- density-fitted Coulomb and exchange for a whole batch.
+//
+// Replaces cuestDFIntPlanCreate / cuestDFCoulombCompute / cuestDFSymmetricExchangeCompute
+// (backends/cuest/backend/mqc_cuest_integrals.f90:531-736,1636-1748); numerics follow the CPU
+// path: build_df_tensor (backends/libcint/mqc_libcint_integrals.F90:913-1038: (mu nu|P) and (P|Q)
+// over the same kernel, B = (mu nu|Q) J^{-1/2}) and build_fock_df
+// (backends/libcint/mqc_libcint_rhf.f90:1576-1646: c_P = sum B D, J = sum_P B_P c_P,
+// W_P = B_P C_occ, K = 2 sum_P W_P W_P^T).
+//
+// J and K depend on the fitted tensor only through B B^T, which is the same for ANY square root of
+// the metric; the engine uses the Cholesky factor (B = L^{-1} (P|mu nu)) instead of the symmetric
+// J^{-1/2} the reference forms by eigen-decomposition.  The reference drops metric eigenvalues
+// below 1e-10; a metric that is that close to singular is REFUSED here (pivot test) rather than
+// silently treated differently.
+//
+// Layouts per fragment:  A3 / Bfit [naux][npair] (auxiliary index major, packed AO pairs fastest:
+// every pass streams contiguous rows), metric / Linv [naux][naux].
+#include "engine.hpp"
+#include "md_integrals.hpp"
+
+namespace mqc {
+
+constexpr int DF_NT = 256;
+constexpr double DF_PIVOT_FLOOR = 1.0e-10;    // metric_inverse_sqrt's eigen-threshold (mqc_libcint_integrals.F90:1002)
+
+__device__ __forceinline__ ShellRef df_shell(const TopologyDev& tp, const double* xyz, int s)
+{
+    ShellRef r;
+    r.nprim = tp.sh_nprim[s];
+    r.exps = tp.exps + tp.sh_poff[s];
+    r.coefs = tp.coefs + tp.sh_poff[s];
+    const int at = tp.sh_atom[s];
+    r.x = xyz[3 * at]; r.y = xyz[3 * at + 1]; r.z = xyz[3 * at + 2];
+    return r;
+}
+
+__device__ __forceinline__ ShellRef unit_shell(const double* unit)
+{
+    // exponent 0, coefficient 1: turns a four-centre routine into a three- or two-centre one
+    ShellRef r;
+    r.nprim = 1; r.exps = unit; r.coefs = unit + 1; r.x = 0.0; r.y = 0.0; r.z = 0.0;
+    return r;
+}
+
+// cart -> sph of one index, rolled (DF blocks are not the hot path)
+template <int L>
+__device__ __forceinline__ void df_c2s(const double* c2s, int pre, int post, const double* in, double* out)
+{
+    constexpr int NC = ncart(L), NS = nsph(L);
+    for (int a = 0; a < pre; ++a)
+        for (int s = 0; s < NS; ++s)
+            for (int r = 0; r < post; ++r) {
+                double v = 0.0;
+                for (int c = 0; c < NC; ++c) v += c2s_coef<L>(c2s, s, c) * in[(a * NC + c) * post + r];
+                out[(a * NS + s) * post + r] = v;
+            }
+}
+
+// (ab|P): thread = (task, fragment); task = (A, B, P) with la >= lb
+template <int LA, int LB, int LC>
+__global__ void __launch_bounds__(64) df3c_kernel(BatchView bv, const int* __restrict__ tasks, int ntask)
+{
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= (long)ntask * bv.nfrag) return;
+    const int it = (int)(tid / bv.nfrag), f = (int)(tid % bv.nfrag);
+    const int A = tasks[3 * it], B = tasks[3 * it + 1], P = tasks[3 * it + 2];
+    const double* xyz = bv.xyz + (size_t)f * bv.topo.natoms * 3;
+    ShellRef a = df_shell(bv.topo, xyz, A), b = df_shell(bv.topo, xyz, B), c = df_shell(bv.aux, xyz, P);
+    ShellRef u = unit_shell(bv.unit);
+    constexpr int NC = ncart(LA) * ncart(LB) * ncart(LC);
+    constexpr int NSA = nsph(LA), NSB = nsph(LB), NSC = nsph(LC);
+    double cart[NC], tmp[NC];
+    eri_cart_block<LA, LB, LC, 0>(a, b, c, u, bv.boys, cart);
+    df_c2s<LA>(bv.c2s, 1, ncart(LB) * ncart(LC), cart, tmp);
+    df_c2s<LB>(bv.c2s, NSA, ncart(LC), tmp, cart);
+    df_c2s<LC>(bv.c2s, NSA * NSB, 1, cart, tmp);
+    const int oa = bv.topo.sh_aoff[A], ob = bv.topo.sh_aoff[B], oc = bv.aux.sh_aoff[P];
+    const size_t np = (size_t)bv.npair;
+    double* A3 = bv.df_a3 + (size_t)f * bv.naux * np;
+    for (int i = 0; i < NSA; ++i)
+        for (int j = 0; j < NSB; ++j) {
+            if (A == B && j > i) continue;
+            const int I = oa + i, J = ob + j;
+            const size_t pr = I >= J ? (size_t)I * (I + 1) / 2 + J : (size_t)J * (J + 1) / 2 + I;
+            for (int k = 0; k < NSC; ++k) A3[(size_t)(oc + k) * np + pr] = tmp[(i * NSB + j) * NSC + k];
+        }
+}
+
+// (P|Q): thread = (aux shell pair P >= Q ordered lp >= lq, fragment)
+template <int LP, int LQ>
+__global__ void __launch_bounds__(64) df2c_kernel(BatchView bv, const int* __restrict__ tasks, int ntask)
+{
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= (long)ntask * bv.nfrag) return;
+    const int it = (int)(tid / bv.nfrag), f = (int)(tid % bv.nfrag);
+    const int P = tasks[2 * it], Q = tasks[2 * it + 1];
+    const double* xyz = bv.xyz + (size_t)f * bv.topo.natoms * 3;
+    ShellRef p = df_shell(bv.aux, xyz, P), q = df_shell(bv.aux, xyz, Q);
+    ShellRef u = unit_shell(bv.unit);
+    constexpr int NC = ncart(LP) * ncart(LQ);
+    constexpr int NSP = nsph(LP), NSQ = nsph(LQ);
+    double cart[NC], tmp[NC];
+    eri_cart_block<LP, 0, LQ, 0>(p, u, q, u, bv.boys, cart);
+    df_c2s<LP>(bv.c2s, 1, ncart(LQ), cart, tmp);
+    df_c2s<LQ>(bv.c2s, NSP, 1, tmp, cart);
+    const int op = bv.aux.sh_aoff[P], oq = bv.aux.sh_aoff[Q];
+    const int na = bv.naux;
+    double* M = bv.df_metric + (size_t)f * na * na;
+    for (int i = 0; i < NSP; ++i)
+        for (int k = 0; k < NSQ; ++k) {
+            const double v = cart[i * NSQ + k];
+            M[(size_t)(op + i) * na + oq + k] = v;
+            M[(size_t)(oq + k) * na + op + i] = v;
+        }
+}
+
+// In-place Cholesky M = L L^T (lower) and Linv = L^{-1}, one workgroup per fragment, global memory.
+__global__ void __launch_bounds__(DF_NT) df_cholesky_kernel(BatchView bv)
+{
+    const int f = blockIdx.x, tid = threadIdx.x, na = bv.naux;
+    double* M = bv.df_metric + (size_t)f * na * na;
+    double* Li = bv.df_linv + (size_t)f * na * na;
+    __shared__ double s_d;
+    __shared__ int s_bad;
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    for (int k = 0; k < na; ++k) {
+        if (tid == 0) {
+            const double akk = M[(size_t)k * na + k];
+            if (!(akk > DF_PIVOT_FLOOR)) s_bad = 1;
+            s_d = sqrt(akk > DF_PIVOT_FLOOR ? akk : 1.0);
+        }
+        __syncthreads();
+        const double d = s_d;
+        for (int i = k + tid; i < na; i += DF_NT) M[(size_t)i * na + k] = (i == k) ? d : M[(size_t)i * na + k] / d;
+        __syncthreads();
+        // trailing update of the lower triangle: rows i > k, columns k < j <= i
+        const int m = na - k - 1;
+        for (long idx = tid; idx < (long)m * m; idx += DF_NT) {
+            const int ii = (int)(idx / m), jj = (int)(idx % m);
+            if (jj > ii) continue;
+            const int i = k + 1 + ii, j = k + 1 + jj;
+            M[(size_t)i * na + j] -= M[(size_t)i * na + k] * M[(size_t)j * na + k];
+        }
+        __syncthreads();
+    }
+    // Linv by forward substitution, one column per thread: L X = I
+    for (int c = tid; c < na; c += DF_NT) {
+        for (int r = 0; r < na; ++r) {
+            double s = (r == c) ? 1.0 : 0.0;
+            if (r < c) { Li[(size_t)r * na + c] = 0.0; continue; }
+            for (int t = c; t < r; ++t) s -= M[(size_t)r * na + t] * Li[(size_t)t * na + c];
+            Li[(size_t)r * na + c] = s / M[(size_t)r * na + r];
+        }
+    }
+    if (tid == 0 && s_bad) bv.scal[(size_t)f * 8 + 7] = 1.0;   // near-singular metric: reported by the host
+}
+
+// Bfit[R][col] = sum_{S <= R} Linv[R][S] A3[S][col]; thread = one packed pair column, 8 rows at a time
+__global__ void __launch_bounds__(DF_NT) df_fit_kernel(BatchView bv)
+{
+    const int f = blockIdx.y, na = bv.naux;
+    const size_t np = (size_t)bv.npair;
+    const long col = (long)blockIdx.x * DF_NT + threadIdx.x;
+    if (col >= (long)np) return;
+    const double* __restrict__ A3 = bv.df_a3 + (size_t)f * na * np;
+    double* __restrict__ Bf = bv.df_b + (size_t)f * na * np;
+    const double* __restrict__ Li = bv.df_linv + (size_t)f * na * na;
+    constexpr int RB = 8;
+    for (int r0 = 0; r0 < na; r0 += RB) {
+        double acc[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = 0.0;
+        const int rmax = min(r0 + RB, na);
+        for (int s = 0; s < rmax; ++s) {
+            const double a = A3[(size_t)s * np + col];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int R = r0 + r;
+                if (R < na && s <= R) acc[r] += Li[(size_t)R * na + s] * a;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) if (r0 + r < na) Bf[(size_t)(r0 + r) * np + col] = acc[r];
+    }
+}
+
+__device__ __forceinline__ void df_unpack(int idx, int& k, int& l)
+{
+    k = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+    while ((k + 1) * (k + 2) / 2 <= idx) ++k;
+    while (k * (k + 1) / 2 > idx) --k;
+    l = idx - k * (k + 1) / 2;
+}
+
+// J: c_R = sum_pairs B[R][pair] (2 - delta) D[pair];  J[pair] = sum_R B[R][pair] c_R.  One workgroup per fragment.
+__global__ void __launch_bounds__(DF_NT) df_j_kernel(BatchView bv, int only_active)
+{
+    extern __shared__ double lds[];
+    const int f = blockIdx.x, tid = threadIdx.x, n = bv.n, na = bv.naux;
+    if (only_active && bv.istate[4 * f] == ST_DONE) return;
+    const size_t np = (size_t)bv.npair;
+    const double* __restrict__ Bf = bv.df_b + (size_t)f * na * np;
+    const double* __restrict__ D = bv.D + (size_t)f * n * n;
+    double* __restrict__ J = bv.J + (size_t)f * n * n;
+    double* Dp = lds;             // np
+    double* c = lds + np;         // na
+    for (int idx = tid; idx < (int)np; idx += DF_NT) {
+        int k, l;
+        df_unpack(idx, k, l);
+        const double d = D[k * n + l];
+        Dp[idx] = k == l ? d : 2.0 * d;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int R = wave; R < na; R += DF_NT / 64) {
+        const double* __restrict__ row = Bf + (size_t)R * np;
+        double s = 0.0;
+        for (int idx = lane; idx < (int)np; idx += 64) s += row[idx] * Dp[idx];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) c[R] = s;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < (int)np; idx += DF_NT) {
+        double s = 0.0;
+        for (int R = 0; R < na; ++R) s += Bf[(size_t)R * np + idx] * c[R];
+        int k, l;
+        df_unpack(idx, k, l);
+        J[k * n + l] = s; J[l * n + k] = s;
+    }
+}
+
+// K = 2 sum_R W_R W_R^T, W_R = B_R C_occ.  grid = (R-chunks, fragment); K accumulates in registers
+// over the chunk and is flushed with atomics (K is zeroed by the launcher).
+template <int NV>
+__global__ void __launch_bounds__(DF_NT) df_k_kernel(BatchView bv, int only_active)
+{
+    extern __shared__ double lds[];
+    const int f = blockIdx.y, tid = threadIdx.x, n = bv.n, na = bv.naux, o = bv.nocc;
+    if (only_active && bv.istate[4 * f] == ST_DONE) return;
+    const size_t np = (size_t)bv.npair;
+    const double* __restrict__ Bf = bv.df_b + (size_t)f * na * np;
+    const double* __restrict__ C = bv.C + (size_t)f * n * n;
+    double* Bs = lds;                       // n x (n+1) unpacked B_R
+    double* Co = Bs + (size_t)n * (n + 1);  // n x o occupied orbitals
+    double* W = Co + (size_t)n * o;         // n x (o+1)
+    const int ldb = n + 1, ldw = o + 1;
+    for (int idx = tid; idx < n * o; idx += DF_NT) { const int r = idx / o, i = idx - r * o; Co[idx] = C[r * n + i]; }
+    double acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = 0.0;
+    __syncthreads();
+    for (int R = blockIdx.x; R < na; R += gridDim.x) {
+        const double* __restrict__ row = Bf + (size_t)R * np;
+        for (int idx = tid; idx < (int)np; idx += DF_NT) {
+            int k, l;
+            df_unpack(idx, k, l);
+            const double v = row[idx];
+            Bs[k * ldb + l] = v; Bs[l * ldb + k] = v;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < n * o; idx += DF_NT) {
+            const int mu = idx / o, i = idx - mu * o;
+            double s = 0.0;
+            for (int la = 0; la < n; ++la) s += Bs[mu * ldb + la] * Co[la * o + i];
+            W[mu * ldw + i] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int idx = tid + DF_NT * k;
+            if (idx < n * n) {
+                const int mu = idx / n, nu = idx - mu * n;
+                double s = 0.0;
+                for (int i = 0; i < o; ++i) s += W[mu * ldw + i] * W[nu * ldw + i];
+                acc[k] += s;
+            }
+        }
+        __syncthreads();
+    }
+    double* K = bv.K + (size_t)f * n * n;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int idx = tid + DF_NT * k;
+        if (idx < n * n && acc[k] != 0.0) atomicAdd(&K[idx], 2.0 * acc[k]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+template <int LA, int LB, int LC>
+static void df3c_launch(const BatchView& bv, const std::vector<int>& t, int* d, hipStream_t s)
+{
+    const int nt = (int)t.size() / 3;
+    if (!nt) return;
+    (void)hipMemcpyAsync(d, t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice, s);
+    const long total = (long)nt * bv.nfrag;
+    hipLaunchKernelGGL((df3c_kernel<LA, LB, LC>), dim3((int)((total + 63) / 64)), dim3(64), 0, s, bv, d, nt);
+}
+
+template <int LP, int LQ>
+static void df2c_launch(const BatchView& bv, const std::vector<int>& t, int* d, hipStream_t s)
+{
+    const int nt = (int)t.size() / 2;
+    if (!nt) return;
+    (void)hipMemcpyAsync(d, t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice, s);
+    const long total = (long)nt * bv.nfrag;
+    hipLaunchKernelGGL((df2c_kernel<LP, LQ>), dim3((int)((total + 63) / 64)), dim3(64), 0, s, bv, d, nt);
+}
+
+void launch_df_build(const BatchView& bv, const Topology& topo, const Topology& aux, hipStream_t s)
+{
+    static DevicePool lists;
+    const int ns = (int)topo.shells.size(), nx = (int)aux.shells.size();
+    // bucket tasks
+    std::vector<int> t3[3][3][4], t2[4][4];
+    for (int A = 0; A < ns; ++A)
+        for (int B = 0; B <= A; ++B) {
+            int a = A, b = B;
+            if (topo.shells[a].l < topo.shells[b].l) std::swap(a, b);
+            for (int P = 0; P < nx; ++P) {
+                auto& v = t3[topo.shells[a].l][topo.shells[b].l][aux.shells[P].l];
+                v.push_back(a); v.push_back(b); v.push_back(P);
+            }
+        }
+    for (int P = 0; P < nx; ++P)
+        for (int Q = 0; Q <= P; ++Q) {
+            int p = P, q = Q;
+            if (aux.shells[p].l < aux.shells[q].l) std::swap(p, q);
+            auto& v = t2[aux.shells[p].l][aux.shells[q].l];
+            v.push_back(p); v.push_back(q);
+        }
+    size_t tot = 0;
+    for (auto& x : t3) for (auto& y : x) for (auto& z : y) tot += z.size();
+    for (auto& x : t2) for (auto& y : x) tot += y.size();
+    int* d = (int*)lists.ensure((tot + 64) * sizeof(int));
+    size_t off = 0;
+#define DF3(a, b, c) df3c_launch<a, b, c>(bv, t3[a][b][c], d + off, s); off += t3[a][b][c].size();
+#define DF3_ALLC(a, b) DF3(a, b, 0) DF3(a, b, 1) DF3(a, b, 2) DF3(a, b, 3)
+    DF3_ALLC(0, 0) DF3_ALLC(1, 0) DF3_ALLC(1, 1) DF3_ALLC(2, 0) DF3_ALLC(2, 1) DF3_ALLC(2, 2)
+#undef DF3_ALLC
+#undef DF3
+#define DF2(p, q) df2c_launch<p, q>(bv, t2[p][q], d + off, s); off += t2[p][q].size();
+    DF2(0, 0) DF2(1, 0) DF2(1, 1) DF2(2, 0) DF2(2, 1) DF2(2, 2) DF2(3, 0) DF2(3, 1) DF2(3, 2) DF2(3, 3)
+#undef DF2
+    hipLaunchKernelGGL(df_cholesky_kernel, dim3(bv.nfrag), dim3(DF_NT), 0, s, bv);
+    hipLaunchKernelGGL(df_fit_kernel, dim3((bv.npair + DF_NT - 1) / DF_NT, bv.nfrag), dim3(DF_NT), 0, s, bv);
+}
+
+size_t df_k_lds_bytes(int n, int o) { return sizeof(double) * ((size_t)n * (n + 1) + (size_t)n * o + (size_t)n * (o + 1) + 8); }
+
+void launch_df_jk(const BatchView& bv, bool only_active, hipStream_t s)
+{
+    const int n = bv.n, oa = only_active ? 1 : 0;
+    (void)hipMemsetAsync(bv.K, 0, sizeof(double) * (size_t)bv.nfrag * n * n, s);
+    const size_t ldsj = sizeof(double) * ((size_t)bv.npair + bv.naux + 8);
+    (void)hipFuncSetAttribute((const void*)df_j_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsj);
+    hipLaunchKernelGGL(df_j_kernel, dim3(bv.nfrag), dim3(DF_NT), ldsj, s, bv, oa);
+    const size_t ldsk = df_k_lds_bytes(n, bv.nocc);
+    int gx = (2048 + bv.nfrag - 1) / bv.nfrag;
+    if (gx > bv.naux) gx = bv.naux;
+    if (gx < 1) gx = 1;
+    const int nv = (n * n + DF_NT - 1) / DF_NT;
+#define DFK(NVV)                                                                                     \
+    do {                                                                                             \
+        (void)hipFuncSetAttribute((const void*)df_k_kernel<NVV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsk); \
+        hipLaunchKernelGGL(df_k_kernel<NVV>, dim3(gx, bv.nfrag), dim3(DF_NT), ldsk, s, bv, oa);     \
+    } while (0)
+    if (nv <= 10) DFK(10); else if (nv <= 29) DFK(29); else DFK(54);
+#undef DFK
+}
+
+}  // namespace mqc

@@ -159,7 +159,7 @@ def _options(settings: ScfSettings, want_gradient: bool) -> capi.ScfOptions:
 class _Marshalled:
     """Keeps the numpy arrays alive for as long as the C structs that point into them."""
 
-    def __init__(self, fragment: PhysicalFragment, fb: FlatBasis):
+    def __init__(self, fragment: PhysicalFragment, fb: FlatBasis, aux: Optional[FlatBasis] = None):
         self.z = np.ascontiguousarray(fragment.element_numbers, dtype=np.int32)
         self.xyz = np.ascontiguousarray(fragment.coordinates.T, dtype=np.float64)   # atom-major
         self.ghost = None if fragment.ghost is None else np.ascontiguousarray(fragment.ghost, dtype=np.uint8)
@@ -171,6 +171,13 @@ class _Marshalled:
                               fb.nshell_per_atom.ctypes.data_as(capi.c_int64_p), fb.nshell,
                               fb.shell_l.ctypes.data_as(capi.c_int32_p), fb.shell_nprim.ctypes.data_as(capi.c_int32_p),
                               capi.dptr(fb.exps), capi.dptr(fb.coefs))
+        self.aux = aux
+        self.aux_bas = None
+        if aux is not None:
+            self.aux_bas = capi.Basis(1 if aux.spherical else 0, fragment.n_atoms,
+                                      aux.nshell_per_atom.ctypes.data_as(capi.c_int64_p), aux.nshell,
+                                      aux.shell_l.ctypes.data_as(capi.c_int32_p), aux.shell_nprim.ctypes.data_as(capi.c_int32_p),
+                                      capi.dptr(aux.exps), capi.dptr(aux.coefs))
 
 
 _BASIS_CACHE = {}
@@ -215,11 +222,13 @@ def run_hip_scf(settings: ScfSettings, fragment: PhysicalFragment, result: Optio
         ctx = capi.get_context(settings.device_rank)
         opts = _options(settings, want_gradient)
         fb = _flat_basis(settings.basis_set, fragment)
-        m = _Marshalled(fragment, fb)
+        aux = _flat_basis(settings.aux_basis_set, fragment) if settings.density_fitting else None
+        m = _Marshalled(fragment, fb, aux)
         eps = np.zeros(fb.nao)
         r = capi.ScfResult()
         r.orbital_energies = capi.dptr(eps)
-        rc = lib.mqc_hip_scf_run(ctx, C.byref(m.mol), C.byref(m.bas), None, C.byref(opts), C.byref(r))
+        rc = lib.mqc_hip_scf_run(ctx, C.byref(m.mol), C.byref(m.bas), C.byref(m.aux_bas) if aux is not None else None,
+                                 C.byref(opts), C.byref(r))
         if rc != capi.MQC_HIP_OK and not r.has_error:
             capi.check(rc)
         return _fill(result, r, eps)
@@ -240,11 +249,14 @@ def run_hip_scf_batch(settings: ScfSettings, fragments: Sequence[PhysicalFragmen
     lib = capi.load_library()
     ctx = capi.get_context(settings.device_rank)
     opts = _options(settings, False)
-    ms = [_Marshalled(f, _flat_basis(settings.basis_set, f)) for f in fragments]
+    df = settings.density_fitting
+    ms = [_Marshalled(f, _flat_basis(settings.basis_set, f), _flat_basis(settings.aux_basis_set, f) if df else None)
+          for f in fragments]
     mols = (capi.Molecule * n)(*[m.mol for m in ms])
     bass = (capi.Basis * n)(*[m.bas for m in ms])
+    auxs = (capi.Basis * n)(*[m.aux_bas for m in ms]) if df else None
     res = (capi.ScfResult * n)()
-    rc = lib.mqc_hip_scf_run_batch(ctx, n, mols, bass, None, C.byref(opts), res)
+    rc = lib.mqc_hip_scf_run_batch(ctx, n, mols, bass, auxs, C.byref(opts), res)
     if rc != capi.MQC_HIP_OK and not any(r.has_error for r in res):
         capi.check(rc)
     for out, r in zip(results, res):

@@ -253,3 +253,46 @@ def test_b3lyp_water_dimer_batch_matches_oracle():
 def test_unknown_functional_is_refused():
     r = methods.run_hip_scf(methods.ScfSettings(basis_set="sto-3g", functional="m06-l"), fragment_bohr(*WATER))
     assert r.has_error and "not available" in r.error_message
+
+
+# ---- density fitting ----------------------------------------------------------------------------
+AUX = "mqc-even-tempered-jkfit"    # this repo's own auxiliary set: DF parity is HIP vs oracle only
+
+
+def _oracle_df(frag, basis, functional=""):
+    mol = oracle_mol(basis, frag)
+    aux = oracle_mol(AUX, frag)
+    xc = xc_oracle.XCOracle(mol, functional, 3) if functional else None
+    return so.run_rhf(mol, int(frag.nelec), 100, 1e-10, 1e-8, aux=aux, xc=xc)
+
+
+@pytest.mark.parametrize("basis", ["sto-3g", "cc-pvdz"])
+def test_df_rhf_matches_oracle(basis):
+    frag = fragment_bohr(*WATER)
+    st = methods.ScfSettings(basis_set=basis, density_fitting=True, aux_basis_set=AUX, energy_tol=1e-10, density_tol=1e-8, guess="gwh")
+    r = methods.run_hip_scf(st, frag)
+    assert not r.has_error, r.error_message
+    o = _oracle_df(frag, basis)
+    assert abs(r.energy.scf - o.energy) < 1e-9
+    assert r.scf_iterations == o.iterations
+    exact = methods.run_hip_scf(methods.ScfSettings(basis_set=basis, energy_tol=1e-10, density_tol=1e-8, guess="gwh"), frag)
+    assert 1e-7 < abs(r.energy.scf - exact.energy.scf) < 1e-3        # a fitting error, not zero and not large
+
+
+def test_df_b3lyp_batch_matches_oracle():
+    rng = np.random.default_rng(12)
+    ws = [water_at(rng, c) for c in ([0, 0, 0], [5.5, -0.3, 0.4])]
+    frags = [fragment_bohr([8, 1, 1], ws[0]), fragment_bohr([8, 1, 1, 8, 1, 1], np.vstack(ws))]
+    st = methods.ScfSettings(basis_set="cc-pvdz", functional="b3lyp", density_fitting=True, aux_basis_set=AUX,
+                             energy_tol=1e-9, density_tol=1e-7, guess="gwh")
+    res = methods.run_hip_scf_batch(st, frags)
+    for f, r in zip(frags, res):
+        assert not r.has_error, r.error_message
+        o = _oracle_df(f, "cc-pvdz", "b3lyp")
+        assert abs(r.energy.scf - o.energy) < 1e-8, (r.energy.scf, o.energy)
+
+
+def test_df_without_aux_basis_file_is_an_error():
+    st = methods.ScfSettings(basis_set="sto-3g", density_fitting=True, aux_basis_set="def2-universal-jkfit")
+    r = methods.run_hip_scf(st, fragment_bohr(*WATER))
+    assert r.has_error and "not found" in r.error_message
