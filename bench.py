@@ -43,6 +43,7 @@ def parse_args():
     ap.add_argument("--side", type=int, default=4, help="water lattice side (4 -> 64 waters)")
     ap.add_argument("--basis", default="cc-pvdz")
     ap.add_argument("--functional", default="", help="empty = RHF (configs[2]); e.g. b3lyp")
+    ap.add_argument("--df", action="store_true", help="density-fitted J/K with the repo's even-tempered auxiliary set")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=6, help="dimers in the CPU-baseline sample")
     return ap.parse_args()
@@ -88,7 +89,8 @@ def main():
     system = mbe.water_cluster(args.side)
     terms = mbe.generate_mbe_term_list(system, 2)
     settings = methods.ScfSettings(basis_set=args.basis, functional=args.functional, guess="gwh", energy_tol=1e-8,
-                                   density_tol=1e-6, device_rank=local_rank)
+                                   density_tol=1e-6, device_rank=local_rank, density_fitting=args.df,
+                                   aux_basis_set="mqc-even-tempered-jkfit")
 
     def barrier():
         if world > 1:
@@ -150,10 +152,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "(H2O)%d MBE-2 %s/%s, exact in-core ERIs, %d SCFs (%d monomers + %d dimers), GWH guess, "
-                                   "e_tol 1e-8 d_tol 1e-6%s" % (system.n_monomers, (args.functional.upper() or "RHF"), args.basis,
-                                                                 len(terms), system.n_monomers, len(terms) - system.n_monomers,
-                                                                 ", grid level 3 (pruned)" if args.functional else ""),
+            "config": {"workload": "(H2O)%d MBE-2 %s/%s, %s, %d SCFs (%d monomers + %d dimers), GWH guess, e_tol 1e-8 d_tol 1e-6%s"
+                                   % (system.n_monomers, (args.functional.upper() or "RHF"), args.basis,
+                                      "density-fitted J/K (even-tempered aux)" if args.df else "exact in-core ERIs",
+                                      len(terms), system.n_monomers, len(terms) - system.n_monomers,
+                                      ", grid level 3 (pruned)" if args.functional else ""),
                        "fragments": len(terms), "parallelism": "fragments round-robin over %d GPU(s)" % world},
             "mbe2_wall_s": elapsed / n_steps,
             "mbe2_energy_hartree": e_total,

@@ -21,6 +21,7 @@
 namespace mqc {
 
 constexpr double XC_DENS_THRESHOLD = 1.0e-20;
+constexpr double XC_EXP_CUTOFF = 46.0;
 
 // ------------------------------------------------------------------ dual numbers (value, d/drho, d/dsigma)
 struct Dual {
@@ -222,8 +223,11 @@ __device__ __forceinline__ void eval_shell(const TopologyDev& tp, const double* 
     double rad = 0.0, drad = 0.0;
     const int np = tp.sh_nprim[sh];
     for (int i = 0; i < np; ++i) {
-        const double t = c[i] * exp(-e[i] * r2);
-        rad += t; drad -= 2.0 * e[i] * t;
+        const double ar2 = e[i] * r2;
+        if (ar2 < XC_EXP_CUTOFF) {           // exp(-46) = 1e-20: tight primitives vanish a fraction of a bohr from their nucleus
+            const double t = c[i] * exp(-ar2);
+            rad += t; drad -= 2.0 * e[i] * t;
+        }
     }
     if (l == 0) {
         chi[ao * ptp + p] = rad;
@@ -383,6 +387,182 @@ __global__ void __launch_bounds__(XC_NT) xc_kernel(BatchView bv, int only_active
     (void)red;
 }
 
+// ------------------------------------------------------------------ MFMA path (n <= 48)
+// The two GEMM-shaped contractions of the quadrature, X = D chi and A += a chi^T, on the FP64 matrix
+// cores (v_mfma_f64_16x16x4_f64).  Each WAVE is independent: it owns 16 grid points at a time, keeps
+// the whole density matrix as MFMA A-fragments in registers (NT16 * NP/4 doubles per lane, loaded
+// once) and the n x n result tiles as MFMA accumulators across all its points.  Operand layout
+// (guide section 3): A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
+// C/D[row = (lane>>4) + 4*reg][col = lane&15].  LDS rows are 17 doubles so both the row-wise
+// (B of X = D chi) and the column-wise (A and B of a chi^T) fragment reads are conflict-free.
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+constexpr int XM_RS = 17;      // LDS row stride in doubles (16 points + 1 pad)
+constexpr int XM_NW = 2;       // waves per workgroup
+
+template <bool GGA, int NT16>
+__global__ void __launch_bounds__(64 * XM_NW) xc_mfma_kernel(BatchView bv, int only_active)
+{
+    extern __shared__ double lds[];
+    const int f = blockIdx.y;
+    if (only_active && bv.istate[4 * f] == ST_DONE) return;
+    constexpr int NP = 16 * NT16, KS = NP / 4, NARR = GGA ? 4 : 1;
+    const int n = bv.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lo = lane & 15, hi = lane >> 4;
+    const TopologyDev& tp = bv.topo;
+    const GridDev& gd = bv.grid;
+    double* chi = lds + (size_t)wave * NARR * NP * XM_RS;
+    double* gx = chi + (GGA ? NP * XM_RS : 0);
+    double* gy = gx + (GGA ? NP * XM_RS : 0);
+    double* gz = gy + (GGA ? NP * XM_RS : 0);
+    const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
+    const double* __restrict__ D = bv.D + (size_t)f * n * n;
+    const double* __restrict__ wts = gd.weights + (size_t)f * gd.npts;
+
+    // zero the padding rows once; real rows are rewritten for every point group
+    for (int idx = lane; idx < NARR * NP * XM_RS; idx += 64) chi[idx] = 0.0;
+
+    // density matrix as A-fragments: dfrag[mt][ks] = D[16 mt + lo][4 ks + hi]
+    double dfrag[NT16][KS];
+#pragma unroll
+    for (int mt = 0; mt < NT16; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int mu = 16 * mt + lo, nu = 4 * ks + hi;
+            dfrag[mt][ks] = (mu < n && nu < n) ? D[mu * n + nu] : 0.0;
+        }
+    v4f64 vacc[NT16][NT16];
+#pragma unroll
+    for (int a = 0; a < NT16; ++a)
+#pragma unroll
+        for (int b = 0; b < NT16; ++b) vacc[a][b] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    double e_acc = 0.0, n_acc = 0.0;
+
+    const int ngroups = (gd.npts + 15) / 16;
+    for (int grp = blockIdx.x * XM_NW + wave; grp < ngroups; grp += gridDim.x * XM_NW) {
+        const int g0 = grp * 16;
+        // 1. AO values for (shell, point) items of this wave's 16 points
+        for (int idx = lane; idx < tp.nshell * 16; idx += 64) {
+            const int sh = idx >> 4, p = idx & 15;
+            const int g = g0 + p;
+            if (g < gd.npts) {
+                const int oa = gd.pt_atom[g], it = gd.pt_tmpl[g];
+                eval_shell<GGA>(tp, xyz, sh, xyz[3 * oa] + gd.tmpl_xyz[3 * it], xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1],
+                                xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2], chi, gx, gy, gz, XM_RS, p);
+            } else {
+                const int l = tp.sh_l[sh], ao = tp.sh_aoff[sh];
+                for (int m = 0; m < 2 * l + 1; ++m) {
+                    chi[(ao + m) * XM_RS + p] = 0.0;
+                    if (GGA) { gx[(ao + m) * XM_RS + p] = 0.0; gy[(ao + m) * XM_RS + p] = 0.0; gz[(ao + m) * XM_RS + p] = 0.0; }
+                }
+            }
+        }
+        const double w = (g0 + lo < gd.npts) ? wts[g0 + lo] : 0.0;
+        // (DS operations of one wave execute in order; the fence keeps the compiler from reordering)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // 2. X = D chi on the matrix cores
+        v4f64 xacc[NT16];
+#pragma unroll
+        for (int mt = 0; mt < NT16; ++mt) xacc[mt] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const double b = chi[(4 * ks + hi) * XM_RS + lo];
+#pragma unroll
+            for (int mt = 0; mt < NT16; ++mt) xacc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(dfrag[mt][ks], b, xacc[mt], 0, 0, 0);
+        }
+        // 3. density at this lane's point (p = lo): partial over the rows this lane holds, then across hi
+        double rho = 0.0, rx = 0.0, ry = 0.0, rz = 0.0;
+#pragma unroll
+        for (int mt = 0; mt < NT16; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mu = 16 * mt + hi + 4 * r;
+                const double x = xacc[mt][r];
+                rho += x * chi[mu * XM_RS + lo];
+                if (GGA) { rx += x * gx[mu * XM_RS + lo]; ry += x * gy[mu * XM_RS + lo]; rz += x * gz[mu * XM_RS + lo]; }
+            }
+        rho += __shfl_xor(rho, 16, 64); rho += __shfl_xor(rho, 32, 64);
+        if (GGA) {
+            rx += __shfl_xor(rx, 16, 64); rx += __shfl_xor(rx, 32, 64);
+            ry += __shfl_xor(ry, 16, 64); ry += __shfl_xor(ry, 32, 64);
+            rz += __shfl_xor(rz, 16, 64); rz += __shfl_xor(rz, 32, 64);
+            rx *= 2.0; ry *= 2.0; rz *= 2.0;
+        }
+        const double sigma = GGA ? rx * rx + ry * ry + rz * rz : 0.0;
+        double fx, vr, vs;
+        eval_functional(bv.xc, rho, sigma, fx, vr, vs);
+        if (hi == 0) { e_acc += w * fx; n_acc += w * rho; }
+        const double pvr = 0.5 * w * vr;
+        const double t2 = 2.0 * w * vs;
+        const double pgx = t2 * rx, pgy = t2 * ry, pgz = t2 * rz;
+        // 4. a[mu][p], written over gx (LDA: into a register-free spot is not needed, a = pvr chi on the fly)
+        double* arow = GGA ? gx : chi;
+        if (GGA) {
+#pragma unroll
+            for (int mt = 0; mt < NT16; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = (16 * mt + hi + 4 * r) * XM_RS + lo;
+                    gx[o] = pvr * chi[o] + pgx * gx[o] + pgy * gy[o] + pgz * gz[o];
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        // 5. A += a chi^T on the matrix cores: k runs over the 16 points in 4 steps
+        //    (LDA: a[mu][p] = pvr[p] chi[mu][p]; the point factor is applied to the A fragment)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            double af[NT16], bf[NT16];
+            const double pf = GGA ? 1.0 : __shfl(pvr, 4 * ks + hi, 64);    // lane (4ks+hi) has lo = that point
+#pragma unroll
+            for (int t = 0; t < NT16; ++t) {
+                af[t] = arow[(16 * t + lo) * XM_RS + 4 * ks + hi] * pf;
+                bf[t] = chi[(16 * t + lo) * XM_RS + 4 * ks + hi];
+            }
+#pragma unroll
+            for (int mt = 0; mt < NT16; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT16; ++nt) vacc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mt], bf[nt], vacc[mt][nt], 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // flush: lane holds A[mu = 16 mt + hi + 4 r][nu = 16 nt + lo]
+    double* Vx = bv.Vxc + (size_t)f * n * n;
+#pragma unroll
+    for (int mt = 0; mt < NT16; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT16; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mu = 16 * mt + hi + 4 * r, nu = 16 * nt + lo;
+                const double v = vacc[mt][nt][r];
+                if (mu < n && nu < n && v != 0.0) atomicAdd(&Vx[mu * n + nu], v);
+            }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) { e_acc += __shfl_down(e_acc, off, 64); n_acc += __shfl_down(n_acc, off, 64); }
+    if (lane == 0) {
+        atomicAdd(&bv.scal[(size_t)f * 8 + 5], e_acc);
+        atomicAdd(&bv.scal[(size_t)f * 8 + 6], n_acc);
+    }
+}
+
+template <bool GGA, int NT16>
+static void xc_mfma_launch(const BatchView& bv, int oa, hipStream_t s)
+{
+    const size_t lds = sizeof(double) * (size_t)XM_NW * (GGA ? 4 : 1) * 16 * NT16 * XM_RS;
+    auto kern = xc_mfma_kernel<GGA, NT16>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int ngroups = (bv.grid.npts + 15) / 16;
+    int gx = (16384 + bv.nfrag - 1) / bv.nfrag;
+    const int maxx = (ngroups + XM_NW - 1) / XM_NW;
+    if (gx > maxx) gx = maxx;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(kern, dim3(gx, bv.nfrag), dim3(64 * XM_NW), lds, s, bv, oa);
+}
+
 __global__ void xc_reset_kernel(BatchView bv)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -409,6 +589,12 @@ void launch_xc(const BatchView& bv, bool only_active, hipStream_t s)
     (void)hipMemsetAsync(bv.Vxc, 0, sizeof(double) * (size_t)bv.nfrag * n * n, s);
     hipLaunchKernelGGL(xc_reset_kernel, dim3((bv.nfrag + 255) / 256), dim3(256), 0, s, bv);
     const bool gga = bv.xc.gga != 0;
+    if (n <= 48) {
+        // fragment sizes of an MBE run: both GEMMs on the FP64 matrix cores
+        if (n <= 32) { if (gga) xc_mfma_launch<true, 2>(bv, oa, s); else xc_mfma_launch<false, 2>(bv, oa, s); }
+        else { if (gga) xc_mfma_launch<true, 3>(bv, oa, s); else xc_mfma_launch<false, 3>(bv, oa, s); }
+        return;
+    }
     const int nv = (n * n + XC_NT - 1) / XC_NT;
     // LDS: (6 or 3) * n * (PT+1) doubles: n = 48 GGA PT = 32 -> 76 KB (two workgroups per CU)
     if (nv <= 10) {

@@ -214,7 +214,7 @@ MQC_HD void cart_lmn(int l, int k, int& lx, int& ly, int& lz)
 
 // classes whose Cartesian block is at most this many numbers are fully unrolled into registers;
 // larger ones keep rolled component loops (tables addressed at run time) to bound code size
-constexpr int ERI_UNROLL_LIMIT = 108;
+constexpr int ERI_UNROLL_LIMIT = 324;
 
 // ---------------------------------------------------------------------------------------
 // Contracted Cartesian ERI block (ab|cd), out[((ia*NCB+ib)*NCC+ic)*NCD+id] (accumulated
