@@ -5,14 +5,24 @@ cd "$(dirname "$0")"
 OUT=../libmqc_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result -Wno-pass-failed"
 mkdir -p _obj
-pids=()
 [ -f lebedev_tables.inc ] || python3 gen_lebedev.py
+HDRS="md_integrals.hpp engine.hpp eri_kernels.hpp ../../include/mqc_hip.h"
+stale() { # obj src
+  [ ! -f "$1" ] && return 0
+  [ "$2" -nt "$1" ] && return 0
+  for h in $HDRS; do [ "$h" -nt "$1" ] && return 0; done
+  return 1
+}
+pids=()
+njobs=0
+run() { ( "$@" ) & pids+=($!); njobs=$((njobs+1)); if [ $njobs -ge 8 ]; then wait ${pids[0]}; pids=("${pids[@]:1}"); njobs=$((njobs-1)); fi; }
+for g in 12 4 13 5 14 6 10 2 11 3 9 1 8 0 7; do
+  o=_obj/kern_eri_inst_$g.o
+  if stale "$o" kern_eri_inst.hip; then run hipcc $FLAGS -DERI_GROUP=$g -x hip -c kern_eri_inst.hip -o "$o"; fi
+done
 for f in kern_int1e.hip kern_eri.hip kern_fock.hip kern_scf.hip kern_xc.hip kern_df.hip host_setup.cpp grid_host.cpp engine.cpp; do
   o=_obj/${f%.*}.o
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ md_integrals.hpp -nt "$o" ] || [ engine.hpp -nt "$o" ] || [ ../../include/mqc_hip.h -nt "$o" ]; then
-    ( hipcc $FLAGS -x hip -c "$f" -o "$o" $EXTRA ) &
-    pids+=($!)
-  fi
+  if stale "$o" "$f"; then run hipcc $FLAGS -x hip -c "$f" -o "$o"; fi
 done
 for p in "${pids[@]}"; do wait $p; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT _obj/*.o

@@ -17,6 +17,13 @@
 namespace mqc {
 const std::string& last_error_string();
 
+static int stage_check(const char* stage)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MQC_HIP_ERR_DEVICE, std::string("HIP error after stage '") + stage + "': " + hipGetErrorString(e));
+    return MQC_HIP_OK;
+}
+
 static double now_s()
 {
     using namespace std::chrono;
@@ -126,8 +133,7 @@ static int validate_options(const mqc_hip_scf_options_t& o, const Topology& topo
     if (topo.nelec < 2) { msg = "RHF: no electrons to place"; return MQC_HIP_ERR_VALIDATION; }
     if (o.max_iter < 1) { msg = "max_iter must be positive"; return MQC_HIP_ERR_VALIDATION; }
     if (o.use_diis && (o.diis_size < 0 || o.diis_size > DIIS_MAX)) { msg = "diis_size must be within 0..8"; return MQC_HIP_ERR_VALIDATION; }
-    if (o.eri_mode == MQC_HIP_ERI_DIRECT) { msg = "the direct (integral-recomputing) Fock build is not available in this build; use in-core"; return MQC_HIP_ERR_UNSUPPORTED; }
-    if (!o.density_fitting && !incore_supported(topo.nao)) { msg = "fragment too large for the in-core exact-ERI path (n_ao <= 116); use density fitting"; return MQC_HIP_ERR_UNSUPPORTED; }
+    if (!o.density_fitting && o.eri_mode == MQC_HIP_ERI_INCORE && !incore_supported(topo.nao)) { msg = "fragment too large for the in-core exact-ERI path (n_ao <= 116); use eri_mode auto/direct or density fitting"; return MQC_HIP_ERR_UNSUPPORTED; }
     if (topo.nao > 140) { msg = "fragment too large for the LDS eigen-solver (n_ao <= 140)"; return MQC_HIP_ERR_UNSUPPORTED; }
     return MQC_HIP_OK;
 }
@@ -154,6 +160,10 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
     rc = upload_topology(ctx, topo, td);
     if (rc != MQC_HIP_OK) return rc;
     const bool use_df = opts.density_fitting != 0;
+    // exact-ERI path selection (mqc_libcint_bridge.f90:819-892 with an HBM budget instead of 2 GB of host memory)
+    const bool use_direct = !use_df && (opts.eri_mode == MQC_HIP_ERI_DIRECT ||
+                                        (opts.eri_mode == MQC_HIP_ERI_AUTO && !incore_supported(topo.nao)));
+    const double direct_tol = opts.schwarz_tol > 0.0 ? opts.schwarz_tol : 1.0e-11;   // mqc_libcint_direct.f90:61
     TopologyDev tdx{};
     int naux = 0;
     if (use_df) {
@@ -216,7 +226,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
 
     const int n = topo.nao;
     const size_t np = (size_t)topo.npair;
-    const size_t two_e = use_df ? (2 * (size_t)naux * np + 2 * (size_t)naux * naux) : np * np;
+    const size_t two_e = use_df ? (2 * (size_t)naux * np + 2 * (size_t)naux * naux) : (use_direct ? 2 * (size_t)n * n : np * np);
     const size_t per_frag = sizeof(double) * (per_fragment_main_doubles(n, topo.natoms) + two_e + (xc.ncomp > 0 ? (size_t)n * n + grid.npts : 0));
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
@@ -236,7 +246,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         const int nf = std::min<long>(chunk, ntot - start);
         const double t0 = now_s();
         BatchView bv{};
-        rc = carve_batch(ctx, topo, td, nf, !use_df, bv);
+        rc = carve_batch(ctx, topo, td, nf, !use_df && !use_direct, bv);
         if (rc != MQC_HIP_OK) { (void)hipHostFree(h_counter); return rc; }
         bv.naux = naux; bv.aux = tdx; bv.unit = ctx->d_unit;
         if (use_df) {
@@ -264,15 +274,19 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         ctx->stats.t_setup += t1 - t0;
 
         launch_int1e(bv, topo, s);
+        if ((rc = stage_check("int1e")) != MQC_HIP_OK) { (void)hipHostFree(h_counter); return rc; }
         launch_orthogonalizer(bv, s);
+        if ((rc = stage_check("orthogonalizer")) != MQC_HIP_OK) { (void)hipHostFree(h_counter); return rc; }
         if (xc.ncomp > 0) launch_becke_weights(bv, s);
         HIP_CHECK_RET(hipStreamSynchronize(s));
+        if ((rc = stage_check("grid weights")) != MQC_HIP_OK) { (void)hipHostFree(h_counter); return rc; }
         const double t2 = now_s();
         ctx->stats.t_int1e += t2 - t1;
 
         const double stol = opts.schwarz_tol > 0.0 ? opts.schwarz_tol : 0.0;
         HIP_CHECK_RET(hipEventRecord(ctx->ev0, s));
         if (use_df) launch_df_build(bv, topo, *aux, s);
+        else if (use_direct) launch_direct_setup(bv, topo, s);
         else launch_eri(bv, topo, stol, s);
         HIP_CHECK_RET(hipEventRecord(ctx->ev1, s));
         HIP_CHECK_RET(hipStreamSynchronize(s));
@@ -281,7 +295,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
             (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
             ctx->stats.eri_kernel_seconds += ms * 1e-3;
         }
-        HIP_CHECK_RET(hipGetLastError());
+        if ((rc = stage_check("two-electron setup")) != MQC_HIP_OK) { (void)hipHostFree(h_counter); return rc; }
         const double t3 = now_s();
         ctx->stats.t_eri += t3 - t2;
         ctx->stats.eri_quartets += topo.n_quartets * nf;
@@ -289,15 +303,17 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         // nmo check: more occupied orbitals than the basis supports after dropping near-null modes
         launch_guess(bv, opts.guess == MQC_HIP_GUESS_CORE ? MQC_HIP_GUESS_CORE : MQC_HIP_GUESS_GWH, s);
         HIP_CHECK_RET(hipStreamSynchronize(s));
-        HIP_CHECK_RET(hipGetLastError());
+        if ((rc = stage_check("guess")) != MQC_HIP_OK) { (void)hipHostFree(h_counter); return rc; }
 
         int remaining = nf;
         int guard = 0;
         while (remaining > 0 && guard < opts.max_iter + 2) {
             HIP_CHECK_RET(hipEventRecord(ctx->ev0, s));
             if (use_df) launch_df_jk(bv, true, s);
+            else if (use_direct) launch_jk_direct(bv, topo, direct_tol, true, s);
             else launch_jk_incore(bv, true, s);
             HIP_CHECK_RET(hipEventRecord(ctx->ev1, s));
+            if (guard == 0 && (rc = stage_check("J/K build")) != MQC_HIP_OK) { (void)hipHostFree(h_counter); return rc; }
             if (xc.ncomp > 0) {
                 HIP_CHECK_RET(hipEventRecord(ctx->ev2, s));
                 launch_xc(bv, true, s);
@@ -321,7 +337,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
             remaining = h_counter[0];
             ++guard;
         }
-        HIP_CHECK_RET(hipGetLastError());
+        if ((rc = stage_check("SCF loop")) != MQC_HIP_OK) { (void)hipHostFree(h_counter); return rc; }
         const double t4 = now_s();
         ctx->stats.t_fock += t4 - t3;
 

@@ -161,6 +161,8 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
 void launch_int1e(const BatchView& bv, const Topology& topo, hipStream_t s);
 void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, hipStream_t s);
 void launch_jk_incore(const BatchView& bv, bool only_active, hipStream_t s);
+void launch_direct_setup(const BatchView& bv, const Topology& topo, hipStream_t s);
+void launch_jk_direct(const BatchView& bv, const Topology& topo, double thresh, bool only_active, hipStream_t s);
 void launch_orthogonalizer(const BatchView& bv, hipStream_t s);
 void launch_guess(const BatchView& bv, int guess_kind, hipStream_t s);
 void launch_scf_step(const BatchView& bv, hipStream_t s);

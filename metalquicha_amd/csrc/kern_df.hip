@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(DF_NT) df_j_kernel(BatchView bv, int only_acti
 
 // K = 2 sum_R W_R W_R^T, W_R = B_R C_occ.  grid = (R-chunks, fragment); K accumulates in registers
 // over the chunk and is flushed with atomics (K is zeroed by the launcher).
-template <int NV>
+template <int NV, bool BLDS>
 __global__ void __launch_bounds__(DF_NT) df_k_kernel(BatchView bv, int only_active)
 {
     extern __shared__ double lds[];
@@ -242,8 +242,8 @@ __global__ void __launch_bounds__(DF_NT) df_k_kernel(BatchView bv, int only_acti
     const size_t np = (size_t)bv.npair;
     const double* __restrict__ Bf = bv.df_b + (size_t)f * na * np;
     const double* __restrict__ C = bv.C + (size_t)f * n * n;
-    double* Bs = lds;                       // n x (n+1) unpacked B_R
-    double* Co = Bs + (size_t)n * (n + 1);  // n x o occupied orbitals
+    double* Bs = lds;                       // n x (n+1) unpacked B_R (BLDS only)
+    double* Co = Bs + (BLDS ? (size_t)n * (n + 1) : 0);  // n x o occupied orbitals
     double* W = Co + (size_t)n * o;         // n x (o+1)
     const int ldb = n + 1, ldw = o + 1;
     for (int idx = tid; idx < n * o; idx += DF_NT) { const int r = idx / o, i = idx - r * o; Co[idx] = C[r * n + i]; }
@@ -253,17 +253,26 @@ __global__ void __launch_bounds__(DF_NT) df_k_kernel(BatchView bv, int only_acti
     __syncthreads();
     for (int R = blockIdx.x; R < na; R += gridDim.x) {
         const double* __restrict__ row = Bf + (size_t)R * np;
-        for (int idx = tid; idx < (int)np; idx += DF_NT) {
-            int k, l;
-            df_unpack(idx, k, l);
-            const double v = row[idx];
-            Bs[k * ldb + l] = v; Bs[l * ldb + k] = v;
+        if (BLDS) {
+            for (int idx = tid; idx < (int)np; idx += DF_NT) {
+                int k, l;
+                df_unpack(idx, k, l);
+                const double v = row[idx];
+                Bs[k * ldb + l] = v; Bs[l * ldb + k] = v;
+            }
+            __syncthreads();
         }
-        __syncthreads();
         for (int idx = tid; idx < n * o; idx += DF_NT) {
             const int mu = idx / o, i = idx - mu * o;
             double s = 0.0;
-            for (int la = 0; la < n; ++la) s += Bs[mu * ldb + la] * Co[la * o + i];
+            if (BLDS) {
+                for (int la = 0; la < n; ++la) s += Bs[mu * ldb + la] * Co[la * o + i];
+            } else {
+                // large fragments: the packed row is read straight from global memory (L2)
+                const int mbase = mu * (mu + 1) / 2;
+                for (int la = 0; la <= mu; ++la) s += row[mbase + la] * Co[la * o + i];
+                for (int la = mu + 1; la < n; ++la) s += row[la * (la + 1) / 2 + mu] * Co[la * o + i];
+            }
             W[mu * ldw + i] = s;
         }
         __syncthreads();
@@ -347,7 +356,7 @@ void launch_df_build(const BatchView& bv, const Topology& topo, const Topology& 
     hipLaunchKernelGGL(df_fit_kernel, dim3((bv.npair + DF_NT - 1) / DF_NT, bv.nfrag), dim3(DF_NT), 0, s, bv);
 }
 
-size_t df_k_lds_bytes(int n, int o) { return sizeof(double) * ((size_t)n * (n + 1) + (size_t)n * o + (size_t)n * (o + 1) + 8); }
+size_t df_k_lds_bytes(int n, int o, bool blds) { return sizeof(double) * ((blds ? (size_t)n * (n + 1) : 0) + (size_t)n * o + (size_t)n * (o + 1) + 8); }
 
 void launch_df_jk(const BatchView& bv, bool only_active, hipStream_t s)
 {
@@ -356,17 +365,18 @@ void launch_df_jk(const BatchView& bv, bool only_active, hipStream_t s)
     const size_t ldsj = sizeof(double) * ((size_t)bv.npair + bv.naux + 8);
     (void)hipFuncSetAttribute((const void*)df_j_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsj);
     hipLaunchKernelGGL(df_j_kernel, dim3(bv.nfrag), dim3(DF_NT), ldsj, s, bv, oa);
-    const size_t ldsk = df_k_lds_bytes(n, bv.nocc);
+    const bool blds = df_k_lds_bytes(n, bv.nocc, true) <= 150 * 1024;
+    const size_t ldsk = df_k_lds_bytes(n, bv.nocc, blds);
     int gx = (2048 + bv.nfrag - 1) / bv.nfrag;
     if (gx > bv.naux) gx = bv.naux;
     if (gx < 1) gx = 1;
     const int nv = (n * n + DF_NT - 1) / DF_NT;
-#define DFK(NVV)                                                                                     \
+#define DFK(NVV, BL)                                                                                 \
     do {                                                                                             \
-        (void)hipFuncSetAttribute((const void*)df_k_kernel<NVV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsk); \
-        hipLaunchKernelGGL(df_k_kernel<NVV>, dim3(gx, bv.nfrag), dim3(DF_NT), ldsk, s, bv, oa);     \
+        (void)hipFuncSetAttribute((const void*)df_k_kernel<NVV, BL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsk); \
+        hipLaunchKernelGGL((df_k_kernel<NVV, BL>), dim3(gx, bv.nfrag), dim3(DF_NT), ldsk, s, bv, oa); \
     } while (0)
-    if (nv <= 10) DFK(10); else if (nv <= 29) DFK(29); else DFK(54);
+    if (nv <= 10) DFK(10, true); else if (nv <= 29) DFK(29, true); else if (blds) DFK(54, true); else DFK(77, false);
 #undef DFK
 }
 

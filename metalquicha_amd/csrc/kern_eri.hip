@@ -1,230 +1,29 @@
-// kern_eri.hip -- four-centre ERI formation into the HBM-resident packed tensor.
-//
-// Replaces the reference's in-core integral pass (molecule_eris,
-// backends/libcint/mqc_libcint_integrals.F90:1449, chosen by mqc_libcint_bridge.f90:819-892
-// whenever the tensor fits) and supplies the Schwarz bounds of
-// backends/libcint/mqc_libcint_direct.f90:105-153.
-//
-// MI355X mapping: the tensor is kept as a symmetric pair matrix M[f][pair(i,j)][pair(k,l)]
-// (pair(i,j) = i(i+1)/2 + j, i >= j) in HBM -- 11 MB for a cc-pVDZ water dimer, so a few
-// thousand fragments fit in 288 GB -- and every SCF iteration then streams it once
-// (kern_fock.hip).  One thread owns one contracted shell quartet of one fragment; threads
-// are ordered (quartet, fragment) with the fragment fastest, so the 64 lanes of a wave run
-// the SAME quartet class with the SAME contraction depth on 64 different geometries: no
-// divergence, exponents and coefficients come through scalar loads.  Each (la lb|lc ld)
-// class is its own template instantiation with every inner loop unrolled into registers.
-//
-// Wavefront-level Schwarz screening: a lane whose bound Q_ab * Q_cd is below the threshold
-// skips its primitive loops; when the whole wave is below (one ballot), the wave exits
-// before touching any contraction data.
-#include "engine.hpp"
-#include "md_integrals.hpp"
+// kern_eri.hip -- dispatcher of the four-centre ERI formation (kernels: eri_kernels.hpp,
+// instantiated per class group in kern_eri_inst.hip).
+#include "eri_kernels.hpp"
 
 namespace mqc {
 
-__device__ __forceinline__ ShellRef make_shell(const TopologyDev& tp, const double* xyz, int s)
-{
-    ShellRef r;
-    r.nprim = tp.sh_nprim[s];
-    r.exps = tp.exps + tp.sh_poff[s];
-    r.coefs = tp.coefs + tp.sh_poff[s];
-    const int at = tp.sh_atom[s];
-    r.x = xyz[3 * at]; r.y = xyz[3 * at + 1]; r.z = xyz[3 * at + 2];
-    return r;
-}
+#define ERI_DECL(a, b, c, d) \
+    extern template void launch_eri_class<a, b, c, d>(const BatchView&, const int*, int, int*, const double*, double, hipStream_t);
+#define SCHWARZ_DECL(a, b) \
+    extern template void launch_schwarz_class<a, b>(const BatchView&, const int*, int, int*, double*, hipStream_t);
+ERI_DECL(0, 0, 0, 0) ERI_DECL(1, 0, 0, 0) ERI_DECL(1, 0, 1, 0) ERI_DECL(1, 1, 0, 0) ERI_DECL(1, 1, 1, 0) ERI_DECL(1, 1, 1, 1)
+ERI_DECL(2, 0, 0, 0) ERI_DECL(2, 0, 1, 0) ERI_DECL(2, 0, 1, 1) ERI_DECL(2, 0, 2, 0)
+ERI_DECL(2, 1, 0, 0) ERI_DECL(2, 1, 1, 0) ERI_DECL(2, 1, 1, 1) ERI_DECL(2, 1, 2, 0) ERI_DECL(2, 1, 2, 1)
+ERI_DECL(2, 2, 0, 0) ERI_DECL(2, 2, 1, 0) ERI_DECL(2, 2, 1, 1) ERI_DECL(2, 2, 2, 0) ERI_DECL(2, 2, 2, 1) ERI_DECL(2, 2, 2, 2)
+SCHWARZ_DECL(0, 0) SCHWARZ_DECL(1, 0) SCHWARZ_DECL(1, 1) SCHWARZ_DECL(2, 0) SCHWARZ_DECL(2, 1) SCHWARZ_DECL(2, 2)
 
-__device__ __forceinline__ size_t pair_index(int i, int j)
-{
-    return i >= j ? (size_t)i * (i + 1) / 2 + j : (size_t)j * (j + 1) / 2 + i;
-}
+#define DIG_DECL(a, b, c, d) \
+    extern template void launch_eri_digest_class<a, b, c, d>(const BatchView&, const int*, int, const double*, const double*, double, double*, double*, int, hipStream_t);
+DIG_DECL(0, 0, 0, 0) DIG_DECL(1, 0, 0, 0) DIG_DECL(1, 0, 1, 0) DIG_DECL(1, 1, 0, 0) DIG_DECL(1, 1, 1, 0) DIG_DECL(1, 1, 1, 1)
+DIG_DECL(2, 0, 0, 0) DIG_DECL(2, 0, 1, 0) DIG_DECL(2, 0, 1, 1) DIG_DECL(2, 0, 2, 0)
+DIG_DECL(2, 1, 0, 0) DIG_DECL(2, 1, 1, 0) DIG_DECL(2, 1, 1, 1) DIG_DECL(2, 1, 2, 0) DIG_DECL(2, 1, 2, 1)
+DIG_DECL(2, 2, 0, 0) DIG_DECL(2, 2, 1, 0) DIG_DECL(2, 2, 1, 1) DIG_DECL(2, 2, 2, 0) DIG_DECL(2, 2, 2, 1) DIG_DECL(2, 2, 2, 2)
 
-// cart -> sph on ONE index of a block: in[pre][NC][post] -> out[pre][NS][post].
-// UNR: fully unrolled (register-resident small classes) or rolled (large classes, scratch).
-template <int L, int PRE, int POST, bool UNR>
-__device__ __forceinline__ void c2s_one_index(const double* c2s, const double* in, double* out)
-{
-    constexpr int NC = ncart(L), NS = nsph(L);
-    if constexpr (L < 2) {
-        if constexpr (UNR) {
-#pragma unroll
-            for (int i = 0; i < PRE * NC * POST; ++i) out[i] = in[i];
-        } else {
-            for (int i = 0; i < PRE * NC * POST; ++i) out[i] = in[i];
-        }
-    } else if constexpr (UNR) {
-#pragma unroll
-        for (int a = 0; a < PRE; ++a)
-#pragma unroll
-            for (int s = 0; s < NS; ++s)
-#pragma unroll
-                for (int r = 0; r < POST; ++r) {
-                    double v = 0.0;
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) v += c2s_coef<L>(c2s, s, c) * in[(a * NC + c) * POST + r];
-                    out[(a * NS + s) * POST + r] = v;
-                }
-    } else {
-#pragma unroll 1
-        for (int a = 0; a < PRE; ++a)
-#pragma unroll 1
-            for (int s = 0; s < NS; ++s)
-#pragma unroll 1
-                for (int r = 0; r < POST; ++r) {
-                    double v = 0.0;
-                    for (int c = 0; c < NC; ++c) v += c2s_coef<L>(c2s, s, c) * in[(a * NC + c) * POST + r];
-                    out[(a * NS + s) * POST + r] = v;
-                }
-    }
-}
-
-// all four indices; `cart` is clobbered (used as the ping-pong buffer)
-template <int LA, int LB, int LC, int LD>
-__device__ __forceinline__ void block_to_spherical(const double* c2s, double* cart, double* sph)
-{
-    constexpr int NCA = ncart(LA), NCB = ncart(LB), NCC = ncart(LC), NCD = ncart(LD);
-    constexpr int NSA = nsph(LA), NSB = nsph(LB), NSC = nsph(LC), NSD = nsph(LD);
-    constexpr bool UNR = (NCA * NCB * NCC * NCD <= ERI_UNROLL_LIMIT);
-    (void)NSD;
-    c2s_one_index<LA, 1, NCB * NCC * NCD, UNR>(c2s, cart, sph);
-    c2s_one_index<LB, NSA, NCC * NCD, UNR>(c2s, sph, cart);
-    c2s_one_index<LC, NSA * NSB, NCD, UNR>(c2s, cart, sph);
-    c2s_one_index<LD, NSA * NSB * NSC, 1, UNR>(c2s, sph, cart);
-    constexpr int NOUT = NSA * NSB * NSC * NSD;
-    if constexpr (UNR) {
-#pragma unroll
-        for (int i = 0; i < NOUT; ++i) sph[i] = cart[i];
-    } else {
-        for (int i = 0; i < NOUT; ++i) sph[i] = cart[i];
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// Schwarz bounds Q[f][A][B] = sqrt(max |(ab|ab)|) over the spherical block.
-template <int LA, int LB>
-__global__ void __launch_bounds__(64) schwarz_kernel(BatchView bv, const int* __restrict__ pairs, int npairs,
-                                                     double* __restrict__ Q)
-{
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= (long)npairs * bv.nfrag) return;
-    const int ip = (int)(tid / bv.nfrag), f = (int)(tid % bv.nfrag);
-    const int A = pairs[2 * ip], B = pairs[2 * ip + 1];
-    const TopologyDev& tp = bv.topo;
-    const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
-    ShellRef a = make_shell(tp, xyz, A), b = make_shell(tp, xyz, B);
-    constexpr int NC = ncart(LA) * ncart(LB);
-    constexpr int NS = nsph(LA) * nsph(LB);
-    double cart[NC * NC], sph[NC * NC];
-    eri_cart_block<LA, LB, LA, LB>(a, b, a, b, bv.boys, cart);
-    block_to_spherical<LA, LB, LA, LB>(bv.c2s, cart, sph);
-    double m = 0.0;
-    for (int i = 0; i < NS * NS; ++i) m = fmax(m, fabs(sph[i]));
-    const int ns = tp.nshell;
-    double* q = Q + (size_t)f * ns * ns;
-    const double v = sqrt(m);
-    q[A * ns + B] = v;
-    q[B * ns + A] = v;
-}
-
-// ---------------------------------------------------------------------------------------
-template <int LA, int LB, int LC, int LD>
-__global__ void __launch_bounds__(64) eri_kernel(BatchView bv, const int* __restrict__ quartets, int nquart,
-                                                 const double* __restrict__ Q, double thresh)
-{
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)nquart * bv.nfrag;
-    const bool live = tid < total;
-    const long t = live ? tid : total - 1;
-    const int iq = (int)(t / bv.nfrag), f = (int)(t % bv.nfrag);
-    const int A = quartets[4 * iq], B = quartets[4 * iq + 1], C = quartets[4 * iq + 2], D = quartets[4 * iq + 3];
-    const TopologyDev& tp = bv.topo;
-    const int ns = tp.nshell;
-    bool keep = live;
-    if (Q != nullptr) {
-        const double* q = Q + (size_t)f * ns * ns;
-        keep = live && (q[A * ns + B] * q[C * ns + D] >= thresh);
-    }
-    // wavefront-level early exit: one ballot decides for all 64 lanes
-    if (__ballot(keep) == 0ull) return;
-    if (!keep) return;   // the tensor was zero-filled, a skipped quartet stays zero
-
-    const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
-    ShellRef a = make_shell(tp, xyz, A), b = make_shell(tp, xyz, B);
-    ShellRef c = make_shell(tp, xyz, C), d = make_shell(tp, xyz, D);
-    constexpr int NC = ncart(LA) * ncart(LB) * ncart(LC) * ncart(LD);
-    constexpr int NSA = nsph(LA), NSB = nsph(LB), NSC = nsph(LC), NSD = nsph(LD);
-    double cart[NC], sph[NC];
-    eri_cart_block<LA, LB, LC, LD>(a, b, c, d, bv.boys, cart);
-    block_to_spherical<LA, LB, LC, LD>(bv.c2s, cart, sph);
-
-    const int oa = tp.sh_aoff[A], ob = tp.sh_aoff[B], oc = tp.sh_aoff[C], od = tp.sh_aoff[D];
-    const size_t np = (size_t)bv.npair;
-    double* M = bv.eri + (size_t)f * np * np;
-#define MQC_ERI_STORE                                                              \
-    {                                                                              \
-        if (!(A == B && j > i)) {                                                  \
-            const size_t row = pair_index(oa + i, ob + j);                         \
-            MQC_INNER_PRAGMA                                                       \
-            for (int k = 0; k < NSC; ++k) {                                        \
-                MQC_INNER_PRAGMA                                                   \
-                for (int l = 0; l < NSD; ++l) {                                    \
-                    if (!(C == D && l > k)) {                                      \
-                        const size_t col = pair_index(oc + k, od + l);             \
-                        const double v = sph[((i * NSB + j) * NSC + k) * NSD + l]; \
-                        M[row * np + col] = v;                                     \
-                        M[col * np + row] = v;                                     \
-                    }                                                              \
-                }                                                                  \
-            }                                                                      \
-        }                                                                          \
-    }
-    if constexpr (NC <= ERI_UNROLL_LIMIT) {
-#define MQC_INNER_PRAGMA _Pragma("unroll")
-#pragma unroll
-        for (int i = 0; i < NSA; ++i) {
-#pragma unroll
-            for (int j = 0; j < NSB; ++j) MQC_ERI_STORE
-        }
-#undef MQC_INNER_PRAGMA
-    } else {
-#define MQC_INNER_PRAGMA _Pragma("unroll 1")
-#pragma unroll 1
-        for (int i = 0; i < NSA; ++i) {
-#pragma unroll 1
-            for (int j = 0; j < NSB; ++j) MQC_ERI_STORE
-        }
-#undef MQC_INNER_PRAGMA
-    }
-#undef MQC_ERI_STORE
-}
-
-// ---------------------------------------------------------------------------------------
-template <int LA, int LB, int LC, int LD>
-static void launch_eri_class(const BatchView& bv, const Topology::ClassList& cl, int* d_list,
-                             const double* Q, double thresh, hipStream_t s)
-{
-    const int nq = (int)cl.quartets.size() / 4;
-    if (nq == 0) return;
-    (void)hipMemcpyAsync(d_list, cl.quartets.data(), cl.quartets.size() * sizeof(int), hipMemcpyHostToDevice, s);
-    const long total = (long)nq * bv.nfrag;
-    const int blocks = (int)((total + 63) / 64);
-    hipLaunchKernelGGL((eri_kernel<LA, LB, LC, LD>), dim3(blocks), dim3(64), 0, s, bv, d_list, nq, Q, thresh);
-}
-
-template <int LA, int LB>
-static void launch_schwarz_class(const BatchView& bv, const std::vector<int>& list, int* d_list, double* Q, hipStream_t s)
-{
-    const int np = (int)list.size() / 2;
-    if (np == 0) return;
-    (void)hipMemcpyAsync(d_list, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice, s);
-    const long total = (long)np * bv.nfrag;
-    hipLaunchKernelGGL((schwarz_kernel<LA, LB>), dim3((int)((total + 63) / 64)), dim3(64), 0, s, bv, d_list, np, Q);
-}
-
-#define ERI_CASE(a, b, c, d)                                                              \
-    if (cl.la == a && cl.lb == b && cl.lc == c && cl.ld == d) {                           \
-        launch_eri_class<a, b, c, d>(bv, cl, d_list + off, Q, thresh, s);                 \
-        handled = true;                                                                   \
-    }
+#define ERI_CASE(a, b, c, d)                                                                          \
+    if (cl.la == a && cl.lb == b && cl.lc == c && cl.ld == d)                                         \
+        launch_eri_class<a, b, c, d>(bv, cl.quartets.data(), (int)cl.quartets.size() / 4, d_list + off, Q, thresh, s);
 
 void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, hipStream_t s)
 {
@@ -250,15 +49,15 @@ void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, h
             auto& bk = bucket[topo.shells[A].l][topo.shells[B].l];
             bk.push_back(A); bk.push_back(B);
         }
-#define SCHWARZ_CASE(a, b)                                                          \
-    launch_schwarz_class<a, b>(bv, bucket[a][b], d_list + off, Q, s);               \
+#define SCHWARZ_CASE(a, b)                                                                                   \
+    launch_schwarz_class<a, b>(bv, bucket[a][b].data(), (int)bucket[a][b].size() / 2, d_list + off, Q, s);   \
     off += bucket[a][b].size();
         SCHWARZ_CASE(0, 0) SCHWARZ_CASE(1, 0) SCHWARZ_CASE(1, 1)
         SCHWARZ_CASE(2, 0) SCHWARZ_CASE(2, 1) SCHWARZ_CASE(2, 2)
 #undef SCHWARZ_CASE
+        (void)hipStreamSynchronize(s);     // the bucket vectors go out of scope
     }
     for (auto& cl : topo.classes) {
-        bool handled = false;
         ERI_CASE(0, 0, 0, 0)
         ERI_CASE(1, 0, 0, 0) ERI_CASE(1, 0, 1, 0)
         ERI_CASE(1, 1, 0, 0) ERI_CASE(1, 1, 1, 0) ERI_CASE(1, 1, 1, 1)
@@ -266,9 +65,98 @@ void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, h
         ERI_CASE(2, 1, 0, 0) ERI_CASE(2, 1, 1, 0) ERI_CASE(2, 1, 1, 1) ERI_CASE(2, 1, 2, 0) ERI_CASE(2, 1, 2, 1)
         ERI_CASE(2, 2, 0, 0) ERI_CASE(2, 2, 1, 0) ERI_CASE(2, 2, 1, 1) ERI_CASE(2, 2, 2, 0) ERI_CASE(2, 2, 2, 1)
         ERI_CASE(2, 2, 2, 2)
-        (void)handled;
         off += cl.quartets.size();
     }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Direct path: Schwarz bounds once per batch, then every iteration: block maxima of D, zero J~/K~,
+// digest kernels per class, symmetrise into J and K.
+__global__ void density_block_max_kernel(BatchView bv, double* __restrict__ Dmax)
+{
+    const int f = blockIdx.y, ns = bv.topo.nshell, n = bv.n;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= ns * ns) return;
+    const int A = idx / ns, B = idx - A * ns;
+    const int oa = bv.topo.sh_aoff[A], ob = bv.topo.sh_aoff[B];
+    const int na = 2 * bv.topo.sh_l[A] + 1, nb = 2 * bv.topo.sh_l[B] + 1;
+    const double* D = bv.D + (size_t)f * n * n;
+    double m = 0.0;
+    for (int i = 0; i < na; ++i)
+        for (int j = 0; j < nb; ++j) m = fmax(m, fabs(D[(oa + i) * n + ob + j]));
+    Dmax[(size_t)f * ns * ns + idx] = m;
+}
+
+__global__ void symmetrise_jk_kernel(BatchView bv, const double* __restrict__ Jt, const double* __restrict__ Kt)
+{
+    const int f = blockIdx.y, n = bv.n;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * n) return;
+    const int i = idx / n, j = idx - i * n;
+    const size_t o = (size_t)f * n * n;
+    bv.J[o + idx] = 0.5 * (Jt[o + idx] + Jt[o + j * n + i]);
+    bv.K[o + idx] = 0.5 * (Kt[o + idx] + Kt[o + j * n + i]);
+}
+
+static DevicePool g_direct_lists, g_direct_q, g_direct_work;
+
+// Uploads the class lists and computes the Schwarz bounds; call once per batch before the SCF loop.
+void launch_direct_setup(const BatchView& bv, const Topology& topo, hipStream_t s)
+{
+    size_t total_ints = topo.pairs.size();
+    for (auto& cl : topo.classes) total_ints += cl.quartets.size();
+    int* d_list = (int*)g_direct_lists.ensure((total_ints + 16) * sizeof(int));
+    const size_t nss = (size_t)bv.nfrag * topo.shells.size() * topo.shells.size();
+    double* Q = (double*)g_direct_q.ensure(sizeof(double) * 2 * nss);
+    size_t off = 0;
+    for (auto& cl : topo.classes) {
+        (void)hipMemcpyAsync(d_list + off, cl.quartets.data(), cl.quartets.size() * sizeof(int), hipMemcpyHostToDevice, s);
+        off += cl.quartets.size();
+    }
+    std::vector<int> bucket[KERNEL_LMAX + 1][KERNEL_LMAX + 1];
+    for (size_t k = 0; k + 1 < topo.pairs.size(); k += 2) {
+        int A = topo.pairs[k], B = topo.pairs[k + 1];
+        if (topo.shells[A].l < topo.shells[B].l) std::swap(A, B);
+        auto& bk = bucket[topo.shells[A].l][topo.shells[B].l];
+        bk.push_back(A); bk.push_back(B);
+    }
+#define SCHWARZ_CASE(a, b)                                                                                   \
+    launch_schwarz_class<a, b>(bv, bucket[a][b].data(), (int)bucket[a][b].size() / 2, d_list + off, Q, s);   \
+    off += bucket[a][b].size();
+    SCHWARZ_CASE(0, 0) SCHWARZ_CASE(1, 0) SCHWARZ_CASE(1, 1)
+    SCHWARZ_CASE(2, 0) SCHWARZ_CASE(2, 1) SCHWARZ_CASE(2, 2)
+#undef SCHWARZ_CASE
+    (void)hipStreamSynchronize(s);
+}
+
+#define DIG_CASE(a, b, c, d)                                                                          \
+    if (cl.la == a && cl.lb == b && cl.lc == c && cl.ld == d)                                         \
+        launch_eri_digest_class<a, b, c, d>(bv, d_list + off, (int)cl.quartets.size() / 4, Q, Dmax, thresh, Jt, Kt, oa, s);
+
+void launch_jk_direct(const BatchView& bv, const Topology& topo, double thresh, bool only_active, hipStream_t s)
+{
+    const int n = bv.n, ns = (int)topo.shells.size(), oa = only_active ? 1 : 0;
+    const size_t nn = (size_t)bv.nfrag * n * n, nss = (size_t)bv.nfrag * ns * ns;
+    const int* d_list = (const int*)g_direct_lists.ensure(0);
+    double* Q = (double*)g_direct_q.ensure(0);
+    double* Dmax = Q + nss;
+    double* Jt = (double*)g_direct_work.ensure(sizeof(double) * 2 * nn);
+    double* Kt = Jt + nn;
+    (void)hipMemsetAsync(Jt, 0, sizeof(double) * 2 * nn, s);
+    hipLaunchKernelGGL(density_block_max_kernel, dim3((ns * ns + 255) / 256, bv.nfrag), dim3(256), 0, s, bv, Dmax);
+    size_t off = 0;
+    for (auto& cl : topo.classes) {
+        DIG_CASE(0, 0, 0, 0)
+        DIG_CASE(1, 0, 0, 0) DIG_CASE(1, 0, 1, 0)
+        DIG_CASE(1, 1, 0, 0) DIG_CASE(1, 1, 1, 0) DIG_CASE(1, 1, 1, 1)
+        DIG_CASE(2, 0, 0, 0) DIG_CASE(2, 0, 1, 0) DIG_CASE(2, 0, 1, 1) DIG_CASE(2, 0, 2, 0)
+        DIG_CASE(2, 1, 0, 0) DIG_CASE(2, 1, 1, 0) DIG_CASE(2, 1, 1, 1) DIG_CASE(2, 1, 2, 0) DIG_CASE(2, 1, 2, 1)
+        DIG_CASE(2, 2, 0, 0) DIG_CASE(2, 2, 1, 0) DIG_CASE(2, 2, 1, 1) DIG_CASE(2, 2, 2, 0) DIG_CASE(2, 2, 2, 1)
+        DIG_CASE(2, 2, 2, 2)
+        off += cl.quartets.size();
+    }
+    hipLaunchKernelGGL(symmetrise_jk_kernel, dim3((n * n + 255) / 256, bv.nfrag), dim3(256), 0, s, bv, Jt, Kt);
 }
 
 }  // namespace mqc

@@ -601,8 +601,10 @@ void launch_xc(const BatchView& bv, bool only_active, hipStream_t s)
         if (gga) xc_launch<true, 32, 10>(bv, oa, s); else xc_launch<false, 32, 10>(bv, oa, s);
     } else if (nv <= 29) {
         if (gga) xc_launch<true, 16, 29>(bv, oa, s); else xc_launch<false, 32, 29>(bv, oa, s);
-    } else {
+    } else if (nv <= 54) {
         if (gga) xc_launch<true, 16, 54>(bv, oa, s); else xc_launch<false, 16, 54>(bv, oa, s);
+    } else {
+        if (gga) xc_launch<true, 16, 77>(bv, oa, s); else xc_launch<false, 16, 77>(bv, oa, s);
     }
 }
 

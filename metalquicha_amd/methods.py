@@ -92,6 +92,7 @@ class ScfSettings:
     angular_points: int = 0
     backend: int = BACKEND_AUTO
     schwarz_tol: float = 0.0
+    eri_mode: str = "auto"          # auto | incore | direct
 
 
 @dataclass
@@ -153,6 +154,7 @@ def _options(settings: ScfSettings, want_gradient: bool) -> capi.ScfOptions:
     o.allow_crap_scf = int(settings.allow_crap_scf)
     o.verbose = int(settings.verbose)
     o.schwarz_tol = settings.schwarz_tol
+    o.eri_mode = {"auto": capi.ERI_AUTO, "incore": capi.ERI_INCORE, "direct": capi.ERI_DIRECT}[settings.eri_mode.lower()]
     return o
 
 

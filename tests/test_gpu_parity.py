@@ -296,3 +296,46 @@ def test_df_without_aux_basis_file_is_an_error():
     st = methods.ScfSettings(basis_set="sto-3g", density_fitting=True, aux_basis_set="def2-universal-jkfit")
     r = methods.run_hip_scf(st, fragment_bohr(*WATER))
     assert r.has_error and "not found" in r.error_message
+
+
+# ---- direct (integral-recomputing) Fock build ---------------------------------------------------
+def test_direct_scf_matches_incore_and_oracle():
+    """The reference's own direct-vs-in-core check (test_mqc_libcint_direct.f90): same energy, same
+    iteration count; screening at 1e-11 changes nothing at the 1e-9 level."""
+    frag = fragment_bohr(*WATER)
+    kw = dict(basis_set="cc-pvdz", energy_tol=1e-10, density_tol=1e-8, guess="gwh")
+    inc = methods.run_hip_scf(methods.ScfSettings(eri_mode="incore", **kw), frag)
+    dire = methods.run_hip_scf(methods.ScfSettings(eri_mode="direct", **kw), frag)
+    assert not dire.has_error, dire.error_message
+    assert abs(dire.energy.scf - inc.energy.scf) < 1e-9
+    assert dire.scf_iterations == inc.scf_iterations
+    assert abs(dire.energy.scf - (-76.0220988827)) < 1e-9
+
+
+def test_direct_scf_batch_with_far_apart_dimer_screens_and_agrees():
+    rng = np.random.default_rng(31)
+    ws = [water_at(rng, c) for c in ([0, 0, 0], [14.0, 0.5, -0.3])]
+    frags = [fragment_bohr([8, 1, 1, 8, 1, 1], np.vstack(ws)), fragment_bohr([8, 1, 1], ws[0])]
+    kw = dict(basis_set="cc-pvdz", energy_tol=1e-9, density_tol=1e-7, guess="gwh")
+    a = methods.run_hip_scf_batch(methods.ScfSettings(eri_mode="incore", **kw), frags)
+    b = methods.run_hip_scf_batch(methods.ScfSettings(eri_mode="direct", **kw), frags)
+    for x, y in zip(a, b):
+        assert not y.has_error, y.error_message
+        assert abs(x.energy.scf - y.energy.scf) < 1e-8
+
+
+def test_auto_mode_goes_direct_for_large_fragments():
+    """Benzene/cc-pVDZ has n_ao = 114 (in-core still fits); a water pentamer (n_ao = 120) does not and must
+    run through the direct path under eri_mode auto; checked against DF within the fitting error."""
+    rng = np.random.default_rng(8)
+    cs = [[0, 0, 0], [5.6, 0.2, 0.1], [0.2, 5.7, -0.3], [5.5, 5.8, 0.2], [2.8, 2.9, 4.9]]
+    xyz = np.vstack([water_at(rng, c) for c in cs])
+    frag = fragment_bohr([8, 1, 1] * 5, xyz)
+    st = methods.ScfSettings(basis_set="cc-pvdz", energy_tol=1e-8, density_tol=1e-6, guess="gwh")
+    r = methods.run_hip_scf(st, frag)
+    assert not r.has_error, r.error_message
+    d = methods.run_hip_scf(methods.ScfSettings(basis_set="cc-pvdz", density_fitting=True, aux_basis_set=AUX,
+                                                energy_tol=1e-8, density_tol=1e-6, guess="gwh"), frag)
+    assert not d.has_error, d.error_message
+    assert abs(r.energy.scf - d.energy.scf) < 5e-4
+    assert r.scf_iterations == d.scf_iterations
