@@ -44,6 +44,7 @@ def parse_args():
     ap.add_argument("--basis", default="cc-pvdz")
     ap.add_argument("--functional", default="", help="empty = RHF (configs[2]); e.g. b3lyp")
     ap.add_argument("--df", action="store_true", help="density-fitted J/K with the repo's even-tempered auxiliary set")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for CPU rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=6, help="dimers in the CPU-baseline sample")
     return ap.parse_args()
@@ -70,6 +71,17 @@ def cpu_baseline(system, terms, basis, n_dimers):
             "seconds": dt, "fragments": len(sample)}
 
 
+def pmc_traffic_bytes_per_launch():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of THIS
+    command (profiles/r01_pmc_traffic.json, written by scripts/pmc_traffic.py); None when absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -77,11 +89,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     torch = None
+    use_cuda_tensors = False
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", init_method="env://", rank=rank, world_size=world)
+        use_cuda_tensors = args.backend == "nccl"
+        if use_cuda_tensors:
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=args.backend, init_method="env://", rank=rank, world_size=world)
 
     from metalquicha_amd import capi, mbe, methods
 
@@ -95,7 +110,8 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            if use_cuda_tensors:
+                torch.cuda.synchronize()
 
     def one_step():
         run = mbe.run_mbe(system, settings, level=2, rank=rank, world=world, terms=terms)
@@ -104,9 +120,12 @@ def main():
         energies, iters = run.energies, run.iterations.astype(np.float64)
         if world > 1:
             # the only inter-GPU traffic: one all-reduce of the zero-padded per-fragment vectors
-            buf = torch.from_numpy(np.concatenate([energies, iters])).cuda()
+            buf = torch.from_numpy(np.concatenate([energies, iters]))
+            if use_cuda_tensors:
+                buf = buf.cuda()
             dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-            torch.cuda.synchronize()
+            if use_cuda_tensors:
+                torch.cuda.synchronize()
             both = buf.cpu().numpy()
             energies, iters = both[: len(terms)], both[len(terms):]
         total, by_order, _ = mbe.compute_mbe(terms, energies)
@@ -126,7 +145,9 @@ def main():
     elapsed = time.perf_counter() - t0
     st = methods.get_stats()
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64).cuda()
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
+        if use_cuda_tensors:
+            tmax = tmax.cuda()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -136,7 +157,7 @@ def main():
         fock_s, eri_s = st.fock_kernel_seconds, st.eri_kernel_seconds
         roof = {"bound": "hbm", "kernel": "jk_incore_kernel", "achieved": (st.fock_bytes / fock_s / 1e9) if fock_s > 0 else None,
                 "peak": 8000.0, "unit": "GB/s", "frac": (st.fock_bytes / fock_s / 1e9 / 8000.0) if fock_s > 0 else None,
-                "traffic": None, "kernel_seconds": fock_s, "launches": int(st.fock_launches),
+                "traffic": pmc_traffic_bytes_per_launch(), "kernel_seconds": fock_s, "launches": int(st.fock_launches),
                 "algorithmic_bytes": st.fock_bytes,
                 "other_kernel_seconds": {"eri_kernels": eri_s, "xc_kernel": st.xc_kernel_seconds}, "xc_points": st.xc_points}
         line = {

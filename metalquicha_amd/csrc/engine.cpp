@@ -526,7 +526,8 @@ int mqc_hip_scf_run_batch(mqc_hip_context* ctx, int64_t nfrag, const mqc_hip_mol
         const auto& idx = kv.second;
         Topology topo;
         std::string err;
-        int rc = build_topology(mols[idx[0]], orbitals[idx[0]], topo, err);
+        const bool need_quartets = !(opts->density_fitting && auxes);
+        int rc = build_topology(mols[idx[0]], orbitals[idx[0]], topo, err, KERNEL_LMAX, need_quartets);
         if (rc != MQC_HIP_OK) {
             for (auto i : idx) { results[i].has_error = 1; std::snprintf(results[i].message, sizeof(results[i].message), "%s", err.c_str()); }
             set_error(err);
@@ -536,7 +537,7 @@ int mqc_hip_scf_run_batch(mqc_hip_context* ctx, int64_t nfrag, const mqc_hip_mol
         Topology auxt;
         const Topology* auxp = nullptr;
         if (opts->density_fitting && auxes) {
-            rc = build_topology(mols[idx[0]], auxes[idx[0]], auxt, err, AUX_LMAX);
+            rc = build_topology(mols[idx[0]], auxes[idx[0]], auxt, err, AUX_LMAX, false);
             if (rc != MQC_HIP_OK) {
                 for (auto i : idx) { results[i].has_error = 1; std::snprintf(results[i].message, sizeof(results[i].message), "auxiliary basis: %s", err.c_str()); }
                 set_error(err);

@@ -150,7 +150,8 @@ void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);
 void build_boys_table(std::vector<double>& table);
 void build_c2s_tables(std::vector<double>& packed, int* offsets);
-int build_topology(const mqc_hip_molecule_t& mol, const mqc_hip_basis_t& bas, Topology& topo, std::string& err, int max_l = KERNEL_LMAX);
+int build_topology(const mqc_hip_molecule_t& mol, const mqc_hip_basis_t& bas, Topology& topo, std::string& err,
+                   int max_l = KERNEL_LMAX, bool with_quartets = true);
 std::string topology_key(const mqc_hip_molecule_t& mol, const mqc_hip_basis_t& bas);
 double nuclear_repulsion(const Topology& topo, const double* xyz);
 

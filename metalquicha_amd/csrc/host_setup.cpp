@@ -142,7 +142,8 @@ std::string topology_key(const mqc_hip_molecule_t& mol, const mqc_hip_basis_t& b
     return os.str();
 }
 
-int build_topology(const mqc_hip_molecule_t& mol, const mqc_hip_basis_t& bas, Topology& topo, std::string& err, int max_l)
+int build_topology(const mqc_hip_molecule_t& mol, const mqc_hip_basis_t& bas, Topology& topo, std::string& err, int max_l,
+                   bool with_quartets)
 {
     if (mol.n_atoms <= 0) { err = "fragment has no atoms"; return MQC_HIP_ERR_VALIDATION; }
     if (bas.n_atoms != mol.n_atoms) { err = "the basis covers a different number of atoms than the geometry has"; return MQC_HIP_ERR_VALIDATION; }
@@ -210,6 +211,7 @@ int build_topology(const mqc_hip_molecule_t& mol, const mqc_hip_basis_t& bas, To
     for (int A = 0; A < ns; ++A)
         for (int B = 0; B <= A; ++B) { topo.pairs.push_back(A); topo.pairs.push_back(B); }
 
+    if (!with_quartets) return MQC_HIP_OK;     // auxiliary bases and density-fitted runs need no quartet lists
     // canonical quartets: pair index ab >= cd; inside a pair the higher l first; bra class >= ket class
     struct P { int a, b, la, lb, pc, np; };
     std::vector<P> pl;
