@@ -70,7 +70,7 @@ static int upload_topology(mqc_hip_context* ctx, const Topology& topo, TopologyD
 static size_t per_fragment_main_doubles(int n, int natoms)
 {
     const size_t nn = (size_t)n * n;
-    return 8 * nn      // S H X F D C J K
+    return 9 * nn      // S H X F D C J K Vprev
            + 6 * nn    // W
            + 2 * DIIS_MAX * nn   // DIIS histories
            + DIIS_MAX * DIIS_MAX + n + 8 + 3 * (size_t)natoms + 8;   // diis_b, eps, scal, xyz, ints (padded)
@@ -93,6 +93,7 @@ static int carve_batch(mqc_hip_context* ctx, const Topology& topo, const Topolog
     bv.D = (double*)take(sizeof(double) * nf * nn); bv.C = (double*)take(sizeof(double) * nf * nn);
     bv.J = (double*)take(sizeof(double) * nf * nn); bv.K = (double*)take(sizeof(double) * nf * nn);
     bv.W = (double*)take(sizeof(double) * nf * 6 * nn);
+    bv.Vprev = (double*)take(sizeof(double) * nf * nn);
     bv.diis_f = (double*)take(sizeof(double) * nf * DIIS_MAX * nn);
     bv.diis_e = (double*)take(sizeof(double) * nf * DIIS_MAX * nn);
     bv.diis_b = (double*)take(sizeof(double) * nf * DIIS_MAX * DIIS_MAX);

@@ -102,6 +102,7 @@ struct BatchView {      // plain pointers handed to kernels
     const double* c2s;            // cart->sph tables, l = 0..LMAX_AO, offsets in c2s_off
     double* xyz;                  // [nfrag][natoms][3]
     double *S, *H, *X, *F, *D, *C, *J, *K, *W;   // [nfrag][n*n]; W = [nfrag][6][n*n] workspace
+    double* Vprev;                // [nfrag][n*n] last eigenvectors in the orthogonal basis (Jacobi warm start)
     double* eps;                  // [nfrag][n]
     double* eri;                  // [nfrag][npair*npair]
     double *diis_f, *diis_e, *diis_b;   // [nfrag][8][n*n], [nfrag][8][n*n], [nfrag][8*8]

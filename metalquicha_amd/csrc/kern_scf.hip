@@ -116,16 +116,20 @@ __device__ inline JacobiLds carve_jacobi(double* lds, int m, bool v_in_lds, doub
 // with a zero row/column).  On exit jl.A's diagonal holds the eigenvalues and V's columns the
 // eigenvectors (V addressed as V[row * ldv + col]).
 template <bool VLDS>
-__device__ void jacobi_eig(JacobiLds& jl, int m, int ldv)
+__device__ void jacobi_eig(JacobiLds& jl, int m, int ldv, const double* __restrict__ v0 = nullptr, int ldv0 = 0)
 {
     const int mp = even_up(m), lda = jl.lda, half = mp / 2;
     const int tid = threadIdx.x;
     double* A = jl.A;
     double* V = jl.V;
-    // V = I
+    // V = I, or the basis the matrix was pre-rotated into (warm start)
     for (int idx = tid; idx < mp * mp; idx += NT) {
         const int r = idx / mp, c = idx - r * mp;
-        if (VLDS || (r < m && c < m)) V[r * ldv + c] = (r == c) ? 1.0 : 0.0;
+        if (VLDS || (r < m && c < m)) {
+            double v = (r == c) ? 1.0 : 0.0;
+            if (v0 != nullptr && r < m && c < m) v = v0[r * ldv0 + c];
+            V[r * ldv + c] = v;
+        }
     }
     double dmax = 0.0;
     for (int i = tid; i < m; i += NT) dmax = fmax(dmax, fabs(A[i * lda + i]));
@@ -263,13 +267,17 @@ __global__ void __launch_bounds__(NT) orthogonalizer_kernel(BatchView bv)
 }
 
 // F (n x n, global) -> eps, C, D.  Uses W[2] (n x m) as scratch and the Jacobi LDS block.
-template <bool VLDS>
+// WARM: the previous iteration's eigenvectors Vp (orthogonal basis, bv.Vprev) pre-rotate F' so
+// that the Jacobi sweeps start from a nearly diagonal matrix; V then starts from Vp, so the final
+// V is the full eigenvector matrix and no extra product is needed.
+template <bool VLDS, bool WARM>
 __device__ void diagonalize_and_density(const BatchView& bv, FragPtrs& p, JacobiLds& jl, int m)
 {
     const int n = bv.n, tid = threadIdx.x;
     const size_t nn = (size_t)n * n;
-    double* T = p.W + 2 * nn;       // F X  (n x m)
+    double* T = p.W + 2 * nn;       // F X  (n x m), then F' Vp (m x m)
     double* Vg = p.W + 3 * nn;      // global eigenvectors when they do not fit in LDS
+    double* Vp = bv.Vprev + (size_t)blockIdx.x * nn;    // m x m, ld n
     const int mp = even_up(m), lda = jl.lda;
     const int ldv = VLDS ? lda : m;
     if (!VLDS) jl.V = Vg;
@@ -284,6 +292,23 @@ __device__ void diagonalize_and_density(const BatchView& bv, FragPtrs& p, Jacobi
         jl.A[i * lda + j] = s;
     }
     __syncthreads();
+    if (WARM) {
+        // T = F' Vp  (m x m, ld n), then F'' = Vp^T T back into LDS
+        for (int idx = tid; idx < m * m; idx += NT) {
+            const int i = idx / m, j = idx - i * m;
+            double s = 0.0;
+            for (int k = 0; k < m; ++k) s += jl.A[i * lda + k] * Vp[k * n + j];
+            T[i * n + j] = s;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < m * m; idx += NT) {
+            const int i = idx / m, j = idx - i * m;
+            double s = 0.0;
+            for (int k = 0; k < m; ++k) s += Vp[k * n + i] * T[k * n + j];
+            jl.A[i * lda + j] = s;
+        }
+        __syncthreads();
+    }
     // symmetrise (F' is symmetric up to rounding; Jacobi assumes exact symmetry)
     for (int idx = tid; idx < m * m; idx += NT) {
         const int i = idx / m, j = idx - i * m;
@@ -293,7 +318,12 @@ __device__ void diagonalize_and_density(const BatchView& bv, FragPtrs& p, Jacobi
         }
     }
     __syncthreads();
-    jacobi_eig<VLDS>(jl, m, ldv);
+    jacobi_eig<VLDS>(jl, m, ldv, WARM ? Vp : nullptr, n);
+    // keep the eigenvectors for the next iteration's warm start
+    for (int idx = tid; idx < m * m; idx += NT) {
+        const int i = idx / m, j = idx - i * m;
+        Vp[i * n + j] = jl.V[i * ldv + j];
+    }
     // sorted eigenvalues + C = X C'
     int* rank = (int*)(p.W + 4 * nn);   // m ints
     for (int i = tid; i < m; i += NT) {
@@ -337,7 +367,7 @@ __global__ void __launch_bounds__(NT) guess_kernel(BatchView bv, int guess_kind)
         p.F[idx] = v;
     }
     __syncthreads();
-    diagonalize_and_density<VLDS>(bv, p, jl, m);
+    diagonalize_and_density<VLDS, false>(bv, p, jl, m);
     if (tid == 0) {
         p.istate[0] = ST_ITER; p.istate[1] = 0; p.istate[3] = 0;
         p.diis_state[0] = 0; p.diis_state[1] = 0;
@@ -493,7 +523,7 @@ __global__ void __launch_bounds__(NT) scf_step_kernel(BatchView bv)
     double* Dold = p.W + nn;    // W1 is free again
     for (int idx = tid; idx < n * n; idx += NT) Dold[idx] = p.D[idx];
     __syncthreads();
-    diagonalize_and_density<VLDS>(bv, p, jl, m);
+    diagonalize_and_density<VLDS, true>(bv, p, jl, m);
 
     double d2 = 0.0;
     for (int idx = tid; idx < n * n; idx += NT) { const double d = p.D[idx] - Dold[idx]; d2 += d * d; }

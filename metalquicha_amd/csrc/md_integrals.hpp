@@ -337,6 +337,11 @@ MQC_HD void eri_cart_block(const ShellRef& A, const ShellRef& B, const ShellRef&
                                             }
                                         }
                                         ++icd;
+#if defined(__HIP_DEVICE_COMPILE__)
+                                        // keep the scheduler from interleaving ket components: the temporaries of
+                                        // one component die before the next starts (register pressure, not order)
+                                        __builtin_amdgcn_sched_barrier(0);
+#endif
                                     }
                                 }
                             }

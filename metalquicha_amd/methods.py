@@ -242,8 +242,26 @@ def run_hip_scf(settings: ScfSettings, fragment: PhysicalFragment, result: Optio
         return result
 
 
+_MOL_DTYPE = np.dtype({"names": ["n_atoms", "atomic_numbers", "xyz", "ghost", "charge", "multiplicity", "nelec"],
+                       "formats": ["<i4", "<u8", "<u8", "<u8", "<i4", "<i4", "<i4"],
+                       "offsets": [0, 8, 16, 24, 32, 36, 40], "itemsize": C.sizeof(capi.Molecule)})
+_BAS_DTYPE = np.dtype({"names": ["spherical", "n_atoms", "nshell_per_atom", "n_shells", "shell_l", "shell_nprim",
+                                 "exponents", "coefficients"],
+                       "formats": ["<i4", "<i4", "<u8", "<i4", "<u8", "<u8", "<u8", "<u8"],
+                       "offsets": [0, 4, 8, 16, 24, 32, 40, 48], "itemsize": C.sizeof(capi.Basis)})
+
+
+def _basis_record(fb: FlatBasis, n_atoms: int):
+    return (1 if fb.spherical else 0, n_atoms, fb.nshell_per_atom.ctypes.data, fb.nshell, fb.shell_l.ctypes.data,
+            fb.shell_nprim.ctypes.data, fb.exps.ctypes.data, fb.coefs.ctypes.data)
+
+
 def run_hip_scf_batch(settings: ScfSettings, fragments: Sequence[PhysicalFragment]) -> List[CalculationResult]:
-    """Many independent fragments in one call (mqc_hip_scf_run_batch)."""
+    """Many independent fragments in one call (mqc_hip_scf_run_batch).
+
+    The C structs are filled as numpy structured arrays with the header's exact layout
+    (tests/test_host_logic.py checks the sizes), so marshalling a few thousand fragments is a
+    handful of vector operations rather than a Python loop over ctypes objects."""
     n = len(fragments)
     results = [CalculationResult() for _ in range(n)]
     if n == 0:
@@ -252,17 +270,44 @@ def run_hip_scf_batch(settings: ScfSettings, fragments: Sequence[PhysicalFragmen
     ctx = capi.get_context(settings.device_rank)
     opts = _options(settings, False)
     df = settings.density_fitting
-    ms = [_Marshalled(f, _flat_basis(settings.basis_set, f), _flat_basis(settings.aux_basis_set, f) if df else None)
-          for f in fragments]
-    mols = (capi.Molecule * n)(*[m.mol for m in ms])
-    bass = (capi.Basis * n)(*[m.bas for m in ms])
-    auxs = (capi.Basis * n)(*[m.aux_bas for m in ms]) if df else None
+    mols = np.zeros(n, dtype=_MOL_DTYPE)
+    bass = np.zeros(n, dtype=_BAS_DTYPE)
+    auxs = np.zeros(n, dtype=_BAS_DTYPE) if df else None
+    keep = []                                   # arrays the structs point into
+    groups = {}
+    for i, f in enumerate(fragments):
+        key = (f.element_numbers.tobytes(), None if f.ghost is None else f.ghost.tobytes())
+        groups.setdefault(key, []).append(i)
+    for key, idx in groups.items():
+        idx = np.asarray(idx)
+        f0 = fragments[idx[0]]
+        na = f0.n_atoms
+        z = np.ascontiguousarray(f0.element_numbers, dtype=np.int32)
+        ghost = None if f0.ghost is None else np.ascontiguousarray(f0.ghost, dtype=np.uint8)
+        xyz = np.ascontiguousarray(np.stack([fragments[i].coordinates.T for i in idx]), dtype=np.float64)   # (m, na, 3)
+        fb = _flat_basis(settings.basis_set, f0)
+        keep += [z, ghost, xyz, fb]
+        mols["n_atoms"][idx] = na
+        mols["atomic_numbers"][idx] = z.ctypes.data
+        mols["xyz"][idx] = xyz.ctypes.data + np.arange(len(idx), dtype=np.uint64) * np.uint64(na * 3 * 8)
+        mols["ghost"][idx] = 0 if ghost is None else ghost.ctypes.data
+        mols["charge"][idx] = [fragments[i].charge for i in idx]
+        mols["multiplicity"][idx] = [fragments[i].multiplicity for i in idx]
+        mols["nelec"][idx] = [fragments[i].nelec for i in idx]
+        bass[idx] = _basis_record(fb, na)
+        if df:
+            ab = _flat_basis(settings.aux_basis_set, f0)
+            keep.append(ab)
+            auxs[idx] = _basis_record(ab, na)
     res = (capi.ScfResult * n)()
-    rc = lib.mqc_hip_scf_run_batch(ctx, n, mols, bass, auxs, C.byref(opts), res)
+    rc = lib.mqc_hip_scf_run_batch(ctx, n, mols.ctypes.data_as(C.POINTER(capi.Molecule)),
+                                   bass.ctypes.data_as(C.POINTER(capi.Basis)),
+                                   auxs.ctypes.data_as(C.POINTER(capi.Basis)) if df else None, C.byref(opts), res)
     if rc != capi.MQC_HIP_OK and not any(r.has_error for r in res):
         capi.check(rc)
     for out, r in zip(results, res):
         _fill(out, r, None)
+    del keep
     return results
 
 

@@ -198,3 +198,13 @@ def test_fortran_iso_c_binding_module_links():
     out = subprocess.run(["bash", os.path.join(ROOT, "fortran", "check_link.sh")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "abi version 1" in out.stdout
+
+
+def test_vectorised_marshalling_layouts_match_ctypes():
+    import ctypes as C
+    assert methods._MOL_DTYPE.itemsize == C.sizeof(capi.Molecule)
+    assert methods._BAS_DTYPE.itemsize == C.sizeof(capi.Basis)
+    for name in methods._MOL_DTYPE.names:
+        assert getattr(capi.Molecule, name).offset == methods._MOL_DTYPE.fields[name][1], name
+    for name in methods._BAS_DTYPE.names:
+        assert getattr(capi.Basis, name).offset == methods._BAS_DTYPE.fields[name][1], name
