@@ -199,6 +199,81 @@ __global__ void __launch_bounds__(64) eri_kernel(BatchView bv, const int* __rest
 }
 
 // ---------------------------------------------------------------------------------------
+// Pass kernel for the classes whose accumulators exceed the register file (md_integrals.hpp,
+// eri_pass): same (quartet, fragment) thread mapping; the accumulators of a wave sit in its own
+// LDS slab acc[entry][lane].
+struct TensorSink {
+    double* M;
+    size_t np;
+    int oa, ob, oc, od;
+    bool ab_same, cd_same;
+    __device__ __forceinline__ void operator()(int i, int j, int k, int l, double v) const
+    {
+        if (ab_same && j > i) return;
+        if (cd_same && l > k) return;
+        const size_t row = pair_index(oa + i, ob + j), col = pair_index(oc + k, od + l);
+        M[row * np + col] = v;
+        M[col * np + row] = v;
+    }
+};
+
+template <int LA, int LB, int LC, int LD>
+__global__ void __launch_bounds__(64) eri_pass_kernel(BatchView bv, const int* __restrict__ quartets, int nquart,
+                                                      const double* __restrict__ Q, double thresh)
+{
+    extern __shared__ double lds[];
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)nquart * bv.nfrag;
+    const bool live = tid < total;
+    const long t = live ? tid : total - 1;
+    const int iq = (int)(t / bv.nfrag), f = (int)(t % bv.nfrag);
+    const int A = quartets[4 * iq], B = quartets[4 * iq + 1], C = quartets[4 * iq + 2], D = quartets[4 * iq + 3];
+    const TopologyDev& tp = bv.topo;
+    const int ns = tp.nshell;
+    bool keep = live;
+    if (Q != nullptr) {
+        const double* q = Q + (size_t)f * ns * ns;
+        keep = live && (q[A * ns + B] * q[C * ns + D] >= thresh);
+    }
+    if (__ballot(keep) == 0ull) return;
+    if (!keep) return;
+    const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
+    ShellRef a = make_shell(tp, xyz, A), b = make_shell(tp, xyz, B);
+    ShellRef c = make_shell(tp, xyz, C), d = make_shell(tp, xyz, D);
+    const size_t np = (size_t)bv.npair;
+    TensorSink sink{bv.eri + (size_t)f * np * np, np, tp.sh_aoff[A], tp.sh_aoff[B], tp.sh_aoff[C], tp.sh_aoff[D], A == B, C == D};
+    constexpr int CH = eri_pass_chunk(LA, LB, LC, LD);
+    eri_passes_from<LA, LB, LC, LD, CH, 0>(a, b, c, d, bv.boys, bv.c2s, lds + threadIdx.x, 64, sink);
+}
+
+struct MaxSink {
+    double m;
+    __device__ __forceinline__ void operator()(int, int, int, int, double v) { m = fmax(m, fabs(v)); }
+};
+
+template <int LA, int LB>
+__global__ void __launch_bounds__(64) schwarz_pass_kernel(BatchView bv, const int* __restrict__ pairs, int npairs,
+                                                          double* __restrict__ Q)
+{
+    extern __shared__ double lds[];
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= (long)npairs * bv.nfrag) return;
+    const int ip = (int)(tid / bv.nfrag), f = (int)(tid % bv.nfrag);
+    const int A = pairs[2 * ip], B = pairs[2 * ip + 1];
+    const TopologyDev& tp = bv.topo;
+    const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
+    ShellRef a = make_shell(tp, xyz, A), b = make_shell(tp, xyz, B);
+    MaxSink sink{0.0};
+    constexpr int CH = eri_pass_chunk(LA, LB, LA, LB);
+    eri_passes_from<LA, LB, LA, LB, CH, 0>(a, b, a, b, bv.boys, bv.c2s, lds + threadIdx.x, 64, sink);
+    const int ns = tp.nshell;
+    double* q = Q + (size_t)f * ns * ns;
+    const double v = sqrt(sink.m);
+    q[A * ns + B] = v;
+    q[B * ns + A] = v;
+}
+
+// ---------------------------------------------------------------------------------------
 // Direct (integral-recomputing) Fock build: the same quartet arithmetic, but the block is digested
 // into J~ and K~ straight away instead of being stored -- build_fock_direct,
 // backends/libcint/mqc_libcint_direct.f90:306-620 (Huang/Sherrill/Chow JCP 152, 024122 Alg. 1).
@@ -336,7 +411,15 @@ void launch_eri_class(const BatchView& bv, const int* quartets_host, int nq, int
     (void)hipMemcpyAsync(d_list, quartets_host, (size_t)nq * 4 * sizeof(int), hipMemcpyHostToDevice, s);
     const long total = (long)nq * bv.nfrag;
     const int blocks = (int)((total + 63) / 64);
-    hipLaunchKernelGGL((eri_kernel<LA, LB, LC, LD>), dim3(blocks), dim3(64), 0, s, bv, d_list, nq, Q, thresh);
+    if constexpr (eri_uses_passes(LA, LB, LC, LD)) {
+        constexpr int CH = eri_pass_chunk(LA, LB, LC, LD);
+        const size_t lds = sizeof(double) * 64 * ncart(LA) * ncart(LB) * CH;
+        auto kern = eri_pass_kernel<LA, LB, LC, LD>;
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, s, bv, d_list, nq, Q, thresh);
+    } else {
+        hipLaunchKernelGGL((eri_kernel<LA, LB, LC, LD>), dim3(blocks), dim3(64), 0, s, bv, d_list, nq, Q, thresh);
+    }
 }
 
 template <int LA, int LB>
@@ -345,7 +428,15 @@ void launch_schwarz_class(const BatchView& bv, const int* pairs_host, int np, in
     if (np == 0) return;
     (void)hipMemcpyAsync(d_list, pairs_host, (size_t)np * 2 * sizeof(int), hipMemcpyHostToDevice, s);
     const long total = (long)np * bv.nfrag;
-    hipLaunchKernelGGL((schwarz_kernel<LA, LB>), dim3((int)((total + 63) / 64)), dim3(64), 0, s, bv, d_list, np, Q);
+    if constexpr (eri_uses_passes(LA, LB, LA, LB)) {
+        constexpr int CH = eri_pass_chunk(LA, LB, LA, LB);
+        const size_t lds = sizeof(double) * 64 * ncart(LA) * ncart(LB) * CH;
+        auto kern = schwarz_pass_kernel<LA, LB>;
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3((int)((total + 63) / 64)), dim3(64), lds, s, bv, d_list, np, Q);
+    } else {
+        hipLaunchKernelGGL((schwarz_kernel<LA, LB>), dim3((int)((total + 63) / 64)), dim3(64), 0, s, bv, d_list, np, Q);
+    }
 }
 
 }  // namespace mqc

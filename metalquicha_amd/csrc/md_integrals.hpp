@@ -18,6 +18,16 @@ namespace mqc {
 
 #define MQC_HD __host__ __device__ __forceinline__
 
+// Makes a register value opaque to the optimiser at this point (no instruction is emitted).  Used on
+// the bra Hermite tables inside the ket primitive loops: without it LLVM's loop-invariant code motion
+// hoists every ex*ey*ez product out of those loops and keeps ~100 extra doubles alive, which is what
+// pushed the d classes into scratch memory.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MQC_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define MQC_OPAQUE(x) ((void)0)
+#endif
+
 constexpr int LMAX_AO = 4;                     // g functions, as the reference's c2s table
 constexpr int BOYS_MAX_ORDER = 4 * LMAX_AO;    // highest Boys order an ERI can ask for
 constexpr int BOYS_TAYLOR = 8;                 // terms k = 0..7 of the Taylor expansion
@@ -78,7 +88,47 @@ MQC_HD void boys(double T, const double* __restrict__ table, double* F)
 
 // ---------------------------------------------------------------------------------------
 // Hermite Coulomb integrals R_{tuv}(alpha, PQ) for t+u+v <= L, packed with hidx().
-// Level-by-level: Rn holds R^(n) for all (tuv) of degree <= L-n.
+// Level recursion R^(n)_{t+1,u,v} = t R^(n+1)_{t-1,u,v} + X R^(n+1)_{t,u,v}: level n holds all (tuv)
+// of degree <= L-n.  Written as a template recursion over n so that EVERY array index is a
+// compile-time constant (a run-time-bounded copy loop here kept the work arrays in scratch memory).
+template <int L, int N>
+struct HermiteLevel {
+    // out: R^(N), degrees 0..L-N
+    MQC_HD static void run(const double* F, double X, double Y, double Z, double* out)
+    {
+        if constexpr (N == L) {
+            out[0] = F[L];
+        } else {
+            double prev[nherm(L - N - 1)];
+            HermiteLevel<L, N + 1>::run(F, X, Y, Z, prev);
+            out[0] = F[N];
+            constexpr int deg = L - N;
+#pragma unroll
+            for (int D = 1; D <= deg; ++D) {
+#pragma unroll
+                for (int t = D; t >= 0; --t) {
+#pragma unroll
+                    for (int u = D - t; u >= 0; --u) {
+                        const int v = D - t - u;
+                        double val;
+                        if (t > 0) {
+                            val = X * prev[hidx(t - 1, u, v)];
+                            if (t > 1) val += (t - 1) * prev[hidx(t - 2, u, v)];
+                        } else if (u > 0) {
+                            val = Y * prev[hidx(t, u - 1, v)];
+                            if (u > 1) val += (u - 1) * prev[hidx(t, u - 2, v)];
+                        } else {
+                            val = Z * prev[hidx(t, u, v - 1)];
+                            if (v > 1) val += (v - 1) * prev[hidx(t, u, v - 2)];
+                        }
+                        out[hidx(t, u, v)] = val;
+                    }
+                }
+            }
+        }
+    }
+};
+
 template <int L>
 MQC_HD void hermite_r(double alpha, double X, double Y, double Z, const double* __restrict__ table, double* R)
 {
@@ -88,44 +138,7 @@ MQC_HD void hermite_r(double alpha, double X, double Y, double Z, const double* 
     double s = 1.0;
 #pragma unroll
     for (int n = 0; n <= L; ++n) { F[n] *= s; s *= -2.0 * alpha; }
-    if constexpr (L == 0) { R[0] = F[0]; return; }
-    // work[n] arrays, built from n = L down to 0.  cur = R^(n+1) (degree <= L-n-1)
-    double cur[nherm(L > 0 ? L - 1 : 0)];
-    double nxt[nherm(L)];
-    cur[0] = F[L];
-#pragma unroll
-    for (int n = L - 1; n >= 0; --n) {
-        const int deg = L - n;          // nxt gets degrees 0..deg
-        nxt[0] = F[n];
-#pragma unroll
-        for (int N = 1; N <= deg; ++N) {
-#pragma unroll
-            for (int t = N; t >= 0; --t) {
-#pragma unroll
-                for (int u = N - t; u >= 0; --u) {
-                    const int v = N - t - u;
-                    double val;
-                    if (t > 0) {
-                        val = X * cur[hidx(t - 1, u, v)];
-                        if (t > 1) val += (t - 1) * cur[hidx(t - 2, u, v)];
-                    } else if (u > 0) {
-                        val = Y * cur[hidx(t, u - 1, v)];
-                        if (u > 1) val += (u - 1) * cur[hidx(t, u - 2, v)];
-                    } else {
-                        val = Z * cur[hidx(t, u, v - 1)];
-                        if (v > 1) val += (v - 1) * cur[hidx(t, u, v - 2)];
-                    }
-                    nxt[hidx(t, u, v)] = val;
-                }
-            }
-        }
-        if (n > 0) {
-#pragma unroll
-            for (int i = 0; i < nherm(deg); ++i) cur[i] = nxt[i];
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < nherm(L); ++i) R[i] = nxt[i];
+    HermiteLevel<L, 0>::run(F, X, Y, Z, R);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -137,6 +150,15 @@ struct E1D {
     double e[(LA + 1) * (LB + 1) * NT];
     MQC_HD double& at(int i, int j, int t) { return e[(i * (LB + 1) + j) * NT + t]; }
     MQC_HD double get(int i, int j, int t) const { return e[(i * (LB + 1) + j) * NT + t]; }
+    MQC_HD void pin()
+    {
+#pragma unroll
+        for (int i = 0; i <= LA; ++i)
+#pragma unroll
+            for (int j = 0; j <= LB; ++j)
+#pragma unroll
+                for (int t = 0; t <= i + j; ++t) MQC_OPAQUE(e[(i * (LB + 1) + j) * NT + t]);
+    }
     MQC_HD void build(double xpa, double xpb, double hp /* 1/(2p) */)
     {
 #pragma unroll
@@ -385,6 +407,184 @@ MQC_HD void eri_cart_block(const ShellRef& A, const ShellRef& B, const ShellRef&
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// Pass-structured ERI block for the classes whose accumulators do not fit the register file.
+//
+//   * the ket index is transformed to real solid harmonics ON THE FLY (the c2s weight is folded
+//     into the ket Hermite coefficient), so only NCA*NCB x (ket spherical components) numbers
+//     are accumulated and no ket-side post-transform exists;
+//   * the ket spherical components are processed in PASSES of at most CH components; within a
+//     pass the accumulators acc[(iab*CH + s)*stride] live wherever the caller put them -- the
+//     gfx950 kernels pass a wave-private LDS slab ([accumulator][lane], stride 64: conflict-free,
+//     one ds_read/ds_write pair per update), the host harness a plain array (stride 1);
+//   * after a pass the bra indices are transformed and every finished value is handed to
+//     `sink(i, j, k, l, value)` (spherical indices inside the shell block).
+// Each pass recomputes the Hermite tables and R_tuv for its primitive quartets: more arithmetic,
+// no scratch memory -- which is what the profile said these classes were waiting on.
+template <int LA, int LB, int LC, int LD, int CH, int PASS, class Sink>
+MQC_HD void eri_pass(const ShellRef& A, const ShellRef& B, const ShellRef& C, const ShellRef& D,
+                     const double* __restrict__ boys_table, const double* __restrict__ c2s,
+                     double* __restrict__ acc, int stride, Sink& sink)
+{
+    constexpr int NCA = ncart(LA), NCB = ncart(LB), NCC = ncart(LC), NCD = ncart(LD);
+    constexpr int NSA = nsph(LA), NSB = nsph(LB), NSC = nsph(LC), NSD = nsph(LD);
+    constexpr int LAB = LA + LB, L = LA + LB + LC + LD;
+    constexpr int NHAB = nherm(LAB);
+    constexpr int S0 = PASS * CH, S1 = (S0 + CH < NSC * NSD) ? S0 + CH : NSC * NSD;
+    constexpr int NS = S1 - S0;
+    (void)NSC;
+#pragma unroll
+    for (int i = 0; i < NCA * NCB * NS; ++i) acc[i * stride] = 0.0;
+
+    const double abx = A.x - B.x, aby = A.y - B.y, abz = A.z - B.z;
+    const double ab2 = abx * abx + aby * aby + abz * abz;
+    const double cdx = C.x - D.x, cdy = C.y - D.y, cdz = C.z - D.z;
+    const double cd2 = cdx * cdx + cdy * cdy + cdz * cdz;
+    constexpr double TWO_PI_25 = 34.986836655249725693;
+
+    for (int ip = 0; ip < A.nprim; ++ip) {
+        const double a = A.exps[ip], ca = A.coefs[ip];
+        for (int jp = 0; jp < B.nprim; ++jp) {
+            const double b = B.exps[jp];
+            const double p = a + b, ip_ = 1.0 / p;
+            const double kab = exp(-a * b * ip_ * ab2) * ca * B.coefs[jp];
+            const double px = (a * A.x + b * B.x) * ip_, py = (a * A.y + b * B.y) * ip_, pz = (a * A.z + b * B.z) * ip_;
+            E1D<LA, LB> ex, ey, ez;
+            ex.build(px - A.x, px - B.x, 0.5 * ip_);
+            ey.build(py - A.y, py - B.y, 0.5 * ip_);
+            ez.build(pz - A.z, pz - B.z, 0.5 * ip_);
+            for (int kp = 0; kp < C.nprim; ++kp) {
+                const double c = C.exps[kp], cc = C.coefs[kp];
+                for (int lp = 0; lp < D.nprim; ++lp) {
+                    const double d = D.exps[lp];
+                    ex.pin(); ey.pin(); ez.pin();
+                    const double q = c + d, iq = 1.0 / q;
+                    const double kcd = exp(-c * d * iq * cd2) * cc * D.coefs[lp];
+                    const double qx = (c * C.x + d * D.x) * iq, qy = (c * C.y + d * D.y) * iq, qz = (c * C.z + d * D.z) * iq;
+                    E1D<LC, LD> fx, fy, fz;
+                    fx.build(qx - C.x, qx - D.x, 0.5 * iq);
+                    fy.build(qy - C.y, qy - D.y, 0.5 * iq);
+                    fz.build(qz - C.z, qz - D.z, 0.5 * iq);
+                    const double alpha = p * q / (p + q);
+                    const double pref = TWO_PI_25 * ip_ * iq / sqrt(p + q) * kab * kcd;
+                    double R[nherm(L)];
+                    hermite_r<L>(alpha, px - qx, py - qy, pz - qz, boys_table, R);
+#pragma unroll
+                    for (int s = S0; s < S1; ++s) {
+                        const int mc = s / NSD, md = s - mc * NSD;
+                        double G[NHAB];
+#pragma unroll
+                        for (int h = 0; h < NHAB; ++h) G[h] = 0.0;
+#pragma unroll
+                        for (int kc = 0; kc < NCC; ++kc) {
+                            const double wc = c2s_coef<LC>(c2s, mc, kc);
+                            if (wc == 0.0) continue;
+                            int cx = 0, cy = 0, cz = 0;
+                            cart_lmn(LC, kc, cx, cy, cz);
+#pragma unroll
+                            for (int kd = 0; kd < NCD; ++kd) {
+                                const double wd = c2s_coef<LD>(c2s, md, kd);
+                                if (wd == 0.0) continue;
+                                int dx = 0, dy = 0, dz = 0;
+                                cart_lmn(LD, kd, dx, dy, dz);
+#pragma unroll
+                                for (int tt = 0; tt <= cx + dx; ++tt)
+#pragma unroll
+                                    for (int uu = 0; uu <= cy + dy; ++uu)
+#pragma unroll
+                                        for (int ww = 0; ww <= cz + dz; ++ww) {
+                                            double f = (wc * wd) * fx.get(cx, dx, tt) * fy.get(cy, dy, uu) * fz.get(cz, dz, ww);
+                                            if ((tt + uu + ww) & 1) f = -f;
+#pragma unroll
+                                            for (int N = 0; N <= LAB; ++N)
+#pragma unroll
+                                                for (int t = N; t >= 0; --t)
+#pragma unroll
+                                                    for (int u = N - t; u >= 0; --u)
+                                                        G[hidx(t, u, N - t - u)] += f * R[hidx(t + tt, u + uu, N - t - u + ww)];
+                                        }
+                            }
+                        }
+                        int iab = 0;
+#pragma unroll
+                        for (int ax = LA; ax >= 0; --ax)
+#pragma unroll
+                            for (int ay = LA - ax; ay >= 0; --ay) {
+                                const int az = LA - ax - ay;
+#pragma unroll
+                                for (int bx = LB; bx >= 0; --bx)
+#pragma unroll
+                                    for (int by = LB - bx; by >= 0; --by) {
+                                        const int bz = LB - bx - by;
+                                        double sm = 0.0;
+#pragma unroll
+                                        for (int t = 0; t <= ax + bx; ++t)
+#pragma unroll
+                                            for (int u = 0; u <= ay + by; ++u)
+#pragma unroll
+                                                for (int v = 0; v <= az + bz; ++v)
+                                                    sm += ex.get(ax, bx, t) * ey.get(ay, by, u) * ez.get(az, bz, v) * G[hidx(t, u, v)];
+                                        acc[(iab * NS + (s - S0)) * stride] += pref * sm;
+                                        ++iab;
+                                    }
+                            }
+                    }
+                }
+            }
+        }
+    }
+    // bra indices to solid harmonics, hand every finished value to the sink
+#pragma unroll
+    for (int s = S0; s < S1; ++s) {
+        const int mc = s / NSD, md = s - mc * NSD;
+#pragma unroll
+        for (int i = 0; i < NSA; ++i)
+#pragma unroll
+            for (int j = 0; j < NSB; ++j) {
+                double v = 0.0;
+#pragma unroll
+                for (int ia = 0; ia < NCA; ++ia) {
+                    const double wa = c2s_coef<LA>(c2s, i, ia);
+                    if (wa == 0.0) continue;
+#pragma unroll
+                    for (int ib = 0; ib < NCB; ++ib) {
+                        const double wb = c2s_coef<LB>(c2s, j, ib);
+                        if (wb == 0.0) continue;
+                        v += (wa * wb) * acc[((ia * NCB + ib) * NS + (s - S0)) * stride];
+                    }
+                }
+                sink(i, j, mc, md, v);
+            }
+    }
+}
+
+template <int LA, int LB, int LC, int LD, int CH, int PASS, class Sink>
+MQC_HD void eri_passes_from(const ShellRef& A, const ShellRef& B, const ShellRef& C, const ShellRef& D,
+                            const double* __restrict__ boys_table, const double* __restrict__ c2s,
+                            double* __restrict__ acc, int stride, Sink& sink)
+{
+    constexpr int NPASS = (nsph(LC) * nsph(LD) + CH - 1) / CH;
+    eri_pass<LA, LB, LC, LD, CH, PASS>(A, B, C, D, boys_table, c2s, acc, stride, sink);
+    if constexpr (PASS + 1 < NPASS) eri_passes_from<LA, LB, LC, LD, CH, PASS + 1>(A, B, C, D, boys_table, c2s, acc, stride, sink);
+}
+
+// ket components per pass: as many as keep the accumulator slab at or under 64 entries per lane
+MQC_HD constexpr int eri_pass_chunk(int la, int lb, int lc, int ld)
+{
+    const int nab = ncart(la) * ncart(lb), ncd = nsph(lc) * nsph(ld);
+    int ch = 64 / nab;
+    if (ch < 1) ch = 1;
+    if (nab == 36 && ncd > 1) ch = 2;      // (dd| bra: two components per pass (72 accumulators)
+    if (ch > ncd) ch = ncd;
+    return ch;
+}
+
+// classes that go through the pass kernel (everything that spilled in the one-shot register kernel)
+MQC_HD constexpr bool eri_uses_passes(int la, int lb, int lc, int ld)
+{
+    return ncart(la) * ncart(lb) * ncart(lc) * ncart(ld) > 30 && (la + lb + lc + ld) >= 4;
 }
 
 }  // namespace mqc

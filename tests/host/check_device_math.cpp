@@ -48,6 +48,20 @@ static void run_class(const ShellRef* sh, double* out_sph)
     std::memcpy(out_sph, cart.data(), sizeof(double) * dims[0] * dims[1] * dims[2] * dims[3]);
 }
 
+struct HostSink {
+    double* out; int nsb, nsc, nsd;
+    void operator()(int i, int j, int k, int l, double v) { out[((i * nsb + j) * nsc + k) * nsd + l] = v; }
+};
+
+template <int LA, int LB, int LC, int LD>
+static void run_class_passes(const ShellRef* sh, double* out_sph)
+{
+    constexpr int CH = eri_pass_chunk(LA, LB, LC, LD);
+    std::vector<double> acc(ncart(LA) * ncart(LB) * CH);
+    HostSink sink{out_sph, nsph(LB), nsph(LC), nsph(LD)};
+    eri_passes_from<LA, LB, LC, LD, CH, 0>(sh[0], sh[1], sh[2], sh[3], g_boys.data(), g_c2s.data(), acc.data(), 1, sink);
+}
+
 extern "C" {
 
 // shells: for each of the 4 shells: nprim, then pointers are passed flat.
@@ -71,6 +85,26 @@ int hostcheck_eri_block(const int* l, const int* nprim, const double* exps, cons
         CASE(2, 0, 0, 0) CASE(2, 0, 1, 0) CASE(2, 0, 1, 1) CASE(2, 0, 2, 0)
         CASE(2, 1, 0, 0) CASE(2, 1, 1, 0) CASE(2, 1, 1, 1) CASE(2, 1, 2, 0) CASE(2, 1, 2, 1)
         CASE(2, 2, 0, 0) CASE(2, 2, 1, 0) CASE(2, 2, 1, 1) CASE(2, 2, 2, 0) CASE(2, 2, 2, 1) CASE(2, 2, 2, 2)
+    }
+    return 1;
+}
+
+int hostcheck_eri_block_passes(const int* l, const int* nprim, const double* exps, const double* coefs, const double* xyz, double* out_sph)
+{
+    ensure_tables();
+    ShellRef sh[4];
+    int off = 0;
+    for (int k = 0; k < 4; ++k) {
+        sh[k].nprim = nprim[k]; sh[k].exps = exps + off; sh[k].coefs = coefs + off;
+        sh[k].x = xyz[3 * k]; sh[k].y = xyz[3 * k + 1]; sh[k].z = xyz[3 * k + 2];
+        off += nprim[k];
+    }
+    const int id = ((l[0] * 8 + l[1]) * 8 + l[2]) * 8 + l[3];
+#define PCASE(a, b, c, d) case (((a * 8 + b) * 8 + c) * 8 + d): run_class_passes<a, b, c, d>(sh, out_sph); return 0;
+    switch (id) {
+        PCASE(0, 0, 0, 0) PCASE(1, 0, 1, 0) PCASE(1, 1, 1, 1)
+        PCASE(2, 0, 1, 1) PCASE(2, 0, 2, 0) PCASE(2, 1, 1, 0) PCASE(2, 1, 1, 1) PCASE(2, 1, 2, 0) PCASE(2, 1, 2, 1)
+        PCASE(2, 2, 0, 0) PCASE(2, 2, 1, 0) PCASE(2, 2, 1, 1) PCASE(2, 2, 2, 0) PCASE(2, 2, 2, 1) PCASE(2, 2, 2, 2)
     }
     return 1;
 }
