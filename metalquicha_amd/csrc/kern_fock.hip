@@ -229,7 +229,13 @@ void launch_jk_incore(const BatchView& bv, bool only_active, hipStream_t s)
     const size_t lds4k = sizeof(double) * ((size_t)5 * np + 2 * (size_t)n * n);   // 4 waves, D and K in LDS
     const size_t lds4 = sizeof(double) * ((size_t)5 * np);                        // 4 waves, D and K global
     const size_t lds2 = sizeof(double) * ((size_t)3 * np);                        // 2 waves, D and K global
-    if (n <= 64 && lds_reg <= LDS_MAX) {
+    const size_t lds_reg12 = sizeof(double) * ((size_t)13 * np + (size_t)n * n);   // 12 waves share D' and the K accumulator
+    if (n <= 64 && np <= 19 * 64 && np > 5 * 64 && lds_reg12 <= LDS_MAX && bv.nfrag >= 64) {
+        // dimer-sized fragments in a large batch: one 12-wave workgroup per CU (141 KB of LDS for n = 48)
+        // keeps 12 x 9.4 KB of row loads in flight per CU instead of 8 x
+        if (np <= 10 * 64) jk_launch<1, true, 12, 10, true>(bv, oa, lds_reg12, s);
+        else jk_launch<1, true, 12, 19, true>(bv, oa, lds_reg12, s);
+    } else if (n <= 64 && lds_reg <= LDS_MAX) {
         // the fragment sizes of an MBE run (n = 48: 65.5 KB -> two workgroups per CU)
         if (np <= 5 * 64) jk_launch<1, true, 4, 5, true>(bv, oa, lds_reg, s);
         else if (np <= 10 * 64) jk_launch<1, true, 4, 10, true>(bv, oa, lds_reg, s);
