@@ -62,7 +62,7 @@ __device__ __forceinline__ void row_exchange(const double* __restrict__ rowbuf, 
         di_reg = Di[ll]; dj_reg = Dj[ll];
     }
     int lbase = 0;
-#pragma unroll 4
+#pragma unroll 12
     for (int l = 0; l < n; ++l) {
         const double dil = DREG ? readlane_f64(di_reg, l) : Di[l];
         const double djl = DREG ? readlane_f64(dj_reg, l) : Dj[l];
