@@ -46,7 +46,8 @@ def parse_args():
     ap.add_argument("--df", action="store_true", help="density-fitted J/K with the repo's even-tempered auxiliary set")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for CPU rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=6, help="dimers in the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=20, help="dimers in the CPU-baseline sample")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the extra B3LYP and DF measurements")
     return ap.parse_args()
 
 
@@ -151,6 +152,39 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # Secondary measurements (never part of `value`): the north star's B3LYP target and the density-fitted
+    # path on the same cluster, one warm-up + one timed evaluation each.
+    secondary = None
+    if not args.no_secondary and not args.functional and not args.df:
+        secondary = {}
+        for label, kw in (("b3lyp_exact_eri", dict(functional="b3lyp")),
+                          ("rhf_density_fitted", dict(density_fitting=True)),
+                          ("b3lyp_density_fitted", dict(functional="b3lyp", density_fitting=True))):
+            s2 = methods.ScfSettings(basis_set=args.basis, guess="gwh", energy_tol=1e-8, density_tol=1e-6,
+                                     device_rank=local_rank, aux_basis_set="mqc-even-tempered-jkfit", **kw)
+            mbe.run_mbe(system, s2, level=2, rank=rank, world=world, terms=terms)
+            methods.get_stats()
+            barrier()
+            t1 = time.perf_counter()
+            run2 = mbe.run_mbe(system, s2, level=2, rank=rank, world=world, terms=terms)
+            barrier()
+            dt = time.perf_counter() - t1
+            st2 = methods.get_stats()
+            its = float(np.sum(run2.iterations))
+            if world > 1:
+                b2 = torch.tensor([its, 0.0], dtype=torch.float64)
+                t2 = torch.tensor([dt], dtype=torch.float64)
+                if use_cuda_tensors:
+                    b2, t2 = b2.cuda(), t2.cuda()
+                dist.all_reduce(b2, op=dist.ReduceOp.SUM)
+                dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+                its, dt = float(b2[0].item()), float(t2.item())
+            secondary[label] = {"mbe2_wall_s": dt, "scf_iterations_per_s": its / dt, "scf_iterations": its,
+                                "xc_kernel_seconds": st2.xc_kernel_seconds, "xc_points": st2.xc_points,
+                                "xc_algorithmic_tflops": (8.0 * st2.xc_points * 48 * 48 / st2.xc_kernel_seconds / 1e12)
+                                if st2.xc_kernel_seconds > 0 else None,
+                                "two_electron_setup_seconds": st2.t_eri, "scf_loop_seconds": st2.t_fock}
+
     if rank == 0:
         n_steps = max(args.steps, 1)
         # dominant kernel by HIP-event time inside the timed region (rank 0's share)
@@ -186,6 +220,7 @@ def main():
                                "scf_loop": st.t_fock, "fetch": st.t_scf_step, "total": st.t_total},
             "roofline": roof,
         }
+        line["secondary"] = secondary
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(system, terms, args.basis, args.cpu_sample)
         else:

@@ -145,11 +145,22 @@ static void fill_error(mqc_hip_scf_result_t* r, const std::string& msg)
     std::snprintf(r->message, sizeof(r->message), "%s", msg.c_str());
 }
 
-int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, const std::vector<const double*>& xyz,
-              const mqc_hip_scf_options_t& opts, std::vector<mqc_hip_scf_result_t*>& results)
+int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, const std::vector<const double*>& xyz_in,
+              const mqc_hip_scf_options_t& opts, std::vector<mqc_hip_scf_result_t*>& results_in)
 {
     const double t_begin = now_s();
-    const int ntot = (int)xyz.size();
+    const int ntot = (int)xyz_in.size();
+    // Order the batch by compactness (nuclear repulsion, most compact first).  Lanes of a wave are
+    // consecutive fragments: with similar geometries side by side, the primitive-pair screening and
+    // the Schwarz ballot drop the same work in every lane, so whole waves skip it.
+    std::vector<const double*> xyz(ntot);
+    std::vector<mqc_hip_scf_result_t*> results(ntot);
+    {
+        std::vector<std::pair<double, int>> key(ntot);
+        for (int i = 0; i < ntot; ++i) key[i] = {-nuclear_repulsion(topo, xyz_in[i]), i};
+        std::stable_sort(key.begin(), key.end());
+        for (int k = 0; k < ntot; ++k) { xyz[k] = xyz_in[key[k].second]; results[k] = results_in[key[k].second]; }
+    }
     std::string msg;
     int rc = validate_options(opts, topo, msg);
     if (rc != MQC_HIP_OK) {

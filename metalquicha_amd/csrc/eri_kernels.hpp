@@ -149,12 +149,11 @@ __global__ void __launch_bounds__(64) eri_kernel(BatchView bv, const int* __rest
     if (!keep) return;   // the tensor was zero-filled, a skipped quartet stays zero
 
     const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
-    ShellRef a = make_shell(tp, xyz, A), b = make_shell(tp, xyz, B);
-    ShellRef c = make_shell(tp, xyz, C), d = make_shell(tp, xyz, D);
+    const PairFly bra(make_shell(tp, xyz, A), make_shell(tp, xyz, B)), ket(make_shell(tp, xyz, C), make_shell(tp, xyz, D));
     constexpr int NC = ncart(LA) * ncart(LB) * ncart(LC) * ncart(LD);
     constexpr int NSA = nsph(LA), NSB = nsph(LB), NSC = nsph(LC), NSD = nsph(LD);
     double cart[NC], sph[NC];
-    eri_cart_block<LA, LB, LC, LD>(a, b, c, d, bv.boys, cart);
+    eri_cart_block_src<LA, LB, LC, LD>(bra, ket, bv.boys, cart);
     block_to_spherical<LA, LB, LC, LD>(bv.c2s, cart, sph);
 
     const int oa = tp.sh_aoff[A], ob = tp.sh_aoff[B], oc = tp.sh_aoff[C], od = tp.sh_aoff[D];
@@ -238,12 +237,11 @@ __global__ void __launch_bounds__(64) eri_pass_kernel(BatchView bv, const int* _
     if (__ballot(keep) == 0ull) return;
     if (!keep) return;
     const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
-    ShellRef a = make_shell(tp, xyz, A), b = make_shell(tp, xyz, B);
-    ShellRef c = make_shell(tp, xyz, C), d = make_shell(tp, xyz, D);
+    const PairFly bra(make_shell(tp, xyz, A), make_shell(tp, xyz, B)), ket(make_shell(tp, xyz, C), make_shell(tp, xyz, D));
     const size_t np = (size_t)bv.npair;
     TensorSink sink{bv.eri + (size_t)f * np * np, np, tp.sh_aoff[A], tp.sh_aoff[B], tp.sh_aoff[C], tp.sh_aoff[D], A == B, C == D};
     constexpr int CH = eri_pass_chunk(LA, LB, LC, LD);
-    eri_passes_from<LA, LB, LC, LD, CH, 0>(a, b, c, d, bv.boys, bv.c2s, lds + threadIdx.x, 64, sink);
+    eri_passes_src<LA, LB, LC, LD, CH, 0>(bra, ket, bv.boys, bv.c2s, lds + threadIdx.x, 64, sink);
 }
 
 struct MaxSink {
@@ -316,12 +314,11 @@ __global__ void __launch_bounds__(64) eri_digest_kernel(BatchView bv, const int*
     if (!keep) return;
 
     const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
-    ShellRef a = make_shell(tp, xyz, A), b = make_shell(tp, xyz, B);
-    ShellRef c = make_shell(tp, xyz, C), d = make_shell(tp, xyz, D);
+    const PairFly bra(make_shell(tp, xyz, A), make_shell(tp, xyz, B)), ket(make_shell(tp, xyz, C), make_shell(tp, xyz, D));
     constexpr int NC = ncart(LA) * ncart(LB) * ncart(LC) * ncart(LD);
     constexpr int NSA = nsph(LA), NSB = nsph(LB), NSC = nsph(LC), NSD = nsph(LD);
     double cart[NC], sph[NC];
-    eri_cart_block<LA, LB, LC, LD>(a, b, c, d, bv.boys, cart);
+    eri_cart_block_src<LA, LB, LC, LD>(bra, ket, bv.boys, cart);
     block_to_spherical<LA, LB, LC, LD>(bv.c2s, cart, sph);
 
     const int n = bv.n;
@@ -428,7 +425,7 @@ void launch_schwarz_class(const BatchView& bv, const int* pairs_host, int np, in
     if (np == 0) return;
     (void)hipMemcpyAsync(d_list, pairs_host, (size_t)np * 2 * sizeof(int), hipMemcpyHostToDevice, s);
     const long total = (long)np * bv.nfrag;
-    if constexpr (eri_uses_passes(LA, LB, LA, LB)) {
+    if constexpr (schwarz_uses_passes(LA, LB)) {
         constexpr int CH = eri_pass_chunk(LA, LB, LA, LB);
         const size_t lds = sizeof(double) * 64 * ncart(LA) * ncart(LB) * CH;
         auto kern = schwarz_pass_kernel<LA, LB>;

@@ -24,7 +24,9 @@ ERI_INST(2, 2, 1, 1)
 #elif ERI_GROUP == 5
 ERI_INST(2, 2, 2, 0)
 #elif ERI_GROUP == 6
-ERI_INST(2, 2, 2, 1) ERI_INST(2, 2, 2, 2)
+ERI_INST(2, 2, 2, 1)
+#elif ERI_GROUP == 15
+ERI_INST(2, 2, 2, 2)
 #elif ERI_GROUP == 7
 SCHWARZ_INST(0, 0) SCHWARZ_INST(1, 0) SCHWARZ_INST(1, 1) SCHWARZ_INST(2, 0) SCHWARZ_INST(2, 1) SCHWARZ_INST(2, 2)
 #elif ERI_GROUP == 8

@@ -224,6 +224,49 @@ struct ShellRef {
     double x, y, z;
 };
 
+// One primitive pair of a shell pair: exponent sum p, product centre P, K' = exp(-ab/p |AB|^2) ca cb / p
+// and 1/(2p).  The ERI routines take their bra and ket primitive pairs from a SOURCE; PairFly builds
+// them from two shells on the fly and screens pairs whose Gaussian product factor underflows 1e-20.
+// (A table of precomputed pairs in HBM was measured and was no faster: the quartet loops are bound by
+// FP64 issue, not by the exp(), and the table loads cost as much as they saved.)
+struct PrimPair {
+    double p, px, py, pz, kp, hp;
+};
+constexpr int PAIR_REC = 6;
+constexpr double PRIM_EXP_CUTOFF = 46.0;
+
+struct PairFly {
+    ShellRef A, B;
+    double ab2;
+    MQC_HD PairFly(const ShellRef& a, const ShellRef& b) : A(a), B(b)
+    {
+        const double dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+        ab2 = dx * dx + dy * dy + dz * dz;
+    }
+    MQC_HD int npa() const { return A.nprim; }
+    MQC_HD int npb() const { return B.nprim; }
+    MQC_HD double ax() const { return A.x; }
+    MQC_HD double ay() const { return A.y; }
+    MQC_HD double az() const { return A.z; }
+    MQC_HD double bx() const { return B.x; }
+    MQC_HD double by() const { return B.y; }
+    MQC_HD double bz() const { return B.z; }
+    MQC_HD int npairs() const { return A.nprim * B.nprim; }
+    MQC_HD PrimPair get_flat(int k) const { const int ip = k / B.nprim; return get(ip, k - ip * B.nprim); }
+    MQC_HD PrimPair get(int ip, int jp) const
+    {
+        const double a = A.exps[ip], b = B.exps[jp];
+        const double p = a + b, ip_ = 1.0 / p;
+        PrimPair r;
+        r.p = p; r.hp = 0.5 * ip_;
+        r.px = (a * A.x + b * B.x) * ip_; r.py = (a * A.y + b * B.y) * ip_; r.pz = (a * A.z + b * B.z) * ip_;
+        // primitive screening: exp(-46) = 1e-20 -- a pair this far apart contributes nothing representable
+        const double arg = a * b * ip_ * ab2;
+        r.kp = (arg < PRIM_EXP_CUTOFF) ? exp(-arg) * A.coefs[ip] * B.coefs[jp] * ip_ : 0.0;
+        return r;
+    }
+};
+
 // decode Cartesian component k of shell l -> (lx, ly, lz), libcint order
 MQC_HD void cart_lmn(int l, int k, int& lx, int& ly, int& lz)
 {
@@ -241,9 +284,8 @@ constexpr int ERI_UNROLL_LIMIT = 324;
 // ---------------------------------------------------------------------------------------
 // Contracted Cartesian ERI block (ab|cd), out[((ia*NCB+ib)*NCC+ic)*NCD+id] (accumulated
 // into a zeroed buffer by this routine).
-template <int LA, int LB, int LC, int LD>
-MQC_HD void eri_cart_block(const ShellRef& A, const ShellRef& B, const ShellRef& C, const ShellRef& D,
-                           const double* __restrict__ boys_table, double* out)
+template <int LA, int LB, int LC, int LD, class Bra, class Ket>
+MQC_HD void eri_cart_block_src(const Bra& bra, const Ket& ket, const double* __restrict__ boys_table, double* out)
 {
     constexpr int NCA = ncart(LA), NCB = ncart(LB), NCC = ncart(LC), NCD = ncart(LD);
     constexpr int LAB = LA + LB, LCD = LC + LD, L = LAB + LCD;
@@ -257,36 +299,34 @@ MQC_HD void eri_cart_block(const ShellRef& A, const ShellRef& B, const ShellRef&
         for (int i = 0; i < NCA * NCB * NCC * NCD; ++i) out[i] = 0.0;
     }
 
-    const double abx = A.x - B.x, aby = A.y - B.y, abz = A.z - B.z;
-    const double ab2 = abx * abx + aby * aby + abz * abz;
-    const double cdx = C.x - D.x, cdy = C.y - D.y, cdz = C.z - D.z;
-    const double cd2 = cdx * cdx + cdy * cdy + cdz * cdz;
     constexpr double TWO_PI_25 = 34.986836655249725693;   // 2 pi^(5/2)
 
-    for (int ip = 0; ip < A.nprim; ++ip) {
-        const double a = A.exps[ip], ca = A.coefs[ip];
-        for (int jp = 0; jp < B.nprim; ++jp) {
-            const double b = B.exps[jp];
-            const double p = a + b, ip_ = 1.0 / p;
-            const double kab = exp(-a * b * ip_ * ab2) * ca * B.coefs[jp];
-            const double px = (a * A.x + b * B.x) * ip_, py = (a * A.y + b * B.y) * ip_, pz = (a * A.z + b * B.z) * ip_;
+    for (int ip = 0; ip < bra.npa(); ++ip) {
+        for (int jp = 0; jp < bra.npb(); ++jp) {
+            const PrimPair P = bra.get(ip, jp);
+            if (P.kp == 0.0) continue;          // screened primitive pair (wave-uniform for rigid monomers)
+            const double p = P.p, px = P.px, py = P.py, pz = P.pz;
             E1D<LA, LB> ex, ey, ez;
-            ex.build(px - A.x, px - B.x, 0.5 * ip_);
-            ey.build(py - A.y, py - B.y, 0.5 * ip_);
-            ez.build(pz - A.z, pz - B.z, 0.5 * ip_);
-            for (int kp = 0; kp < C.nprim; ++kp) {
-                const double c = C.exps[kp], cc = C.coefs[kp];
-                for (int lp = 0; lp < D.nprim; ++lp) {
-                    const double d = D.exps[lp];
-                    const double q = c + d, iq = 1.0 / q;
-                    const double kcd = exp(-c * d * iq * cd2) * cc * D.coefs[lp];
-                    const double qx = (c * C.x + d * D.x) * iq, qy = (c * C.y + d * D.y) * iq, qz = (c * C.z + d * D.z) * iq;
+            ex.build(px - bra.ax(), px - bra.bx(), P.hp);
+            ey.build(py - bra.ay(), py - bra.by(), P.hp);
+            ez.build(pz - bra.az(), pz - bra.bz(), P.hp);
+            // ket primitive pairs as ONE loop with the next record fetched ahead of the arithmetic
+            // (table source: the loads of record k+1 are in flight while record k is consumed)
+            const int nkl = ket.npairs();
+            PrimPair Qn = ket.get_flat(0);
+            for (int kl = 0; kl < nkl; ++kl) {
+                {
+                    const PrimPair Qp = Qn;
+                    if (kl + 1 < nkl) Qn = ket.get_flat(kl + 1);
+                    if (Qp.kp == 0.0) continue;
+                    const double q = Qp.p, qx = Qp.px, qy = Qp.py, qz = Qp.pz;
                     E1D<LC, LD> fx, fy, fz;
-                    fx.build(qx - C.x, qx - D.x, 0.5 * iq);
-                    fy.build(qy - C.y, qy - D.y, 0.5 * iq);
-                    fz.build(qz - C.z, qz - D.z, 0.5 * iq);
-                    const double alpha = p * q / (p + q);
-                    const double pref = TWO_PI_25 * ip_ * iq / sqrt(p + q) * kab * kcd;
+                    fx.build(qx - ket.ax(), qx - ket.bx(), Qp.hp);
+                    fy.build(qy - ket.ay(), qy - ket.by(), Qp.hp);
+                    fz.build(qz - ket.az(), qz - ket.bz(), Qp.hp);
+                    const double rpq = 1.0 / (p + q);
+                    const double alpha = p * q * rpq;
+                    const double pref = TWO_PI_25 * sqrt(rpq) * P.kp * Qp.kp;
                     double R[nherm(L)];
                     hermite_r<L>(alpha, px - qx, py - qy, pz - qz, boys_table, R);
 
@@ -409,6 +449,14 @@ MQC_HD void eri_cart_block(const ShellRef& A, const ShellRef& B, const ShellRef&
     }
 }
 
+template <int LA, int LB, int LC, int LD>
+MQC_HD void eri_cart_block(const ShellRef& A, const ShellRef& B, const ShellRef& C, const ShellRef& D,
+                           const double* __restrict__ boys_table, double* out)
+{
+    const PairFly bra(A, B), ket(C, D);
+    eri_cart_block_src<LA, LB, LC, LD>(bra, ket, boys_table, out);
+}
+
 // ---------------------------------------------------------------------------------------
 // Pass-structured ERI block for the classes whose accumulators do not fit the register file.
 //
@@ -423,8 +471,8 @@ MQC_HD void eri_cart_block(const ShellRef& A, const ShellRef& B, const ShellRef&
 //     `sink(i, j, k, l, value)` (spherical indices inside the shell block).
 // Each pass recomputes the Hermite tables and R_tuv for its primitive quartets: more arithmetic,
 // no scratch memory -- which is what the profile said these classes were waiting on.
-template <int LA, int LB, int LC, int LD, int CH, int PASS, class Sink>
-MQC_HD void eri_pass(const ShellRef& A, const ShellRef& B, const ShellRef& C, const ShellRef& D,
+template <int LA, int LB, int LC, int LD, int CH, int PASS, class Bra, class Ket, class Sink>
+MQC_HD void eri_pass(const Bra& bra, const Ket& ket,
                      const double* __restrict__ boys_table, const double* __restrict__ c2s,
                      double* __restrict__ acc, int stride, Sink& sink)
 {
@@ -438,37 +486,33 @@ MQC_HD void eri_pass(const ShellRef& A, const ShellRef& B, const ShellRef& C, co
 #pragma unroll
     for (int i = 0; i < NCA * NCB * NS; ++i) acc[i * stride] = 0.0;
 
-    const double abx = A.x - B.x, aby = A.y - B.y, abz = A.z - B.z;
-    const double ab2 = abx * abx + aby * aby + abz * abz;
-    const double cdx = C.x - D.x, cdy = C.y - D.y, cdz = C.z - D.z;
-    const double cd2 = cdx * cdx + cdy * cdy + cdz * cdz;
     constexpr double TWO_PI_25 = 34.986836655249725693;
 
-    for (int ip = 0; ip < A.nprim; ++ip) {
-        const double a = A.exps[ip], ca = A.coefs[ip];
-        for (int jp = 0; jp < B.nprim; ++jp) {
-            const double b = B.exps[jp];
-            const double p = a + b, ip_ = 1.0 / p;
-            const double kab = exp(-a * b * ip_ * ab2) * ca * B.coefs[jp];
-            const double px = (a * A.x + b * B.x) * ip_, py = (a * A.y + b * B.y) * ip_, pz = (a * A.z + b * B.z) * ip_;
+    for (int ip = 0; ip < bra.npa(); ++ip) {
+        for (int jp = 0; jp < bra.npb(); ++jp) {
+            const PrimPair P = bra.get(ip, jp);
+            if (P.kp == 0.0) continue;          // screened primitive pair (wave-uniform for rigid monomers)
+            const double p = P.p, px = P.px, py = P.py, pz = P.pz;
             E1D<LA, LB> ex, ey, ez;
-            ex.build(px - A.x, px - B.x, 0.5 * ip_);
-            ey.build(py - A.y, py - B.y, 0.5 * ip_);
-            ez.build(pz - A.z, pz - B.z, 0.5 * ip_);
-            for (int kp = 0; kp < C.nprim; ++kp) {
-                const double c = C.exps[kp], cc = C.coefs[kp];
-                for (int lp = 0; lp < D.nprim; ++lp) {
-                    const double d = D.exps[lp];
+            ex.build(px - bra.ax(), px - bra.bx(), P.hp);
+            ey.build(py - bra.ay(), py - bra.by(), P.hp);
+            ez.build(pz - bra.az(), pz - bra.bz(), P.hp);
+            const int nkl = ket.npairs();
+            PrimPair Qn = ket.get_flat(0);
+            for (int kl = 0; kl < nkl; ++kl) {
+                {
                     ex.pin(); ey.pin(); ez.pin();
-                    const double q = c + d, iq = 1.0 / q;
-                    const double kcd = exp(-c * d * iq * cd2) * cc * D.coefs[lp];
-                    const double qx = (c * C.x + d * D.x) * iq, qy = (c * C.y + d * D.y) * iq, qz = (c * C.z + d * D.z) * iq;
+                    const PrimPair Qp = Qn;
+                    if (kl + 1 < nkl) Qn = ket.get_flat(kl + 1);
+                    if (Qp.kp == 0.0) continue;
+                    const double q = Qp.p, qx = Qp.px, qy = Qp.py, qz = Qp.pz;
                     E1D<LC, LD> fx, fy, fz;
-                    fx.build(qx - C.x, qx - D.x, 0.5 * iq);
-                    fy.build(qy - C.y, qy - D.y, 0.5 * iq);
-                    fz.build(qz - C.z, qz - D.z, 0.5 * iq);
-                    const double alpha = p * q / (p + q);
-                    const double pref = TWO_PI_25 * ip_ * iq / sqrt(p + q) * kab * kcd;
+                    fx.build(qx - ket.ax(), qx - ket.bx(), Qp.hp);
+                    fy.build(qy - ket.ay(), qy - ket.by(), Qp.hp);
+                    fz.build(qz - ket.az(), qz - ket.bz(), Qp.hp);
+                    const double rpq = 1.0 / (p + q);
+                    const double alpha = p * q * rpq;
+                    const double pref = TWO_PI_25 * sqrt(rpq) * P.kp * Qp.kp;
                     double R[nherm(L)];
                     hermite_r<L>(alpha, px - qx, py - qy, pz - qz, boys_table, R);
 #pragma unroll
@@ -560,14 +604,23 @@ MQC_HD void eri_pass(const ShellRef& A, const ShellRef& B, const ShellRef& C, co
     }
 }
 
+template <int LA, int LB, int LC, int LD, int CH, int PASS, class Bra, class Ket, class Sink>
+MQC_HD void eri_passes_src(const Bra& bra, const Ket& ket,
+                           const double* __restrict__ boys_table, const double* __restrict__ c2s,
+                           double* __restrict__ acc, int stride, Sink& sink)
+{
+    constexpr int NPASS = (nsph(LC) * nsph(LD) + CH - 1) / CH;
+    eri_pass<LA, LB, LC, LD, CH, PASS>(bra, ket, boys_table, c2s, acc, stride, sink);
+    if constexpr (PASS + 1 < NPASS) eri_passes_src<LA, LB, LC, LD, CH, PASS + 1>(bra, ket, boys_table, c2s, acc, stride, sink);
+}
+
 template <int LA, int LB, int LC, int LD, int CH, int PASS, class Sink>
 MQC_HD void eri_passes_from(const ShellRef& A, const ShellRef& B, const ShellRef& C, const ShellRef& D,
                             const double* __restrict__ boys_table, const double* __restrict__ c2s,
                             double* __restrict__ acc, int stride, Sink& sink)
 {
-    constexpr int NPASS = (nsph(LC) * nsph(LD) + CH - 1) / CH;
-    eri_pass<LA, LB, LC, LD, CH, PASS>(A, B, C, D, boys_table, c2s, acc, stride, sink);
-    if constexpr (PASS + 1 < NPASS) eri_passes_from<LA, LB, LC, LD, CH, PASS + 1>(A, B, C, D, boys_table, c2s, acc, stride, sink);
+    const PairFly bra(A, B), ket(C, D);
+    eri_passes_src<LA, LB, LC, LD, CH, PASS>(bra, ket, boys_table, c2s, acc, stride, sink);
 }
 
 // ket components per pass: as many as keep the accumulator slab at or under 64 entries per lane
@@ -579,6 +632,12 @@ MQC_HD constexpr int eri_pass_chunk(int la, int lb, int lc, int ld)
     if (nab == 36 && ncd > 1) ch = 2;      // (dd| bra: two components per pass (72 accumulators)
     if (ch > ncd) ch = ncd;
     return ch;
+}
+
+// Schwarz diagonal blocks (ab|ab): a handful per fragment, so only the cheap-to-compile ones use passes
+MQC_HD constexpr bool schwarz_uses_passes(int la, int lb)
+{
+    return (la == 1 && lb == 1) || (la == 2 && lb == 0);
 }
 
 // classes that go through the pass kernel (everything that spilled in the one-shot register kernel)
