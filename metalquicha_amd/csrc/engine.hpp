@@ -110,6 +110,7 @@ struct BatchView {      // plain pointers handed to kernels
     double* scal;                 // [nfrag][8]: e_elec, e_old, de, drms, e_final, E_xc, N_electrons, -
     int* istate;                  // [nfrag][4]: state, iterations, nmo, converged
     int* counters;                // [4]: n_not_done, ...
+    int slot;                     // 0/1: which pipeline slot (stream, pools, launcher scratch) this batch view lives in
     XcSpec xc;                    // ncomp == 0: no XC term
     GridDev grid;
     double* Vxc;                  // [nfrag][n*n] un-symmetrised accumulator A (V_xc = A + A^T), or nullptr
@@ -138,6 +139,13 @@ struct mqc_hip_context {
     std::vector<double> h_c2s;                 // packed l = 0..LMAX_AO, (2l+1) x ncart(l)
     int c2s_off[8];
     mqc::DevicePool pool_main, pool_eri, pool_topo, pool_misc, pool_grid, pool_gridw, pool_aux, pool_df;
+    // second pipeline slot: the next chunk's integrals are formed while the current chunk iterates
+    mqc::DevicePool pool_main2, pool_eri2, pool_misc2, pool_gridw2, pool_df2;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t evb0 = nullptr, evb1 = nullptr, evb2 = nullptr, evb3 = nullptr;
+    hipEvent_t evq0 = nullptr, evq1 = nullptr, evq2 = nullptr, evq3 = nullptr;   // integral-stage timing per slot
+    int pipeline_chunks = 4;            // chunks a large batch is cut into
+    int pipeline_min_fragments = 256;   // batches below this run as one chunk
     double* d_unit = nullptr;
     mqc::Stats stats;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;

@@ -319,7 +319,8 @@ static void df2c_launch(const BatchView& bv, const std::vector<int>& t, int* d, 
 
 void launch_df_build(const BatchView& bv, const Topology& topo, const Topology& aux, hipStream_t s)
 {
-    static DevicePool lists;
+    static DevicePool lists_slot[2];
+    DevicePool& lists = lists_slot[bv.slot & 1];
     const int ns = (int)topo.shells.size(), nx = (int)aux.shells.size();
     // bucket tasks
     std::vector<int> t3[3][3][4], t2[4][4];

@@ -27,7 +27,9 @@ DIG_DECL(2, 2, 0, 0) DIG_DECL(2, 2, 1, 0) DIG_DECL(2, 2, 1, 1) DIG_DECL(2, 2, 2,
 
 void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, hipStream_t s)
 {
-    static DevicePool lists, qpool;
+    static DevicePool lists_slot[2], qpool_slot[2];
+    DevicePool& lists = lists_slot[bv.slot & 1];
+    DevicePool& qpool = qpool_slot[bv.slot & 1];
     // one device buffer for all class lists so that launches need no intermediate sync
     size_t total_ints = 0;
     for (auto& cl : topo.classes) total_ints += cl.quartets.size();
@@ -99,11 +101,13 @@ __global__ void symmetrise_jk_kernel(BatchView bv, const double* __restrict__ Jt
     bv.K[o + idx] = 0.5 * (Kt[o + idx] + Kt[o + j * n + i]);
 }
 
-static DevicePool g_direct_lists, g_direct_q, g_direct_work;
+static DevicePool g_direct_lists_slot[2], g_direct_q_slot[2], g_direct_work_slot[2];
 
 // Uploads the class lists and computes the Schwarz bounds; call once per batch before the SCF loop.
 void launch_direct_setup(const BatchView& bv, const Topology& topo, hipStream_t s)
 {
+    DevicePool& g_direct_lists = g_direct_lists_slot[bv.slot & 1];
+    DevicePool& g_direct_q = g_direct_q_slot[bv.slot & 1];
     size_t total_ints = topo.pairs.size();
     for (auto& cl : topo.classes) total_ints += cl.quartets.size();
     int* d_list = (int*)g_direct_lists.ensure((total_ints + 16) * sizeof(int));
@@ -138,6 +142,9 @@ void launch_jk_direct(const BatchView& bv, const Topology& topo, double thresh, 
 {
     const int n = bv.n, ns = (int)topo.shells.size(), oa = only_active ? 1 : 0;
     const size_t nn = (size_t)bv.nfrag * n * n, nss = (size_t)bv.nfrag * ns * ns;
+    DevicePool& g_direct_lists = g_direct_lists_slot[bv.slot & 1];
+    DevicePool& g_direct_q = g_direct_q_slot[bv.slot & 1];
+    DevicePool& g_direct_work = g_direct_work_slot[bv.slot & 1];
     const int* d_list = (const int*)g_direct_lists.ensure(0);
     double* Q = (double*)g_direct_q.ensure(0);
     double* Dmax = Q + nss;

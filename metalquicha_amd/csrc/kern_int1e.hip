@@ -154,7 +154,8 @@ static void launch_class(const BatchView& bv, const std::vector<int>& list, Devi
 
 void launch_int1e(const BatchView& bv, const Topology& topo, hipStream_t s)
 {
-    static DevicePool scratch;
+    static DevicePool scratch_slot[2];
+    DevicePool& scratch = scratch_slot[bv.slot & 1];
     // bucket the (A>=B) shell pairs by (la,lb) with la >= lb
     std::vector<int> bucket[KERNEL_LMAX + 1][KERNEL_LMAX + 1];
     for (size_t k = 0; k + 1 < topo.pairs.size(); k += 2) {

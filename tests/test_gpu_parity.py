@@ -339,3 +339,44 @@ def test_auto_mode_goes_direct_for_large_fragments():
     assert not d.has_error, d.error_message
     assert abs(r.energy.scf - d.energy.scf) < 5e-4
     assert r.scf_iterations == d.scf_iterations
+
+
+# ---- chunked / pipelined batches ------------------------------------------------------------------
+_CHUNK_CHILD = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from metalquicha_amd import methods
+from tests.helpers import fragment_bohr, water_at
+rng = np.random.default_rng(77)
+ws = [water_at(rng, [5.7 * i, 0.4 * (i % 3), -0.3 * (i % 2)]) for i in range(7)]
+frags = [fragment_bohr([8, 1, 1, 8, 1, 1], np.vstack([ws[i], ws[j]])) for i in range(7) for j in range(i + 1, 7)]
+kw = dict(basis_set="cc-pvdz", energy_tol=1e-9, density_tol=1e-7, guess="gwh")
+kw.update(json.loads(sys.argv[2]))
+res = methods.run_hip_scf_batch(methods.ScfSettings(**kw), frags)
+print(json.dumps({"e": [r.energy.scf for r in res], "it": [r.scf_iterations for r in res],
+                  "err": [r.error_message for r in res if r.has_error]}))
+"""
+
+
+@pytest.mark.parametrize("extra", [{}, {"functional": "pbe"}, {"density_fitting": True, "aux_basis_set": "mqc-even-tempered-jkfit"},
+                                   {"eri_mode": "direct"}], ids=["rhf", "pbe", "df", "direct"])
+def test_chunked_two_slot_batches_match_the_single_chunk_result(extra):
+    """21 dimers as ONE chunk vs cut into 5 chunks alternating between the two stream/pool slots
+    (MQC_HIP_PIPELINE_CHUNKS; the same code path an over-budget batch takes).  Fragments do not interact,
+    so iteration counts are identical and energies agree to the summation-order noise of the atomic
+    accumulations (1e-11 Eh)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(env_extra):
+        env = dict(os.environ, **env_extra)
+        out = subprocess.run([sys.executable, "-c", _CHUNK_CHILD, root, json.dumps(extra)], env=env, check=True,
+                             capture_output=True, text=True, timeout=600).stdout.strip().splitlines()[-1]
+        return json.loads(out)
+
+    one = run({"MQC_HIP_PIPELINE_CHUNKS": "1"})
+    five = run({"MQC_HIP_PIPELINE_CHUNKS": "5", "MQC_HIP_PIPELINE_MIN_FRAGMENTS": "2"})
+    assert not one["err"] and not five["err"], (one["err"], five["err"])
+    assert one["it"] == five["it"]
+    assert np.max(np.abs(np.array(one["e"]) - np.array(five["e"]))) < 1e-11
