@@ -18,6 +18,33 @@ namespace mqc {
 
 #define MQC_HD __host__ __device__ __forceinline__
 
+// 1/x and 1/sqrt(x) from the hardware seed plus two Newton steps (<= 1 ulp for the normal-range
+// arguments met here: exponent sums, T >= 42).  The IEEE-exact expansions cost 12 and ~25 instructions
+// per call and sat in the innermost primitive loop; the host build keeps the plain forms.
+MQC_HD double fast_rcp(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+#else
+    return 1.0 / x;
+#endif
+}
+MQC_HD double fast_rsqrt(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = fma(y, fma(-hx * y, y, 0.5), y);
+    y = fma(y, fma(-hx * y, y, 0.5), y);
+    return y;
+#else
+    return 1.0 / sqrt(x);
+#endif
+}
+
 // Makes a register value opaque to the optimiser at this point (no instruction is emitted).  Used on
 // the bra Hermite tables inside the ket primitive loops: without it LLVM's loop-invariant code motion
 // hoists every ex*ey*ez product out of those loops and keeps ~100 extra doubles alive, which is what
@@ -59,30 +86,37 @@ MQC_HD void boys(double T, const double* __restrict__ table, double* F)
     if (T < BOYS_TMAX) {
         int r = (int)(T * (1.0 / BOYS_STEP) + 0.5);
         double dt = r * BOYS_STEP - T;            // |dt| <= 0.05
-        const double* row = table + r * BOYS_COLS + L;
-        // F_L(T) = sum_k F_{L+k}(T0) dt^k / k!
-        double acc = row[7] * (1.0 / 5040.0);
-        acc = acc * dt + row[6] * (1.0 / 720.0);
-        acc = acc * dt + row[5] * (1.0 / 120.0);
-        acc = acc * dt + row[4] * (1.0 / 24.0);
-        acc = acc * dt + row[3] * (1.0 / 6.0);
-        acc = acc * dt + row[2] * 0.5;
-        acc = acc * dt + row[1];
-        acc = acc * dt + row[0];
-        F[L] = acc;
-        if (L > 0) {
+        const double* row = table + r * BOYS_COLS;
+        // F_n(T) = sum_k F_{n+k}(T0) dt^k / k!
+        auto taylor = [&](int n) {
+            const double* c = row + n;
+            double acc = c[7] * (1.0 / 5040.0);
+            acc = acc * dt + c[6] * (1.0 / 720.0);
+            acc = acc * dt + c[5] * (1.0 / 120.0);
+            acc = acc * dt + c[4] * (1.0 / 24.0);
+            acc = acc * dt + c[3] * (1.0 / 6.0);
+            acc = acc * dt + c[2] * 0.5;
+            acc = acc * dt + c[1];
+            acc = acc * dt + c[0];
+            return acc;
+        };
+        F[L] = taylor(L);
+        if constexpr (L > 0 && L <= 2) {
+            // low orders: a second/third Taylor sum over the same table row is cheaper than exp(-T)
+#pragma unroll
+            for (int n = L - 1; n >= 0; --n) F[n] = taylor(n);
+        } else if constexpr (L > 2) {
             double et = exp(-T);
 #pragma unroll
             for (int n = L; n > 0; --n) F[n - 1] = (2.0 * T * F[n] + et) * (1.0 / (2 * n - 1));
         }
     } else {
-        double inv = 1.0 / T;
-        F[0] = 0.886226925452758014 * sqrt(inv);   // sqrt(pi)/2 / sqrt(T); erfc(sqrt(42)) ~ 1e-20
-        if (L > 0) {
-            double et = exp(-T);
+        // asymptotic form; exp(-T) < 6e-19 is below one ulp of every F_n here and is dropped
+        const double rs = fast_rsqrt(T);
+        const double inv = rs * rs;
+        F[0] = 0.886226925452758014 * rs;   // sqrt(pi)/2 / sqrt(T); erfc(sqrt(42)) ~ 1e-20
 #pragma unroll
-            for (int n = 0; n < L; ++n) F[n + 1] = ((2 * n + 1) * F[n] - et) * (0.5 * inv);
-        }
+        for (int n = 0; n < L; ++n) F[n + 1] = ((2 * n + 1) * F[n]) * (0.5 * inv);
     }
 }
 
@@ -256,7 +290,7 @@ struct PairFly {
     MQC_HD PrimPair get(int ip, int jp) const
     {
         const double a = A.exps[ip], b = B.exps[jp];
-        const double p = a + b, ip_ = 1.0 / p;
+        const double p = a + b, ip_ = fast_rcp(p);
         PrimPair r;
         r.p = p; r.hp = 0.5 * ip_;
         r.px = (a * A.x + b * B.x) * ip_; r.py = (a * A.y + b * B.y) * ip_; r.pz = (a * A.z + b * B.z) * ip_;
@@ -301,148 +335,190 @@ MQC_HD void eri_cart_block_src(const Bra& bra, const Ket& ket, const double* __r
 
     constexpr double TWO_PI_25 = 34.986836655249725693;   // 2 pi^(5/2)
 
-    for (int ip = 0; ip < bra.npa(); ++ip) {
-        for (int jp = 0; jp < bra.npb(); ++jp) {
-            const PrimPair P = bra.get(ip, jp);
-            if (P.kp == 0.0) continue;          // screened primitive pair (wave-uniform for rigid monomers)
+    // one primitive quartet: bra record + Hermite tables, ket record
+    auto quartet = [&](const PrimPair& P, const E1D<LA, LB>& ex, const E1D<LA, LB>& ey, const E1D<LA, LB>& ez,
+                       const PrimPair& Qp) {
             const double p = P.p, px = P.px, py = P.py, pz = P.pz;
-            E1D<LA, LB> ex, ey, ez;
-            ex.build(px - bra.ax(), px - bra.bx(), P.hp);
-            ey.build(py - bra.ay(), py - bra.by(), P.hp);
-            ez.build(pz - bra.az(), pz - bra.bz(), P.hp);
-            // ket primitive pairs as ONE loop with the next record fetched ahead of the arithmetic
-            // (table source: the loads of record k+1 are in flight while record k is consumed)
-            const int nkl = ket.npairs();
-            PrimPair Qn = ket.get_flat(0);
-            for (int kl = 0; kl < nkl; ++kl) {
-                {
-                    const PrimPair Qp = Qn;
-                    if (kl + 1 < nkl) Qn = ket.get_flat(kl + 1);
-                    if (Qp.kp == 0.0) continue;
-                    const double q = Qp.p, qx = Qp.px, qy = Qp.py, qz = Qp.pz;
-                    E1D<LC, LD> fx, fy, fz;
-                    fx.build(qx - ket.ax(), qx - ket.bx(), Qp.hp);
-                    fy.build(qy - ket.ay(), qy - ket.by(), Qp.hp);
-                    fz.build(qz - ket.az(), qz - ket.bz(), Qp.hp);
-                    const double rpq = 1.0 / (p + q);
-                    const double alpha = p * q * rpq;
-                    const double pref = TWO_PI_25 * sqrt(rpq) * P.kp * Qp.kp;
-                    double R[nherm(L)];
-                    hermite_r<L>(alpha, px - qx, py - qy, pz - qz, boys_table, R);
+            const double q = Qp.p, qx = Qp.px, qy = Qp.py, qz = Qp.pz;
+            E1D<LC, LD> fx, fy, fz;
+            fx.build(qx - ket.ax(), qx - ket.bx(), Qp.hp);
+            fy.build(qy - ket.ay(), qy - ket.by(), Qp.hp);
+            fz.build(qz - ket.az(), qz - ket.bz(), Qp.hp);
+            const double rs = fast_rsqrt(p + q);
+            const double rpq = rs * rs;
+            const double alpha = p * q * rpq;
+            const double pref = TWO_PI_25 * rs * P.kp * Qp.kp;
+            double R[nherm(L)];
+            hermite_r<L>(alpha, px - qx, py - qy, pz - qz, boys_table, R);
 
-                    if constexpr (UNROLLED) {
-                        // loop over ket components; for each, G[h] over bra Hermite indices
-                        int icd = 0;
+            if constexpr (UNROLLED) {
+                // loop over ket components; for each, G[h] over bra Hermite indices
+                int icd = 0;
 #pragma unroll
-                        for (int cx = LC; cx >= 0; --cx) {
+                for (int cx = LC; cx >= 0; --cx) {
 #pragma unroll
-                            for (int cy = LC - cx; cy >= 0; --cy) {
-                                const int cz = LC - cx - cy;
+                    for (int cy = LC - cx; cy >= 0; --cy) {
+                        const int cz = LC - cx - cy;
 #pragma unroll
-                                for (int dx = LD; dx >= 0; --dx) {
+                        for (int dx = LD; dx >= 0; --dx) {
 #pragma unroll
-                                    for (int dy = LD - dx; dy >= 0; --dy) {
-                                        const int dz = LD - dx - dy;
-                                        double G[NHAB];
+                            for (int dy = LD - dx; dy >= 0; --dy) {
+                                const int dz = LD - dx - dy;
+                                double G[NHAB];
 #pragma unroll
-                                        for (int h = 0; h < NHAB; ++h) G[h] = 0.0;
+                                for (int h = 0; h < NHAB; ++h) G[h] = 0.0;
 #pragma unroll
-                                        for (int tt = 0; tt <= cx + dx; ++tt) {
+                                for (int tt = 0; tt <= cx + dx; ++tt) {
 #pragma unroll
-                                            for (int uu = 0; uu <= cy + dy; ++uu) {
+                                    for (int uu = 0; uu <= cy + dy; ++uu) {
 #pragma unroll
-                                                for (int ww = 0; ww <= cz + dz; ++ww) {
-                                                    double f = fx.get(cx, dx, tt) * fy.get(cy, dy, uu) * fz.get(cz, dz, ww);
-                                                    if ((tt + uu + ww) & 1) f = -f;
+                                        for (int ww = 0; ww <= cz + dz; ++ww) {
+                                            double f = fx.get(cx, dx, tt) * fy.get(cy, dy, uu) * fz.get(cz, dz, ww);
+                                            if ((tt + uu + ww) & 1) f = -f;
 #pragma unroll
-                                                    for (int N = 0; N <= LAB; ++N) {
+                                            for (int N = 0; N <= LAB; ++N) {
 #pragma unroll
-                                                        for (int t = N; t >= 0; --t) {
+                                                for (int t = N; t >= 0; --t) {
 #pragma unroll
-                                                            for (int u = N - t; u >= 0; --u) {
-                                                                const int v = N - t - u;
-                                                                G[hidx(t, u, v)] += f * R[hidx(t + tt, u + uu, v + ww)];
-                                                            }
-                                                        }
+                                                    for (int u = N - t; u >= 0; --u) {
+                                                        const int v = N - t - u;
+                                                        G[hidx(t, u, v)] += f * R[hidx(t + tt, u + uu, v + ww)];
                                                     }
                                                 }
                                             }
                                         }
-                                        // out[ab][cd] += pref * sum_h Eab[h] G[h]
-                                        int iab = 0;
-#pragma unroll
-                                        for (int ax = LA; ax >= 0; --ax) {
-#pragma unroll
-                                            for (int ay = LA - ax; ay >= 0; --ay) {
-                                                const int az = LA - ax - ay;
-#pragma unroll
-                                                for (int bx = LB; bx >= 0; --bx) {
-#pragma unroll
-                                                    for (int by = LB - bx; by >= 0; --by) {
-                                                        const int bz = LB - bx - by;
-                                                        double s = 0.0;
-#pragma unroll
-                                                        for (int t = 0; t <= ax + bx; ++t) {
-#pragma unroll
-                                                            for (int u = 0; u <= ay + by; ++u) {
-#pragma unroll
-                                                                for (int v = 0; v <= az + bz; ++v) {
-                                                                    s += ex.get(ax, bx, t) * ey.get(ay, by, u) * ez.get(az, bz, v) *
-                                                                         G[hidx(t, u, v)];
-                                                                }
-                                                            }
-                                                        }
-                                                        out[iab * (NCC * NCD) + icd] += pref * s;
-                                                        ++iab;
-                                                    }
-                                                }
-                                            }
-                                        }
-                                        ++icd;
-#if defined(__HIP_DEVICE_COMPILE__)
-                                        // keep the scheduler from interleaving ket components: the temporaries of
-                                        // one component die before the next starts (register pressure, not order)
-                                        __builtin_amdgcn_sched_barrier(0);
-#endif
                                     }
                                 }
-                            }
-                        }
-                    } else {
-                        // rolled form for the large classes: same arithmetic, run-time component indices
-#pragma unroll 1
-                        for (int icd = 0; icd < NCC * NCD; ++icd) {
-                            int cx, cy, cz, dx, dy, dz;
-                            cart_lmn(LC, icd / NCD, cx, cy, cz);
-                            cart_lmn(LD, icd % NCD, dx, dy, dz);
-                            double G[NHAB];
-                            for (int h = 0; h < NHAB; ++h) G[h] = 0.0;
-                            for (int tt = 0; tt <= cx + dx; ++tt)
-                                for (int uu = 0; uu <= cy + dy; ++uu)
-                                    for (int ww = 0; ww <= cz + dz; ++ww) {
-                                        double f = fx.get(cx, dx, tt) * fy.get(cy, dy, uu) * fz.get(cz, dz, ww);
-                                        if ((tt + uu + ww) & 1) f = -f;
-                                        for (int N = 0; N <= LAB; ++N)
-                                            for (int t = N; t >= 0; --t)
-                                                for (int u = N - t; u >= 0; --u) {
-                                                    const int v = N - t - u;
-                                                    G[hidx(t, u, v)] += f * R[hidx(t + tt, u + uu, v + ww)];
+                                // out[ab][cd] += pref * sum_h Eab[h] G[h]
+                                int iab = 0;
+#pragma unroll
+                                for (int ax = LA; ax >= 0; --ax) {
+#pragma unroll
+                                    for (int ay = LA - ax; ay >= 0; --ay) {
+                                        const int az = LA - ax - ay;
+#pragma unroll
+                                        for (int bx = LB; bx >= 0; --bx) {
+#pragma unroll
+                                            for (int by = LB - bx; by >= 0; --by) {
+                                                const int bz = LB - bx - by;
+                                                double s = 0.0;
+#pragma unroll
+                                                for (int t = 0; t <= ax + bx; ++t) {
+#pragma unroll
+                                                    for (int u = 0; u <= ay + by; ++u) {
+#pragma unroll
+                                                        for (int v = 0; v <= az + bz; ++v) {
+                                                            s += ex.get(ax, bx, t) * ey.get(ay, by, u) * ez.get(az, bz, v) *
+                                                                 G[hidx(t, u, v)];
+                                                        }
+                                                    }
                                                 }
+                                                out[iab * (NCC * NCD) + icd] += pref * s;
+                                                ++iab;
+                                            }
+                                        }
                                     }
-#pragma unroll 1
-                            for (int iab = 0; iab < NCA * NCB; ++iab) {
-                                int ax, ay, az, bx, by, bz;
-                                cart_lmn(LA, iab / NCB, ax, ay, az);
-                                cart_lmn(LB, iab % NCB, bx, by, bz);
-                                double s = 0.0;
-                                for (int t = 0; t <= ax + bx; ++t)
-                                    for (int u = 0; u <= ay + by; ++u)
-                                        for (int v = 0; v <= az + bz; ++v)
-                                            s += ex.get(ax, bx, t) * ey.get(ay, by, u) * ez.get(az, bz, v) * G[hidx(t, u, v)];
-                                out[iab * (NCC * NCD) + icd] += pref * s;
+                                }
+                                ++icd;
+#if defined(__HIP_DEVICE_COMPILE__)
+                                // keep the scheduler from interleaving ket components: the temporaries of
+                                // one component die before the next starts (register pressure, not order)
+                                __builtin_amdgcn_sched_barrier(0);
+#endif
                             }
                         }
                     }
+                }
+            } else {
+                // rolled form for the large classes: same arithmetic, run-time component indices
+#pragma unroll 1
+                for (int icd = 0; icd < NCC * NCD; ++icd) {
+                    int cx, cy, cz, dx, dy, dz;
+                    cart_lmn(LC, icd / NCD, cx, cy, cz);
+                    cart_lmn(LD, icd % NCD, dx, dy, dz);
+                    double G[NHAB];
+                    for (int h = 0; h < NHAB; ++h) G[h] = 0.0;
+                    for (int tt = 0; tt <= cx + dx; ++tt)
+                        for (int uu = 0; uu <= cy + dy; ++uu)
+                            for (int ww = 0; ww <= cz + dz; ++ww) {
+                                double f = fx.get(cx, dx, tt) * fy.get(cy, dy, uu) * fz.get(cz, dz, ww);
+                                if ((tt + uu + ww) & 1) f = -f;
+                                for (int N = 0; N <= LAB; ++N)
+                                    for (int t = N; t >= 0; --t)
+                                        for (int u = N - t; u >= 0; --u) {
+                                            const int v = N - t - u;
+                                            G[hidx(t, u, v)] += f * R[hidx(t + tt, u + uu, v + ww)];
+                                        }
+                            }
+#pragma unroll 1
+                    for (int iab = 0; iab < NCA * NCB; ++iab) {
+                        int ax, ay, az, bx, by, bz;
+                        cart_lmn(LA, iab / NCB, ax, ay, az);
+                        cart_lmn(LB, iab % NCB, bx, by, bz);
+                        double s = 0.0;
+                        for (int t = 0; t <= ax + bx; ++t)
+                            for (int u = 0; u <= ay + by; ++u)
+                                for (int v = 0; v <= az + bz; ++v)
+                                    s += ex.get(ax, bx, t) * ey.get(ay, by, u) * ez.get(az, bz, v) * G[hidx(t, u, v)];
+                        out[iab * (NCC * NCD) + icd] += pref * s;
+                    }
+                }
+            }
+    };
+
+    // Small classes (block <= 27 numbers): ket records are formed TK at a time and held in registers
+    // while ALL bra records stream past, so the ket-side exp/reciprocal/centre arithmetic -- a third of
+    // the inner loop of (ss|ss) -- runs once per record instead of once per primitive quartet.
+    constexpr int TK = (UNROLLED && NCA * NCB * NCC * NCD <= 27) ? 4 : 1;
+    if constexpr (TK > 1) {
+        const int nkl = ket.npairs();
+        int kc = 0, kd = 0;
+        for (int kl0 = 0; kl0 < nkl; kl0 += TK) {
+            PrimPair Qt[TK];
+#pragma unroll
+            for (int t = 0; t < TK; ++t) {
+                if (kl0 + t < nkl) {
+                    Qt[t] = ket.get(kc, kd);
+                    if (++kd == ket.npb()) { kd = 0; ++kc; }
+                } else {
+                    Qt[t] = PrimPair{};
+                    Qt[t].p = 1.0; Qt[t].kp = 0.0;
+                }
+            }
+            for (int ip = 0; ip < bra.npa(); ++ip) {
+                for (int jp = 0; jp < bra.npb(); ++jp) {
+                    const PrimPair P = bra.get(ip, jp);
+                    if (P.kp == 0.0) continue;
+                    E1D<LA, LB> ex, ey, ez;
+                    ex.build(P.px - bra.ax(), P.px - bra.bx(), P.hp);
+                    ey.build(P.py - bra.ay(), P.py - bra.by(), P.hp);
+                    ez.build(P.pz - bra.az(), P.pz - bra.bz(), P.hp);
+#pragma unroll
+                    for (int t = 0; t < TK; ++t) {
+                        if (Qt[t].kp != 0.0) quartet(P, ex, ey, ez, Qt[t]);
+                    }
+                }
+            }
+        }
+    } else {
+        for (int ip = 0; ip < bra.npa(); ++ip) {
+            for (int jp = 0; jp < bra.npb(); ++jp) {
+                const PrimPair P = bra.get(ip, jp);
+                if (P.kp == 0.0) continue;          // screened primitive pair (wave-uniform for rigid monomers)
+                E1D<LA, LB> ex, ey, ez;
+                ex.build(P.px - bra.ax(), P.px - bra.bx(), P.hp);
+                ey.build(P.py - bra.ay(), P.py - bra.by(), P.hp);
+                ez.build(P.pz - bra.az(), P.pz - bra.bz(), P.hp);
+                // ket primitive pairs as ONE loop with the next record formed ahead of the arithmetic
+                const int nkl = ket.npairs();
+                PrimPair Qn = ket.get(0, 0);
+                int kc = 0, kd = 0;
+                for (int kl = 0; kl < nkl; ++kl) {
+                    const PrimPair Qp = Qn;
+                    if (++kd == ket.npb()) { kd = 0; ++kc; }
+                    if (kl + 1 < nkl) Qn = ket.get(kc, kd);
+                    if (Qp.kp == 0.0) continue;
+                    quartet(P, ex, ey, ez, Qp);
                 }
             }
         }
@@ -498,21 +574,24 @@ MQC_HD void eri_pass(const Bra& bra, const Ket& ket,
             ey.build(py - bra.ay(), py - bra.by(), P.hp);
             ez.build(pz - bra.az(), pz - bra.bz(), P.hp);
             const int nkl = ket.npairs();
-            PrimPair Qn = ket.get_flat(0);
+            PrimPair Qn = ket.get(0, 0);
+            int kc = 0, kd = 0;
             for (int kl = 0; kl < nkl; ++kl) {
                 {
                     ex.pin(); ey.pin(); ez.pin();
                     const PrimPair Qp = Qn;
-                    if (kl + 1 < nkl) Qn = ket.get_flat(kl + 1);
+                    if (++kd == ket.npb()) { kd = 0; ++kc; }
+                    if (kl + 1 < nkl) Qn = ket.get(kc, kd);
                     if (Qp.kp == 0.0) continue;
                     const double q = Qp.p, qx = Qp.px, qy = Qp.py, qz = Qp.pz;
                     E1D<LC, LD> fx, fy, fz;
                     fx.build(qx - ket.ax(), qx - ket.bx(), Qp.hp);
                     fy.build(qy - ket.ay(), qy - ket.by(), Qp.hp);
                     fz.build(qz - ket.az(), qz - ket.bz(), Qp.hp);
-                    const double rpq = 1.0 / (p + q);
+                    const double rs = fast_rsqrt(p + q);
+                    const double rpq = rs * rs;
                     const double alpha = p * q * rpq;
-                    const double pref = TWO_PI_25 * sqrt(rpq) * P.kp * Qp.kp;
+                    const double pref = TWO_PI_25 * rs * P.kp * Qp.kp;
                     double R[nherm(L)];
                     hermite_r<L>(alpha, px - qx, py - qy, pz - qz, boys_table, R);
 #pragma unroll
