@@ -41,7 +41,15 @@ struct Topology {
     std::vector<double> exps, coefs; // normalised radial coefficients (s,p angular factor folded in)
     int nao = 0, npair = 0, lmax = 0;
     // shell-quartet task lists, one per (la,lb,lc,ld) class, canonical order
-    struct ClassList { int la, lb, lc, ld; std::vector<int> quartets; /* 4 ints each */ };
+    struct ClassList {
+        int la, lb, lc, ld;
+        std::vector<int> quartets;       // 4 ints each: every canonical quartet of the class
+        // twin-shell cut of the same class (in-core ERI build, md_integrals.hpp TwinCoefs):
+        //   twin_entries -- 4 ints each, FIRST member shells, bit 16 set on twin positions;
+        //   rest         -- the quartets no twin entry covers.  Both empty when the class has no twin block.
+        std::vector<int> twin_entries, rest;
+    };
+    std::vector<int> twin_first;     // per shell: 1 when the shell and its successor form a twin s pair
     std::vector<ClassList> classes;
     std::vector<int> pairs;          // (A,B) with A>=B, 2 ints each, for the 1e kernel (la>=lb ordering)
     int64_t n_quartets = 0;

@@ -198,6 +198,77 @@ __global__ void __launch_bounds__(64) eri_kernel(BatchView bv, const int* __rest
 }
 
 // ---------------------------------------------------------------------------------------
+// Twin-shell kernel (md_integrals.hpp, TwinCoefs): list entries are the FIRST member shells with bit 16
+// set where the position is a twin; a thread forms the primitive integrals of its (entry, fragment)
+// once and stores one spherical block per member combination.  Same thread mapping as eri_kernel.
+constexpr int TWIN_FLAG = 1 << 16;
+
+template <int LA, int LB, int LC, int LD>
+__global__ void __launch_bounds__(64) eri_twin_kernel(BatchView bv, const int* __restrict__ quartets, int nquart)
+{
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)nquart * bv.nfrag;
+    if (tid >= total) return;
+    const int iq = (int)(tid / bv.nfrag), f = (int)(tid % bv.nfrag);
+    const int eA = quartets[4 * iq], eB = quartets[4 * iq + 1], eC = quartets[4 * iq + 2], eD = quartets[4 * iq + 3];
+    const int A = eA & (TWIN_FLAG - 1), B = eB & (TWIN_FLAG - 1), C = eC & (TWIN_FLAG - 1), D = eD & (TWIN_FLAG - 1);
+    const bool tA = (eA & TWIN_FLAG) != 0, tB = (eB & TWIN_FLAG) != 0, tC = (eC & TWIN_FLAG) != 0, tD = (eD & TWIN_FLAG) != 0;
+    const TopologyDev& tp = bv.topo;
+    const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
+    const ShellRef sa = make_shell(tp, xyz, A), sb = make_shell(tp, xyz, B), sc = make_shell(tp, xyz, C), sd = make_shell(tp, xyz, D);
+    TwinCoefs tw;
+    tw.ca[0] = sa.coefs; tw.ca[1] = tA ? tp.coefs + tp.sh_poff[A + 1] : sa.coefs; tw.fa = tA ? 1.0 : 0.0;
+    tw.cb[0] = sb.coefs; tw.cb[1] = tB ? tp.coefs + tp.sh_poff[B + 1] : sb.coefs; tw.fb = tB ? 1.0 : 0.0;
+    tw.cc[0] = sc.coefs; tw.cc[1] = tC ? tp.coefs + tp.sh_poff[C + 1] : sc.coefs; tw.fc = tC ? 1.0 : 0.0;
+    tw.cd[0] = sd.coefs; tw.cd[1] = tD ? tp.coefs + tp.sh_poff[D + 1] : sd.coefs; tw.fd = tD ? 1.0 : 0.0;
+
+    constexpr int NC = ncart(LA) * ncart(LB) * ncart(LC) * ncart(LD);
+    constexpr int NSA = nsph(LA), NSB = nsph(LB), NSC = nsph(LC), NSD = nsph(LD);
+    constexpr int MA = twin_mult(true, LA), MB = twin_mult(true, LB), MC = twin_mult(true, LC), MD = twin_mult(true, LD);
+    double acc[MA * MB * MC * MD * NC];
+    eri_cart_block_twin<LA, LB, LC, LD>(sa, sb, sc, sd, tw, bv.boys, acc);
+
+    const size_t np = (size_t)bv.npair;
+    double* M = bv.eri + (size_t)f * np * np;
+#pragma unroll
+    for (int ma = 0; ma < MA; ++ma) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+            for (int mc = 0; mc < MC; ++mc) {
+#pragma unroll
+                for (int md = 0; md < MD; ++md) {
+                    if ((ma && !tA) || (mb && !tB) || (mc && !tC) || (md && !tD)) continue;
+                    const int a = A + ma, b = B + mb, c = C + mc, d = D + md;
+                    double sph[NC];
+                    block_to_spherical<LA, LB, LC, LD>(bv.c2s, acc + (((ma * MB + mb) * MC + mc) * MD + md) * NC, sph);
+                    const int oa = tp.sh_aoff[a], ob = tp.sh_aoff[b], oc = tp.sh_aoff[c], od = tp.sh_aoff[d];
+#pragma unroll
+                    for (int i = 0; i < NSA; ++i) {
+#pragma unroll
+                        for (int j = 0; j < NSB; ++j) {
+                            if (a == b && j > i) continue;
+                            const size_t row = pair_index(oa + i, ob + j);
+#pragma unroll
+                            for (int k = 0; k < NSC; ++k) {
+#pragma unroll
+                                for (int l = 0; l < NSD; ++l) {
+                                    if (c == d && l > k) continue;
+                                    const size_t col = pair_index(oc + k, od + l);
+                                    const double v = sph[((i * NSB + j) * NSC + k) * NSD + l];
+                                    M[row * np + col] = v;
+                                    M[col * np + row] = v;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Pass kernel for the classes whose accumulators exceed the register file (md_integrals.hpp,
 // eri_pass): same (quartet, fragment) thread mapping; the accumulators of a wave sit in its own
 // LDS slab acc[entry][lane].
@@ -417,6 +488,15 @@ void launch_eri_class(const BatchView& bv, const int* quartets_host, int nq, int
     } else {
         hipLaunchKernelGGL((eri_kernel<LA, LB, LC, LD>), dim3(blocks), dim3(64), 0, s, bv, d_list, nq, Q, thresh);
     }
+}
+
+template <int LA, int LB, int LC, int LD>
+void launch_eri_twin_class(const BatchView& bv, const int* entries_host, int nq, int* d_list, hipStream_t s)
+{
+    if (nq == 0) return;
+    (void)hipMemcpyAsync(d_list, entries_host, (size_t)nq * 4 * sizeof(int), hipMemcpyHostToDevice, s);
+    const long total = (long)nq * bv.nfrag;
+    hipLaunchKernelGGL((eri_twin_kernel<LA, LB, LC, LD>), dim3((int)((total + 63) / 64)), dim3(64), 0, s, bv, d_list, nq);
 }
 
 template <int LA, int LB>

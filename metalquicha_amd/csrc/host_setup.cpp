@@ -232,6 +232,45 @@ int build_topology(const mqc_hip_molecule_t& mol, const mqc_hip_basis_t& bas, To
             tmp[id].push_back({bra.np * ket.np, {bra.a, bra.b, ket.a, ket.b}});
             topo.n_quartets++;
         }
+    // ---- twin s shells: consecutive s shells of one atom contracted over identical primitives
+    topo.twin_first.assign(ns, 0);
+    std::vector<int> member_of_twin(ns, 0);
+    for (int A = 0; A + 1 < ns; ++A) {
+        const HostShell &x = topo.shells[A], &y = topo.shells[A + 1];
+        if (member_of_twin[A] || x.l != 0 || y.l != 0 || x.atom != y.atom || x.nprim != y.nprim || x.nprim < 2) continue;
+        bool same = true;
+        for (int k = 0; k < x.nprim; ++k) same = same && (topo.exps[x.poff + k] == topo.exps[y.poff + k]);
+        if (!same) continue;
+        topo.twin_first[A] = 1;
+        member_of_twin[A] = member_of_twin[A + 1] = 1;
+    }
+    // super-shells (a twin pair counts once), their canonical pairs and quartets -> twin entries per class
+    std::map<int, std::vector<std::pair<int, std::array<int, 4>>>> ttmp;
+    {
+        std::vector<int> sup;     // first member of every super-shell
+        for (int A = 0; A < ns; ++A) if (!(member_of_twin[A] && !topo.twin_first[A])) sup.push_back(A);
+        struct SP { int a, b, la, lb, pc, np; };
+        std::vector<SP> spl;
+        for (size_t X = 0; X < sup.size(); ++X)
+            for (size_t Y = 0; Y <= X; ++Y) {
+                int a = sup[X], b = sup[Y];
+                if (topo.shells[a].l < topo.shells[b].l) std::swap(a, b);
+                const int la = topo.shells[a].l, lb = topo.shells[b].l;
+                spl.push_back({a, b, la, lb, la * (la + 1) / 2 + lb, topo.shells[a].nprim * topo.shells[b].nprim});
+            }
+        for (size_t ij = 0; ij < spl.size(); ++ij)
+            for (size_t kl = 0; kl <= ij; ++kl) {
+                SP bra = spl[ij], ket = spl[kl];
+                if (bra.pc < ket.pc) std::swap(bra, ket);
+                if (!eri_has_twin_block(bra.la, bra.lb, ket.la, ket.lb)) continue;
+                const int sh4[4] = {bra.a, bra.b, ket.a, ket.b};
+                if (!(topo.twin_first[sh4[0]] || topo.twin_first[sh4[1]] || topo.twin_first[sh4[2]] || topo.twin_first[sh4[3]])) continue;
+                std::array<int, 4> e;
+                for (int k = 0; k < 4; ++k) e[k] = sh4[k] | (topo.twin_first[sh4[k]] ? (1 << 16) : 0);
+                const int id = ((bra.la * 8 + bra.lb) * 8 + ket.la) * 8 + ket.lb;
+                ttmp[id].push_back({bra.np * ket.np, e});
+            }
+    }
     for (auto& kv : tmp) {
         auto& v = kv.second;
         // deepest contractions first: lanes of a wave then share a trip count even in a batch of one
@@ -240,6 +279,16 @@ int build_topology(const mqc_hip_molecule_t& mol, const mqc_hip_basis_t& bas, To
         const int id = kv.first;
         cl.ld = id % 8; cl.lc = (id / 8) % 8; cl.lb = (id / 64) % 8; cl.la = id / 512;
         for (auto& q : v) for (int k = 0; k < 4; ++k) cl.quartets.push_back(q.second[k]);
+        if (eri_has_twin_block(cl.la, cl.lb, cl.lc, cl.ld) && ttmp.count(id)) {
+            auto& tv = ttmp[id];
+            std::stable_sort(tv.begin(), tv.end(), [](const auto& x, const auto& y) { return x.first > y.first; });
+            for (auto& q : tv) for (int k = 0; k < 4; ++k) cl.twin_entries.push_back(q.second[k]);
+            for (auto& q : v) {
+                const auto& e = q.second;
+                if (member_of_twin[e[0]] || member_of_twin[e[1]] || member_of_twin[e[2]] || member_of_twin[e[3]]) continue;
+                for (int k = 0; k < 4; ++k) cl.rest.push_back(e[k]);
+            }
+        }
         topo.classes.push_back(std::move(cl));
     }
     return MQC_HIP_OK;

@@ -12,6 +12,10 @@ ERI_DECL(0, 0, 0, 0) ERI_DECL(1, 0, 0, 0) ERI_DECL(1, 0, 1, 0) ERI_DECL(1, 1, 0,
 ERI_DECL(2, 0, 0, 0) ERI_DECL(2, 0, 1, 0) ERI_DECL(2, 0, 1, 1) ERI_DECL(2, 0, 2, 0)
 ERI_DECL(2, 1, 0, 0) ERI_DECL(2, 1, 1, 0) ERI_DECL(2, 1, 1, 1) ERI_DECL(2, 1, 2, 0) ERI_DECL(2, 1, 2, 1)
 ERI_DECL(2, 2, 0, 0) ERI_DECL(2, 2, 1, 0) ERI_DECL(2, 2, 1, 1) ERI_DECL(2, 2, 2, 0) ERI_DECL(2, 2, 2, 1) ERI_DECL(2, 2, 2, 2)
+#define TWIN_DECL(a, b, c, d) \
+    extern template void launch_eri_twin_class<a, b, c, d>(const BatchView&, const int*, int, int*, hipStream_t);
+TWIN_DECL(0, 0, 0, 0) TWIN_DECL(1, 0, 0, 0) TWIN_DECL(1, 0, 1, 0) TWIN_DECL(1, 1, 0, 0)
+TWIN_DECL(1, 1, 1, 0) TWIN_DECL(2, 0, 0, 0) TWIN_DECL(2, 0, 1, 0) TWIN_DECL(2, 1, 0, 0)
 SCHWARZ_DECL(0, 0) SCHWARZ_DECL(1, 0) SCHWARZ_DECL(1, 1) SCHWARZ_DECL(2, 0) SCHWARZ_DECL(2, 1) SCHWARZ_DECL(2, 2)
 
 #define DIG_DECL(a, b, c, d) \
@@ -24,6 +28,13 @@ DIG_DECL(2, 2, 0, 0) DIG_DECL(2, 2, 1, 0) DIG_DECL(2, 2, 1, 1) DIG_DECL(2, 2, 2,
 #define ERI_CASE(a, b, c, d)                                                                          \
     if (cl.la == a && cl.lb == b && cl.lc == c && cl.ld == d)                                         \
         launch_eri_class<a, b, c, d>(bv, cl.quartets.data(), (int)cl.quartets.size() / 4, d_list + off, Q, thresh, s);
+
+// MQC_HIP_NO_TWIN_BLOCKS=1 forces the segmented treatment everywhere (A/B measurements, tests)
+static bool twin_blocks_disabled()
+{
+    static const bool off = [] { const char* e = std::getenv("MQC_HIP_NO_TWIN_BLOCKS"); return e && e[0] == '1'; }();
+    return off;
+}
 
 void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, hipStream_t s)
 {
@@ -59,7 +70,22 @@ void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, h
 #undef SCHWARZ_CASE
         (void)hipStreamSynchronize(s);     // the bucket vectors go out of scope
     }
+    // twin-shell cut (exact ERIs without Schwarz screening): twin entries first, then the uncovered rest
+    const bool twins = (schwarz_tol <= 0.0) && !twin_blocks_disabled();
     for (auto& cl : topo.classes) {
+        if (twins && !cl.twin_entries.empty()) {
+            const int nt = (int)cl.twin_entries.size() / 4, nr = (int)cl.rest.size() / 4;
+#define TWIN_CASE(a, b, c, d)                                                                          \
+    if (cl.la == a && cl.lb == b && cl.lc == c && cl.ld == d) {                                         \
+        launch_eri_twin_class<a, b, c, d>(bv, cl.twin_entries.data(), nt, d_list + off, s);             \
+        launch_eri_class<a, b, c, d>(bv, cl.rest.data(), nr, d_list + off + cl.twin_entries.size(), nullptr, 0.0, s); \
+    }
+            TWIN_CASE(0, 0, 0, 0) TWIN_CASE(1, 0, 0, 0) TWIN_CASE(1, 0, 1, 0) TWIN_CASE(1, 1, 0, 0)
+            TWIN_CASE(1, 1, 1, 0) TWIN_CASE(2, 0, 0, 0) TWIN_CASE(2, 0, 1, 0) TWIN_CASE(2, 1, 0, 0)
+#undef TWIN_CASE
+            off += cl.quartets.size();      // twin entries + rest never exceed the full list
+            continue;
+        }
         ERI_CASE(0, 0, 0, 0)
         ERI_CASE(1, 0, 0, 0) ERI_CASE(1, 0, 1, 0)
         ERI_CASE(1, 1, 0, 0) ERI_CASE(1, 1, 1, 0) ERI_CASE(1, 1, 1, 1)

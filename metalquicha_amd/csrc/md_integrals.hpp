@@ -111,12 +111,14 @@ MQC_HD void boys(double T, const double* __restrict__ table, double* F)
             for (int n = L; n > 0; --n) F[n - 1] = (2.0 * T * F[n] + et) * (1.0 / (2 * n - 1));
         }
     } else {
-        // asymptotic form; exp(-T) < 6e-19 is below one ulp of every F_n here and is dropped
+        // asymptotic form; exp(-T) < 6e-19 is below one ulp of F_0..F_2 and only kept for higher orders
         const double rs = fast_rsqrt(T);
         const double inv = rs * rs;
         F[0] = 0.886226925452758014 * rs;   // sqrt(pi)/2 / sqrt(T); erfc(sqrt(42)) ~ 1e-20
+        double et = 0.0;
+        if constexpr (L > 2) et = exp(-T);
 #pragma unroll
-        for (int n = 0; n < L; ++n) F[n + 1] = ((2 * n + 1) * F[n]) * (0.5 * inv);
+        for (int n = 0; n < L; ++n) F[n + 1] = ((2 * n + 1) * F[n] - et) * (0.5 * inv);
     }
 }
 
@@ -269,10 +271,11 @@ struct PrimPair {
 constexpr int PAIR_REC = 6;
 constexpr double PRIM_EXP_CUTOFF = 46.0;
 
-struct PairFly {
+template <bool COEF>
+struct PairFlyT {
     ShellRef A, B;
     double ab2;
-    MQC_HD PairFly(const ShellRef& a, const ShellRef& b) : A(a), B(b)
+    MQC_HD PairFlyT(const ShellRef& a, const ShellRef& b) : A(a), B(b)
     {
         const double dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
         ab2 = dx * dx + dy * dy + dz * dz;
@@ -296,10 +299,14 @@ struct PairFly {
         r.px = (a * A.x + b * B.x) * ip_; r.py = (a * A.y + b * B.y) * ip_; r.pz = (a * A.z + b * B.z) * ip_;
         // primitive screening: exp(-46) = 1e-20 -- a pair this far apart contributes nothing representable
         const double arg = a * b * ip_ * ab2;
-        r.kp = (arg < PRIM_EXP_CUTOFF) ? exp(-arg) * A.coefs[ip] * B.coefs[jp] * ip_ : 0.0;
+        if constexpr (COEF) r.kp = (arg < PRIM_EXP_CUTOFF) ? exp(-arg) * A.coefs[ip] * B.coefs[jp] * ip_ : 0.0;
+        else r.kp = (arg < PRIM_EXP_CUTOFF) ? exp(-arg) * ip_ : 0.0;
         return r;
     }
 };
+using PairFly = PairFlyT<true>;       // contraction coefficients folded into K'
+using PairFlyRaw = PairFlyT<false>;   // bare primitive pairs (twin-shell blocks apply several coefficient sets)
+
 
 // decode Cartesian component k of shell l -> (lx, ly, lz), libcint order
 MQC_HD void cart_lmn(int l, int k, int& lx, int& ly, int& lz)
@@ -316,28 +323,57 @@ MQC_HD void cart_lmn(int l, int k, int& lx, int& ly, int& lz)
 constexpr int ERI_UNROLL_LIMIT = 324;
 
 // ---------------------------------------------------------------------------------------
+// Twin s shells.  Dunning-type sets give an atom two s functions contracted over the SAME primitives
+// (cc-pVDZ oxygen: 9 primitives, two coefficient columns); a segmented treatment forms every primitive
+// integral over them twice per index.  A twin block forms the primitive integrals once and adds them
+// into one accumulator set per member combination with that combination's coefficient product
+// (libcint's general-contraction loop does the same on the CPU: cint2e.c CINT2e_loop_nopt).
+// c?[0] = coefficients of the first member, c?[1] = of the second (any valid pointer with f? = 0 when that
+// position is an ordinary shell: branch-free inner loops).  Only s positions can be twins (multiplicity 2), others have multiplicity 1.
+#ifndef MQC_PLAIN_TK
+#define MQC_PLAIN_TK 2
+#endif
+struct NoTwin {
+    static constexpr bool enabled = false;
+};
+struct TwinCoefs {
+    static constexpr bool enabled = true;
+    const double* ca[2];
+    const double* cb[2];
+    const double* cc[2];
+    const double* cd[2];
+    double fa, fb, fc, fd;    // 1.0 where the position is a twin, 0.0 where c?[1] merely repeats c?[0]
+};
+MQC_HD constexpr int twin_mult(bool enabled, int l) { return (enabled && l == 0) ? 2 : 1; }
+MQC_HD double twin_coef(const double* const* c, double f, int m, int k) { return m == 0 ? c[0][k] : f * c[1][k]; }
+
+// ---------------------------------------------------------------------------------------
 // Contracted Cartesian ERI block (ab|cd), out[((ia*NCB+ib)*NCC+ic)*NCD+id] (accumulated
 // into a zeroed buffer by this routine).
-template <int LA, int LB, int LC, int LD, class Bra, class Ket>
-MQC_HD void eri_cart_block_src(const Bra& bra, const Ket& ket, const double* __restrict__ boys_table, double* out)
+template <int LA, int LB, int LC, int LD, class Bra, class Ket, class Twin = NoTwin>
+MQC_HD void eri_cart_block_src(const Bra& bra, const Ket& ket, const double* __restrict__ boys_table, double* out,
+                               const Twin& tw = Twin())
 {
     constexpr int NCA = ncart(LA), NCB = ncart(LB), NCC = ncart(LC), NCD = ncart(LD);
     constexpr int LAB = LA + LB, LCD = LC + LD, L = LAB + LCD;
     constexpr int NHAB = nherm(LAB);
     constexpr bool UNROLLED = (NCA * NCB * NCC * NCD <= ERI_UNROLL_LIMIT);
-    (void)LCD;
+    constexpr int MA = twin_mult(Twin::enabled, LA), MB = twin_mult(Twin::enabled, LB);
+    constexpr int MC = twin_mult(Twin::enabled, LC), MD = twin_mult(Twin::enabled, LD);
+    constexpr int NCOMB = MA * MB * MC * MD, NC = NCA * NCB * NCC * NCD;
+    (void)LCD; (void)tw;
     if constexpr (UNROLLED) {
 #pragma unroll
-        for (int i = 0; i < NCA * NCB * NCC * NCD; ++i) out[i] = 0.0;
+        for (int i = 0; i < NCOMB * NC; ++i) out[i] = 0.0;
     } else {
-        for (int i = 0; i < NCA * NCB * NCC * NCD; ++i) out[i] = 0.0;
+        for (int i = 0; i < NCOMB * NC; ++i) out[i] = 0.0;
     }
 
     constexpr double TWO_PI_25 = 34.986836655249725693;   // 2 pi^(5/2)
 
     // one primitive quartet: bra record + Hermite tables, ket record
     auto quartet = [&](const PrimPair& P, const E1D<LA, LB>& ex, const E1D<LA, LB>& ey, const E1D<LA, LB>& ez,
-                       const PrimPair& Qp) {
+                       const PrimPair& Qp, auto&& emit) {
             const double p = P.p, px = P.px, py = P.py, pz = P.pz;
             const double q = Qp.p, qx = Qp.px, qy = Qp.py, qz = Qp.pz;
             E1D<LC, LD> fx, fy, fz;
@@ -413,7 +449,7 @@ MQC_HD void eri_cart_block_src(const Bra& bra, const Ket& ket, const double* __r
                                                         }
                                                     }
                                                 }
-                                                out[iab * (NCC * NCD) + icd] += pref * s;
+                                                emit(iab * (NCC * NCD) + icd, pref * s);
                                                 ++iab;
                                             }
                                         }
@@ -460,7 +496,7 @@ MQC_HD void eri_cart_block_src(const Bra& bra, const Ket& ket, const double* __r
                             for (int u = 0; u <= ay + by; ++u)
                                 for (int v = 0; v <= az + bz; ++v)
                                     s += ex.get(ax, bx, t) * ey.get(ay, by, u) * ez.get(az, bz, v) * G[hidx(t, u, v)];
-                        out[iab * (NCC * NCD) + icd] += pref * s;
+                        emit(iab * (NCC * NCD) + icd, pref * s);
                     }
                 }
             }
@@ -469,8 +505,63 @@ MQC_HD void eri_cart_block_src(const Bra& bra, const Ket& ket, const double* __r
     // Small classes (block <= 27 numbers): ket records are formed TK at a time and held in registers
     // while ALL bra records stream past, so the ket-side exp/reciprocal/centre arithmetic -- a third of
     // the inner loop of (ss|ss) -- runs once per record instead of once per primitive quartet.
-    constexpr int TK = (UNROLLED && NCA * NCB * NCC * NCD <= 27) ? 4 : 1;
-    if constexpr (TK > 1) {
+    constexpr int TK = !(UNROLLED && NCA * NCB * NCC * NCD <= 27) ? 1 : (NCA * NCB * NCC * NCD <= 3 ? 4 : MQC_PLAIN_TK);
+    auto plain = [&](int i, double v) { out[i] += v; };
+    (void)plain;
+    if constexpr (Twin::enabled) {
+        static_assert(!Twin::enabled || TK > 1, "twin blocks exist for the small register classes only");
+        constexpr int TKT = (NC == 1) ? 2 : 1;   // ket records held at a time (register budget: NCOMB accumulator sets)
+        const int nkl = ket.npairs();
+        int kc = 0, kd = 0;
+        for (int kl0 = 0; kl0 < nkl; kl0 += TKT) {
+            PrimPair Qt[TKT];
+            double wcd[TKT][MC * MD];
+#pragma unroll
+            for (int t = 0; t < TKT; ++t) {
+                if (kl0 + t < nkl) {
+                    Qt[t] = ket.get(kc, kd);
+#pragma unroll
+                    for (int mc = 0; mc < MC; ++mc)
+#pragma unroll
+                        for (int md = 0; md < MD; ++md) wcd[t][mc * MD + md] = twin_coef(tw.cc, tw.fc, mc, kc) * twin_coef(tw.cd, tw.fd, md, kd);
+                    if (++kd == ket.npb()) { kd = 0; ++kc; }
+                } else {
+                    Qt[t] = PrimPair{};
+                    Qt[t].p = 1.0; Qt[t].kp = 0.0;
+#pragma unroll
+                    for (int m = 0; m < MC * MD; ++m) wcd[t][m] = 0.0;
+                }
+            }
+            for (int ip = 0; ip < bra.npa(); ++ip) {
+                for (int jp = 0; jp < bra.npb(); ++jp) {
+                    const PrimPair P = bra.get(ip, jp);
+                    if (P.kp == 0.0) continue;
+                    double wab[MA * MB];
+#pragma unroll
+                    for (int ma = 0; ma < MA; ++ma)
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb) wab[ma * MB + mb] = twin_coef(tw.ca, tw.fa, ma, ip) * twin_coef(tw.cb, tw.fb, mb, jp);
+                    E1D<LA, LB> ex, ey, ez;
+                    ex.build(P.px - bra.ax(), P.px - bra.bx(), P.hp);
+                    ey.build(P.py - bra.ay(), P.py - bra.by(), P.hp);
+                    ez.build(P.pz - bra.az(), P.pz - bra.bz(), P.hp);
+#pragma unroll
+                    for (int t = 0; t < TKT; ++t) {
+                        if (Qt[t].kp != 0.0) {
+                            quartet(P, ex, ey, ez, Qt[t], [&](int i, double v) {
+#pragma unroll
+                                for (int mcd = 0; mcd < MC * MD; ++mcd) {
+                                    const double vc = wcd[t][mcd] * v;
+#pragma unroll
+                                    for (int mab = 0; mab < MA * MB; ++mab) out[(mab * (MC * MD) + mcd) * NC + i] += wab[mab] * vc;
+                                }
+                            });
+                        }
+                    }
+                }
+            }
+        }
+    } else if constexpr (TK > 1) {
         const int nkl = ket.npairs();
         int kc = 0, kd = 0;
         for (int kl0 = 0; kl0 < nkl; kl0 += TK) {
@@ -495,7 +586,7 @@ MQC_HD void eri_cart_block_src(const Bra& bra, const Ket& ket, const double* __r
                     ez.build(P.pz - bra.az(), P.pz - bra.bz(), P.hp);
 #pragma unroll
                     for (int t = 0; t < TK; ++t) {
-                        if (Qt[t].kp != 0.0) quartet(P, ex, ey, ez, Qt[t]);
+                        if (Qt[t].kp != 0.0) quartet(P, ex, ey, ez, Qt[t], plain);
                     }
                 }
             }
@@ -518,7 +609,7 @@ MQC_HD void eri_cart_block_src(const Bra& bra, const Ket& ket, const double* __r
                     if (++kd == ket.npb()) { kd = 0; ++kc; }
                     if (kl + 1 < nkl) Qn = ket.get(kc, kd);
                     if (Qp.kp == 0.0) continue;
-                    quartet(P, ex, ey, ez, Qp);
+                    quartet(P, ex, ey, ez, Qp, plain);
                 }
             }
         }
@@ -531,6 +622,28 @@ MQC_HD void eri_cart_block(const ShellRef& A, const ShellRef& B, const ShellRef&
 {
     const PairFly bra(A, B), ket(C, D);
     eri_cart_block_src<LA, LB, LC, LD>(bra, ket, boys_table, out);
+}
+
+// Twin block: out[combo][NC] with combo = ((ma*MB + mb)*MC + mc)*MD + md over the member multiplicities
+// (2 on s positions, 1 elsewhere); A..D are the FIRST members, tw carries both coefficient columns.
+constexpr bool eri_has_twin_block(int la, int lb, int lc, int ld)
+{
+    // The block routine covers every class of at most 27 Cartesian components with an s position; the engine
+    // uses it where it measured faster than the segmented kernels on MI355X -- (ss|ss) and (ps|ss), where the
+    // extra accumulator sets are few.  With more components the NCOMB x NC accumulate per primitive quartet and
+    // the register pressure (one wave per SIMD) cancel the saved primitive work.
+    return la <= 1 && lb == 0 && lc == 0 && ld == 0;
+}
+constexpr int eri_twin_combos(int la, int lb, int lc, int ld)
+{
+    return twin_mult(true, la) * twin_mult(true, lb) * twin_mult(true, lc) * twin_mult(true, ld);
+}
+template <int LA, int LB, int LC, int LD>
+MQC_HD void eri_cart_block_twin(const ShellRef& A, const ShellRef& B, const ShellRef& C, const ShellRef& D, const TwinCoefs& tw,
+                                const double* __restrict__ boys_table, double* out)
+{
+    const PairFlyRaw bra(A, B), ket(C, D);
+    eri_cart_block_src<LA, LB, LC, LD, PairFlyRaw, PairFlyRaw, TwinCoefs>(bra, ket, boys_table, out, tw);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -3,7 +3,11 @@
 // the arithmetic the gfx950 kernels instantiate against the oracle here, without a GPU.
 // It is never linked into libmqc_hip.so and is not a fallback path of the product.
 #include "../../metalquicha_amd/csrc/md_integrals.hpp"
+#include "../../metalquicha_amd/csrc/engine.hpp"
 #include <vector>
+#include <set>
+#include <array>
+#include <algorithm>
 #include <cstring>
 
 namespace mqc {
@@ -62,6 +66,40 @@ static void run_class_passes(const ShellRef* sh, double* out_sph)
     eri_passes_from<LA, LB, LC, LD, CH, 0>(sh[0], sh[1], sh[2], sh[3], g_boys.data(), g_c2s.data(), acc.data(), 1, sink);
 }
 
+// twin block vs the plain block of every member combination (Cartesian, before c2s): returns max |diff|
+template <int LA, int LB, int LC, int LD>
+static double run_twin(const ShellRef* sh, const double* const* second, const bool* is_twin)
+{
+    constexpr int NC = ncart(LA) * ncart(LB) * ncart(LC) * ncart(LD);
+    constexpr int MA = twin_mult(true, LA), MB = twin_mult(true, LB), MC = twin_mult(true, LC), MD = twin_mult(true, LD);
+    std::vector<double> acc(MA * MB * MC * MD * NC), ref(NC);
+    TwinCoefs tw;
+    tw.ca[0] = sh[0].coefs; tw.ca[1] = second[0]; tw.fa = is_twin[0] ? 1.0 : 0.0;
+    tw.cb[0] = sh[1].coefs; tw.cb[1] = second[1]; tw.fb = is_twin[1] ? 1.0 : 0.0;
+    tw.cc[0] = sh[2].coefs; tw.cc[1] = second[2]; tw.fc = is_twin[2] ? 1.0 : 0.0;
+    tw.cd[0] = sh[3].coefs; tw.cd[1] = second[3]; tw.fd = is_twin[3] ? 1.0 : 0.0;
+    eri_cart_block_twin<LA, LB, LC, LD>(sh[0], sh[1], sh[2], sh[3], tw, g_boys.data(), acc.data());
+    double worst = 0.0;
+    const int M[4] = {MA, MB, MC, MD};
+    for (int ma = 0; ma < MA; ++ma) for (int mb = 0; mb < MB; ++mb) for (int mc = 0; mc < MC; ++mc) for (int md = 0; md < MD; ++md) {
+        const int m[4] = {ma, mb, mc, md};
+        ShellRef t[4];
+        bool absent = false;
+        for (int k = 0; k < 4; ++k) {
+            t[k] = sh[k];
+            if (m[k]) { if (!is_twin[k]) absent = true; else t[k].coefs = second[k]; }
+        }
+        (void)M;
+        const double* got = acc.data() + (((ma * MB + mb) * MC + mc) * MD + md) * NC;
+        if (absent) { for (int i = 0; i < NC; ++i) worst = std::max(worst, std::fabs(got[i])); continue; }
+        eri_cart_block<LA, LB, LC, LD>(t[0], t[1], t[2], t[3], g_boys.data(), ref.data());
+        double scale = 1.0;
+        for (int i = 0; i < NC; ++i) scale = std::max(scale, std::fabs(ref[i]));
+        for (int i = 0; i < NC; ++i) worst = std::max(worst, std::fabs(got[i] - ref[i]) / scale);
+    }
+    return worst;
+}
+
 extern "C" {
 
 // shells: for each of the 4 shells: nprim, then pointers are passed flat.
@@ -107,6 +145,65 @@ int hostcheck_eri_block_passes(const int* l, const int* nprim, const double* exp
         PCASE(2, 2, 0, 0) PCASE(2, 2, 1, 0) PCASE(2, 2, 1, 1) PCASE(2, 2, 2, 0) PCASE(2, 2, 2, 1) PCASE(2, 2, 2, 2)
     }
     return 1;
+}
+
+// coefs2: second coefficient column for each shell (same layout as coefs); twin[k] != 0 marks twin positions
+int hostcheck_eri_twin(const int* l, const int* nprim, const double* exps, const double* coefs, const double* coefs2,
+                       const int* twin, const double* xyz, double* worst)
+{
+    ensure_tables();
+    ShellRef sh[4];
+    const double* second[4];
+    bool tw[4];
+    int off = 0;
+    for (int k = 0; k < 4; ++k) {
+        sh[k].nprim = nprim[k]; sh[k].exps = exps + off; sh[k].coefs = coefs + off; second[k] = coefs2 + off;
+        sh[k].x = xyz[3 * k]; sh[k].y = xyz[3 * k + 1]; sh[k].z = xyz[3 * k + 2];
+        tw[k] = twin[k] != 0 && l[k] == 0;
+        off += nprim[k];
+    }
+    const int id = ((l[0] * 8 + l[1]) * 8 + l[2]) * 8 + l[3];
+#define TCASE(a, b, c, d) case (((a * 8 + b) * 8 + c) * 8 + d): *worst = run_twin<a, b, c, d>(sh, second, tw); return 0;
+    switch (id) {
+        TCASE(0, 0, 0, 0) TCASE(1, 0, 0, 0) TCASE(1, 0, 1, 0) TCASE(1, 1, 0, 0)
+        TCASE(1, 1, 1, 0) TCASE(2, 0, 0, 0) TCASE(2, 0, 1, 0) TCASE(2, 1, 0, 0)
+    }
+    return 1;
+}
+
+// Twin cut of the topology: entries expanded over their members + rest == the canonical quartet set, per class.
+int hostcheck_twin_cut(const mqc_hip_molecule_t* mol, const mqc_hip_basis_t* bas, int* n_twin_first, int* n_twin_entries, int* n_bad)
+{
+    Topology topo;
+    std::string err;
+    if (build_topology(*mol, *bas, topo, err, KERNEL_LMAX, true) != MQC_HIP_OK) return 1;
+    auto key = [](int a, int b, int c, int d) {
+        if (a < b) std::swap(a, b);
+        if (c < d) std::swap(c, d);
+        if (std::make_pair(a, b) < std::make_pair(c, d)) { std::swap(a, c); std::swap(b, d); }
+        return std::array<int, 4>{a, b, c, d};
+    };
+    *n_twin_first = 0; *n_twin_entries = 0; *n_bad = 0;
+    for (int t : topo.twin_first) *n_twin_first += t;
+    for (auto& cl : topo.classes) {
+        std::set<std::array<int, 4>> full, cut;
+        for (size_t q = 0; q + 3 < cl.quartets.size(); q += 4) full.insert(key(cl.quartets[q], cl.quartets[q + 1], cl.quartets[q + 2], cl.quartets[q + 3]));
+        if (cl.twin_entries.empty()) { if (!cl.rest.empty()) ++*n_bad; continue; }
+        for (size_t q = 0; q + 3 < cl.rest.size(); q += 4) {
+            if (!cut.insert(key(cl.rest[q], cl.rest[q + 1], cl.rest[q + 2], cl.rest[q + 3])).second) ++*n_bad;   // duplicate
+        }
+        for (size_t q = 0; q + 3 < cl.twin_entries.size(); q += 4) {
+            ++*n_twin_entries;
+            int sh[4], m[4];
+            for (int k = 0; k < 4; ++k) { sh[k] = cl.twin_entries[q + k] & 0xffff; m[k] = (cl.twin_entries[q + k] >> 16) ? 2 : 1; }
+            std::set<std::array<int, 4>> mine;
+            for (int a = 0; a < m[0]; ++a) for (int b = 0; b < m[1]; ++b) for (int c = 0; c < m[2]; ++c) for (int d = 0; d < m[3]; ++d)
+                mine.insert(key(sh[0] + a, sh[1] + b, sh[2] + c, sh[3] + d));
+            for (auto& k4 : mine) if (!cut.insert(k4).second) ++*n_bad;     // covered twice
+        }
+        if (cut != full) ++*n_bad;
+    }
+    return 0;
 }
 
 void hostcheck_boys(int L, double T, double* F)

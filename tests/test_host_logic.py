@@ -118,6 +118,49 @@ def test_device_eri_class_matches_oracle(hostcheck, cls):
     assert np.max(np.abs(out.reshape(ref.shape) - ref)) < 1e-13 * max(1.0, np.max(np.abs(ref)))
 
 
+TWIN_CLASSES = [(0, 0, 0, 0), (1, 0, 0, 0), (1, 0, 1, 0), (1, 1, 0, 0), (1, 1, 1, 0), (2, 0, 0, 0), (2, 0, 1, 0), (2, 1, 0, 0)]
+
+
+@pytest.mark.parametrize("cls", TWIN_CLASSES)
+def test_device_twin_block_equals_segmented_blocks(hostcheck, cls):
+    """Twin s shells (two contractions over the same primitives): one pass over the primitive quartets must
+    give exactly the blocks the segmented routine gives member by member; absent members stay zero."""
+    dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
+    rng = np.random.default_rng(100 + sum(c * 5 ** k for k, c in enumerate(cls)))
+    l = np.array(cls, dtype=np.int32)
+    for trial in range(3):
+        nprim = rng.integers(1, 6, size=4).astype(np.int32)
+        n = int(nprim.sum())
+        exps = rng.uniform(0.2, 6.0, size=n)
+        c1, c2 = rng.uniform(-1, 1, size=n), rng.uniform(-1, 1, size=n)
+        twin = (rng.integers(0, 2, size=4) if trial else np.ones(4)).astype(np.int32)
+        xyz = rng.uniform(-1.5, 1.5, size=(4, 3))
+        worst = ctypes.c_double(-1.0)
+        rc = hostcheck.hostcheck_eri_twin(l.ctypes.data_as(ip), nprim.ctypes.data_as(ip), exps.ctypes.data_as(dp),
+                                          c1.ctypes.data_as(dp), c2.ctypes.data_as(dp), twin.ctypes.data_as(ip),
+                                          np.ascontiguousarray(xyz).ctypes.data_as(dp), ctypes.byref(worst))
+        assert rc == 0
+        assert 0.0 <= worst.value < 1e-13, (cls, trial, worst.value)
+
+
+@pytest.mark.parametrize("zs,basis,expect_twins", [([8, 1, 1], "cc-pvdz", 1), ([8, 1, 1, 8, 1, 1], "cc-pvdz", 2),
+                                                  ([6, 7, 8, 1], "cc-pvdz", 3), ([8, 1, 1], "sto-3g", 0)])
+def test_topology_twin_cut_covers_every_quartet_once(hostcheck, zs, basis, expect_twins):
+    """cc-pVDZ C/N/O: the 1s/2s functions are twins (same 9 primitives).  Twin entries expanded over their
+    members plus the uncovered rest must be exactly the canonical quartet set of each class, nothing twice."""
+    from metalquicha_amd import stages
+    from tests.helpers import fragment_bohr
+    rng = np.random.default_rng(3)
+    frag = fragment_bohr(zs, rng.uniform(-3, 3, size=(len(zs), 3)))
+    m = stages._marshal(basis, frag)
+    ntw, nent, nbad = ctypes.c_int(-1), ctypes.c_int(-1), ctypes.c_int(-1)
+    rc = hostcheck.hostcheck_twin_cut(ctypes.byref(m.mol), ctypes.byref(m.bas), ctypes.byref(ntw), ctypes.byref(nent), ctypes.byref(nbad))
+    assert rc == 0
+    assert ntw.value == expect_twins
+    assert nbad.value == 0
+    assert (nent.value > 0) == (expect_twins > 0)
+
+
 # ---- MBE assembly ----------------------------------------------------------------------------
 def test_mbe_term_list_and_coefficients():
     system = mbe.water_cluster(2)
