@@ -340,7 +340,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         HIP_CHECK_RET(hipEventRecord(sl.q0, s));
         if (use_df) launch_df_build(bv, topo, *aux, s);
         else if (use_direct) launch_direct_setup(bv, topo, s);
-        else launch_eri(bv, topo, stol, s);
+        else launch_eri(bv, topo, stol, s, job.hx.data());
         HIP_CHECK_RET(hipEventRecord(sl.q1, s));
         if ((rc = stage_check("two-electron setup")) != MQC_HIP_OK) return rc;
         ctx->stats.eri_quartets += topo.n_quartets * nf;

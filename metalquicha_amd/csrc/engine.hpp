@@ -48,7 +48,10 @@ struct Topology {
         //   twin_entries -- 4 ints each, FIRST member shells, bit 16 set on twin positions;
         //   rest         -- the quartets no twin entry covers.  Both empty when the class has no twin block.
         std::vector<int> twin_entries, rest;
+        // per entry of the three lists: index into Topology::atom_sets (the atoms its four shells sit on)
+        std::vector<int> set_quartets, set_twin, set_rest;
     };
+    std::vector<std::vector<int>> atom_sets;   // distinct sorted atom sets (1..4 atoms) met by the quartets
     std::vector<int> twin_first;     // per shell: 1 when the shell and its successor form a twin s pair
     std::vector<ClassList> classes;
     std::vector<int> pairs;          // (A,B) with A>=B, 2 ints each, for the 1e kernel (la>=lb ordering)
@@ -177,7 +180,8 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
 
 // kernel launchers (kern_*.hip)
 void launch_int1e(const BatchView& bv, const Topology& topo, hipStream_t s);
-void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, hipStream_t s);
+// host_xyz (optional, [nfrag][natoms][3] as uploaded): enables block sharing between fragments with identical atoms
+void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, hipStream_t s, const double* host_xyz = nullptr);
 void launch_jk_incore(const BatchView& bv, bool only_active, hipStream_t s);
 void launch_direct_setup(const BatchView& bv, const Topology& topo, hipStream_t s);
 void launch_jk_direct(const BatchView& bv, const Topology& topo, double thresh, bool only_active, hipStream_t s);

@@ -129,13 +129,16 @@ __global__ void __launch_bounds__(64) schwarz_kernel(BatchView bv, const int* __
 // ---------------------------------------------------------------------------------------
 template <int LA, int LB, int LC, int LD>
 __global__ void __launch_bounds__(64) eri_kernel(BatchView bv, const int* __restrict__ quartets, int nquart,
+                                                 const int* __restrict__ tasks, int ntasks,
                                                  const double* __restrict__ Q, double thresh)
 {
+    // thread -> (list entry, fragment): the dense product, or an explicit task list (entries whose blocks
+    // are shared by several fragments of the batch are formed for one representative only)
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)nquart * bv.nfrag;
+    const long total = tasks ? (long)ntasks : (long)nquart * bv.nfrag;
     const bool live = tid < total;
     const long t = live ? tid : total - 1;
-    const int iq = (int)(t / bv.nfrag), f = (int)(t % bv.nfrag);
+    const int iq = tasks ? tasks[2 * t] : (int)(t / bv.nfrag), f = tasks ? tasks[2 * t + 1] : (int)(t % bv.nfrag);
     const int A = quartets[4 * iq], B = quartets[4 * iq + 1], C = quartets[4 * iq + 2], D = quartets[4 * iq + 3];
     const TopologyDev& tp = bv.topo;
     const int ns = tp.nshell;
@@ -204,12 +207,13 @@ __global__ void __launch_bounds__(64) eri_kernel(BatchView bv, const int* __rest
 constexpr int TWIN_FLAG = 1 << 16;
 
 template <int LA, int LB, int LC, int LD>
-__global__ void __launch_bounds__(64) eri_twin_kernel(BatchView bv, const int* __restrict__ quartets, int nquart)
+__global__ void __launch_bounds__(64) eri_twin_kernel(BatchView bv, const int* __restrict__ quartets, int nquart,
+                                                      const int* __restrict__ tasks, int ntasks)
 {
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)nquart * bv.nfrag;
+    const long total = tasks ? (long)ntasks : (long)nquart * bv.nfrag;
     if (tid >= total) return;
-    const int iq = (int)(tid / bv.nfrag), f = (int)(tid % bv.nfrag);
+    const int iq = tasks ? tasks[2 * tid] : (int)(tid / bv.nfrag), f = tasks ? tasks[2 * tid + 1] : (int)(tid % bv.nfrag);
     const int eA = quartets[4 * iq], eB = quartets[4 * iq + 1], eC = quartets[4 * iq + 2], eD = quartets[4 * iq + 3];
     const int A = eA & (TWIN_FLAG - 1), B = eB & (TWIN_FLAG - 1), C = eC & (TWIN_FLAG - 1), D = eD & (TWIN_FLAG - 1);
     const bool tA = (eA & TWIN_FLAG) != 0, tB = (eB & TWIN_FLAG) != 0, tC = (eC & TWIN_FLAG) != 0, tD = (eD & TWIN_FLAG) != 0;
@@ -289,14 +293,15 @@ struct TensorSink {
 
 template <int LA, int LB, int LC, int LD>
 __global__ void __launch_bounds__(64) eri_pass_kernel(BatchView bv, const int* __restrict__ quartets, int nquart,
+                                                      const int* __restrict__ tasks, int ntasks,
                                                       const double* __restrict__ Q, double thresh)
 {
     extern __shared__ double lds[];
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)nquart * bv.nfrag;
+    const long total = tasks ? (long)ntasks : (long)nquart * bv.nfrag;
     const bool live = tid < total;
     const long t = live ? tid : total - 1;
-    const int iq = (int)(t / bv.nfrag), f = (int)(t % bv.nfrag);
+    const int iq = tasks ? tasks[2 * t] : (int)(t / bv.nfrag), f = tasks ? tasks[2 * t + 1] : (int)(t % bv.nfrag);
     const int A = quartets[4 * iq], B = quartets[4 * iq + 1], C = quartets[4 * iq + 2], D = quartets[4 * iq + 3];
     const TopologyDev& tp = bv.topo;
     const int ns = tp.nshell;
@@ -471,32 +476,31 @@ void launch_eri_digest_class(const BatchView& bv, const int* d_list, int nq, con
 // ---------------------------------------------------------------------------------------
 // Launchers: one explicit instantiation per class, spread over several translation units
 // (kern_eri_inst.hip compiled with -DERI_GROUP=k) so that the classes compile in parallel.
+// d_list: entries already on the device; d_tasks (optional): (entry, fragment) pairs replacing the dense product
 template <int LA, int LB, int LC, int LD>
-void launch_eri_class(const BatchView& bv, const int* quartets_host, int nq, int* d_list,
+void launch_eri_class(const BatchView& bv, const int* d_list, int nq, const int* d_tasks, int ntasks,
                       const double* Q, double thresh, hipStream_t s)
 {
-    if (nq == 0) return;
-    (void)hipMemcpyAsync(d_list, quartets_host, (size_t)nq * 4 * sizeof(int), hipMemcpyHostToDevice, s);
-    const long total = (long)nq * bv.nfrag;
+    const long total = d_tasks ? (long)ntasks : (long)nq * bv.nfrag;
+    if (nq == 0 || total == 0) return;
     const int blocks = (int)((total + 63) / 64);
     if constexpr (eri_uses_passes(LA, LB, LC, LD)) {
         constexpr int CH = eri_pass_chunk(LA, LB, LC, LD);
         const size_t lds = sizeof(double) * 64 * ncart(LA) * ncart(LB) * CH;
         auto kern = eri_pass_kernel<LA, LB, LC, LD>;
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, s, bv, d_list, nq, Q, thresh);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, s, bv, d_list, nq, d_tasks, ntasks, Q, thresh);
     } else {
-        hipLaunchKernelGGL((eri_kernel<LA, LB, LC, LD>), dim3(blocks), dim3(64), 0, s, bv, d_list, nq, Q, thresh);
+        hipLaunchKernelGGL((eri_kernel<LA, LB, LC, LD>), dim3(blocks), dim3(64), 0, s, bv, d_list, nq, d_tasks, ntasks, Q, thresh);
     }
 }
 
 template <int LA, int LB, int LC, int LD>
-void launch_eri_twin_class(const BatchView& bv, const int* entries_host, int nq, int* d_list, hipStream_t s)
+void launch_eri_twin_class(const BatchView& bv, const int* d_list, int nq, const int* d_tasks, int ntasks, hipStream_t s)
 {
-    if (nq == 0) return;
-    (void)hipMemcpyAsync(d_list, entries_host, (size_t)nq * 4 * sizeof(int), hipMemcpyHostToDevice, s);
-    const long total = (long)nq * bv.nfrag;
-    hipLaunchKernelGGL((eri_twin_kernel<LA, LB, LC, LD>), dim3((int)((total + 63) / 64)), dim3(64), 0, s, bv, d_list, nq);
+    const long total = d_tasks ? (long)ntasks : (long)nq * bv.nfrag;
+    if (nq == 0 || total == 0) return;
+    hipLaunchKernelGGL((eri_twin_kernel<LA, LB, LC, LD>), dim3((int)((total + 63) / 64)), dim3(64), 0, s, bv, d_list, nq, d_tasks, ntasks);
 }
 
 template <int LA, int LB>

@@ -291,6 +291,27 @@ int build_topology(const mqc_hip_molecule_t& mol, const mqc_hip_basis_t& bas, To
         }
         topo.classes.push_back(std::move(cl));
     }
+    // atom set of every list entry (block sharing between fragments of a batch, kern_eri.hip)
+    {
+        std::map<std::vector<int>, int> ids;
+        auto set_of = [&](const int* e) {
+            std::vector<int> a(4);
+            for (int k = 0; k < 4; ++k) a[k] = topo.shells[e[k] & 0xffff].atom;
+            std::sort(a.begin(), a.end());
+            a.erase(std::unique(a.begin(), a.end()), a.end());
+            auto it = ids.find(a);
+            if (it != ids.end()) return it->second;
+            const int id = (int)topo.atom_sets.size();
+            ids.emplace(a, id);
+            topo.atom_sets.push_back(a);
+            return id;
+        };
+        for (auto& cl : topo.classes) {
+            for (size_t q = 0; q + 3 < cl.quartets.size(); q += 4) cl.set_quartets.push_back(set_of(&cl.quartets[q]));
+            for (size_t q = 0; q + 3 < cl.twin_entries.size(); q += 4) cl.set_twin.push_back(set_of(&cl.twin_entries[q]));
+            for (size_t q = 0; q + 3 < cl.rest.size(); q += 4) cl.set_rest.push_back(set_of(&cl.rest[q]));
+        }
+    }
     return MQC_HIP_OK;
 }
 

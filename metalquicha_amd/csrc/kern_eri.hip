@@ -1,11 +1,17 @@
 // kern_eri.hip -- dispatcher of the four-centre ERI formation (kernels: eri_kernels.hpp,
 // instantiated per class group in kern_eri_inst.hip).
 #include "eri_kernels.hpp"
+#include <array>
+#include <cstring>
+#include <map>
+#include <unordered_map>
+#include <functional>
+#include <string>
 
 namespace mqc {
 
 #define ERI_DECL(a, b, c, d) \
-    extern template void launch_eri_class<a, b, c, d>(const BatchView&, const int*, int, int*, const double*, double, hipStream_t);
+    extern template void launch_eri_class<a, b, c, d>(const BatchView&, const int*, int, const int*, int, const double*, double, hipStream_t);
 #define SCHWARZ_DECL(a, b) \
     extern template void launch_schwarz_class<a, b>(const BatchView&, const int*, int, int*, double*, hipStream_t);
 ERI_DECL(0, 0, 0, 0) ERI_DECL(1, 0, 0, 0) ERI_DECL(1, 0, 1, 0) ERI_DECL(1, 1, 0, 0) ERI_DECL(1, 1, 1, 0) ERI_DECL(1, 1, 1, 1)
@@ -13,7 +19,7 @@ ERI_DECL(2, 0, 0, 0) ERI_DECL(2, 0, 1, 0) ERI_DECL(2, 0, 1, 1) ERI_DECL(2, 0, 2,
 ERI_DECL(2, 1, 0, 0) ERI_DECL(2, 1, 1, 0) ERI_DECL(2, 1, 1, 1) ERI_DECL(2, 1, 2, 0) ERI_DECL(2, 1, 2, 1)
 ERI_DECL(2, 2, 0, 0) ERI_DECL(2, 2, 1, 0) ERI_DECL(2, 2, 1, 1) ERI_DECL(2, 2, 2, 0) ERI_DECL(2, 2, 2, 1) ERI_DECL(2, 2, 2, 2)
 #define TWIN_DECL(a, b, c, d) \
-    extern template void launch_eri_twin_class<a, b, c, d>(const BatchView&, const int*, int, int*, hipStream_t);
+    extern template void launch_eri_twin_class<a, b, c, d>(const BatchView&, const int*, int, const int*, int, hipStream_t);
 TWIN_DECL(0, 0, 0, 0) TWIN_DECL(1, 0, 0, 0) TWIN_DECL(1, 0, 1, 0) TWIN_DECL(1, 1, 0, 0)
 TWIN_DECL(1, 1, 1, 0) TWIN_DECL(2, 0, 0, 0) TWIN_DECL(2, 0, 1, 0) TWIN_DECL(2, 1, 0, 0)
 SCHWARZ_DECL(0, 0) SCHWARZ_DECL(1, 0) SCHWARZ_DECL(1, 1) SCHWARZ_DECL(2, 0) SCHWARZ_DECL(2, 1) SCHWARZ_DECL(2, 2)
@@ -25,10 +31,6 @@ DIG_DECL(2, 0, 0, 0) DIG_DECL(2, 0, 1, 0) DIG_DECL(2, 0, 1, 1) DIG_DECL(2, 0, 2,
 DIG_DECL(2, 1, 0, 0) DIG_DECL(2, 1, 1, 0) DIG_DECL(2, 1, 1, 1) DIG_DECL(2, 1, 2, 0) DIG_DECL(2, 1, 2, 1)
 DIG_DECL(2, 2, 0, 0) DIG_DECL(2, 2, 1, 0) DIG_DECL(2, 2, 1, 1) DIG_DECL(2, 2, 2, 0) DIG_DECL(2, 2, 2, 1) DIG_DECL(2, 2, 2, 2)
 
-#define ERI_CASE(a, b, c, d)                                                                          \
-    if (cl.la == a && cl.lb == b && cl.lc == c && cl.ld == d)                                         \
-        launch_eri_class<a, b, c, d>(bv, cl.quartets.data(), (int)cl.quartets.size() / 4, d_list + off, Q, thresh, s);
-
 // MQC_HIP_NO_TWIN_BLOCKS=1 forces the segmented treatment everywhere (A/B measurements, tests)
 static bool twin_blocks_disabled()
 {
@@ -36,25 +38,188 @@ static bool twin_blocks_disabled()
     return off;
 }
 
-void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, hipStream_t s)
+// MQC_HIP_NO_BLOCK_SHARING=1: every fragment forms all of its own integral blocks
+static bool block_sharing_disabled()
 {
-    static DevicePool lists_slot[2], qpool_slot[2];
-    DevicePool& lists = lists_slot[bv.slot & 1];
+    static const bool off = [] { const char* e = std::getenv("MQC_HIP_NO_BLOCK_SHARING"); return e && e[0] == '1'; }();
+    return off;
+}
+
+// ---------------------------------------------------------------------------------------
+// Block sharing.  Fragments of one batch often contain the same atoms at the same coordinates (every
+// dimer of an MBE job repeats its two monomers bit for bit).  An integral block depends only on the atoms
+// its four shells sit on, so entries whose atom set is repeated are formed for ONE representative
+// fragment per distinct geometry of that set (task-list launch) and copied to the other fragments by
+// this kernel.  It walks tensor rows: element (r, c) belongs to the atom set (atoms of AO pair r) U
+// (atoms of AO pair c); pp_row[apair(r)][apair(c)] is that set's row in the representative table or -1.
+// Threads run along c, so the reads and writes are contiguous; rows that can never be shared exit early.
+__global__ void __launch_bounds__(256) eri_broadcast_kernel(BatchView bv, const int* __restrict__ pair_apair /*[npair]*/,
+                                                            const int* __restrict__ pp_row /*[nap][nap]*/, int nap,
+                                                            const unsigned char* __restrict__ apair_any /*[nap]*/,
+                                                            const int* __restrict__ rep_table)
+{
+    const int f = blockIdx.y, r = blockIdx.x;
+    const int np = bv.npair;
+    const int ar = pair_apair[r];
+    if (!apair_any[ar]) return;
+    const int* __restrict__ prow = pp_row + (size_t)ar * nap;
+    double* __restrict__ dst = bv.eri + ((size_t)f * np + r) * np;
+    for (int c = threadIdx.x; c < np; c += blockDim.x) {
+        const int row = prow[pair_apair[c]];
+        if (row < 0) continue;
+        const int rep = rep_table[(size_t)row * bv.nfrag + f];
+        if (rep != f) dst[c] = bv.eri[((size_t)rep * np + r) * np + c];
+    }
+}
+
+namespace {
+struct CoordKey {
+    uint64_t w[3];
+    bool operator==(const CoordKey& o) const { return w[0] == o.w[0] && w[1] == o.w[1] && w[2] == o.w[2]; }
+};
+struct CoordHash {
+    size_t operator()(const CoordKey& k) const { return (size_t)(k.w[0] * 0x9E3779B97F4A7C15ull ^ (k.w[1] + 0x7F4A7C15ull) * 0xC2B2AE3D27D4EB4Full ^ k.w[2] * 0x165667B19E3779F9ull); }
+};
+struct SharePlan {
+    bool on = false;
+    std::vector<int> shared_row;             // per atom set: row in rep_table, or -1 when the set is not shared
+    std::vector<std::vector<int>> uniq;      // per atom set: representative fragments
+    std::vector<int> rep_table;              // [rows][nfrag]
+    std::vector<int> pp_row;                 // [nap][nap]: shared row of (atom pair of the bra) U (atom pair of the ket)
+    std::vector<int> apair_any;              // [nap] packed as ints: 1 when some ket makes a shared set with this bra pair
+    int nap = 0;
+};
+}  // namespace
+
+static inline int apair_index(int a, int b) { return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; }
+
+// which atom sets repeat across the batch (exact, bitwise coordinate equality)
+static void plan_sharing(const Topology& topo, const double* host_xyz, int nfrag, SharePlan& plan)
+{
+    const int na = topo.natoms, nsets = (int)topo.atom_sets.size();
+    if (!host_xyz || nfrag < 16 || nfrag > 65535 || na > 12 || nsets == 0) return;
+    // per atom slot: small integer id of the coordinate triple (first fragment that shows it)
+    std::vector<uint16_t> aid((size_t)nfrag * na);
+    {
+        std::vector<std::pair<CoordKey, int>> v(nfrag);
+        for (int a = 0; a < na; ++a) {
+            for (int f = 0; f < nfrag; ++f) {
+                std::memcpy(v[f].first.w, host_xyz + ((size_t)f * na + a) * 3, sizeof(CoordKey));
+                v[f].second = f;
+            }
+            std::sort(v.begin(), v.end(), [](const auto& x, const auto& y) {
+                if (x.first.w[0] != y.first.w[0]) return x.first.w[0] < y.first.w[0];
+                if (x.first.w[1] != y.first.w[1]) return x.first.w[1] < y.first.w[1];
+                if (x.first.w[2] != y.first.w[2]) return x.first.w[2] < y.first.w[2];
+                return x.second < y.second;
+            });
+            int head = 0;
+            for (int k = 0; k < nfrag; ++k) {
+                if (k > 0 && !(v[k].first == v[k - 1].first)) head = k;
+                aid[(size_t)v[k].second * na + a] = (uint16_t)v[head].second;     // run head = smallest fragment index
+            }
+        }
+    }
+    plan.shared_row.assign(nsets, -1);
+    plan.uniq.assign(nsets, {});
+    int rows = 0;
+    std::vector<std::pair<uint64_t, int>> keys(nfrag);
+    std::vector<int> rep(nfrag);
+    for (int sidx = 0; sidx < nsets; ++sidx) {
+        const auto& S = topo.atom_sets[sidx];
+        for (int f = 0; f < nfrag; ++f) {
+            uint64_t k = 0;
+            for (size_t i = 0; i < S.size(); ++i) k = (k << 16) | aid[(size_t)f * na + S[i]];
+            keys[f] = {k, f};
+        }
+        std::sort(keys.begin(), keys.end());
+        int nu = 0, head = 0;
+        for (int k = 0; k < nfrag; ++k) {
+            if (k == 0 || keys[k].first != keys[k - 1].first) { head = k; ++nu; }
+            rep[keys[k].second] = keys[head].second;
+        }
+        if ((size_t)nu * 2 > (size_t)nfrag) continue;      // too few repeats to pay for the copy
+        plan.shared_row[sidx] = rows++;
+        auto& uq = plan.uniq[sidx];
+        for (int f = 0; f < nfrag; ++f) if (rep[f] == f) uq.push_back(f);
+        plan.rep_table.insert(plan.rep_table.end(), rep.begin(), rep.end());
+    }
+    plan.on = rows > 0;
+    if (!plan.on) return;
+    // (bra atom pair, ket atom pair) -> shared row
+    plan.nap = na * (na + 1) / 2;
+    plan.pp_row.assign((size_t)plan.nap * plan.nap, -1);
+    plan.apair_any.assign(plan.nap, 0);
+    std::map<std::vector<int>, int> set_id;
+    for (int sidx = 0; sidx < nsets; ++sidx) set_id[topo.atom_sets[sidx]] = sidx;
+    for (int a = 0; a < na; ++a) for (int b = 0; b <= a; ++b)
+        for (int c = 0; c < na; ++c) for (int d = 0; d <= c; ++d) {
+            std::vector<int> u{a, b, c, d};
+            std::sort(u.begin(), u.end());
+            u.erase(std::unique(u.begin(), u.end()), u.end());
+            auto it = set_id.find(u);
+            if (it == set_id.end()) continue;
+            const int row = plan.shared_row[it->second];
+            if (row < 0) continue;
+            plan.pp_row[(size_t)apair_index(a, b) * plan.nap + apair_index(c, d)] = row;
+            plan.apair_any[apair_index(a, b)] = 1;
+        }
+}
+
+namespace {
+struct EriLaunch { int cls; bool twin; size_t dense_off; int dense_n; size_t sh_off; int sh_n; size_t task_off; int ntasks; };
+// Everything one launch_eri call uploads, kept per (topology, geometry set): an MBE driver that re-evaluates
+// the same fragments (geometry optimisation steps aside, every SCF restart does) skips planning and upload.
+struct EriListCache {
+    uint64_t key = 0;
+    bool valid = false;
+    DevicePool pool;
+    std::vector<int> host;
+    std::vector<EriLaunch> launches;
+    bool shared = false;
+    size_t pair_off = 0, pp_off = 0, any_off = 0, rep_off = 0;
+    int nap = 0;
+};
+constexpr int ERI_CACHE_WAYS = 4;
+constexpr int ERI_SIDE_STREAMS = 4;    // task-list launches of different classes are independent: round-robin
+struct EriSlotState {
+    EriListCache cache[ERI_CACHE_WAYS];
+    int next = 0;
+    hipStream_t side[ERI_SIDE_STREAMS] = {};
+    hipEvent_t fork = nullptr, join[ERI_SIDE_STREAMS] = {};
+};
+}  // namespace
+
+static uint64_t hash_words(const void* p, size_t bytes, uint64_t h)
+{
+    const uint64_t* w = (const uint64_t*)p;
+    for (size_t i = 0; i < bytes / 8; ++i) { h ^= w[i]; h *= 0x9E3779B97F4A7C15ull; h ^= h >> 29; }
+    return h;
+}
+
+void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, hipStream_t s, const double* host_xyz)
+{
+    static DevicePool qpool_slot[2], pairs_slot[2];
+    static EriSlotState state_slot[2];
     DevicePool& qpool = qpool_slot[bv.slot & 1];
-    // one device buffer for all class lists so that launches need no intermediate sync
-    size_t total_ints = 0;
-    for (auto& cl : topo.classes) total_ints += cl.quartets.size();
-    total_ints += topo.pairs.size();
-    int* d_list = (int*)lists.ensure((total_ints + 16) * sizeof(int));
+    EriSlotState& st = state_slot[bv.slot & 1];
+    if (!st.fork) {
+        (void)hipEventCreateWithFlags(&st.fork, hipEventDisableTiming);
+        for (int k = 0; k < ERI_SIDE_STREAMS; ++k) {
+            (void)hipStreamCreateWithFlags(&st.side[k], hipStreamNonBlocking);
+            (void)hipEventCreateWithFlags(&st.join[k], hipEventDisableTiming);
+        }
+    }
     const size_t np = (size_t)bv.npair;
     (void)hipMemsetAsync(bv.eri, 0, sizeof(double) * np * np * bv.nfrag, s);
 
     double* Q = nullptr;
     double thresh = 0.0;
-    size_t off = 0;
     if (schwarz_tol > 0.0) {
         Q = (double*)qpool.ensure(sizeof(double) * (size_t)bv.nfrag * topo.shells.size() * topo.shells.size());
         thresh = schwarz_tol;
+        int* d_pairs = (int*)pairs_slot[bv.slot & 1].ensure((topo.pairs.size() + 16) * sizeof(int));
+        size_t off = 0;
         std::vector<int> bucket[KERNEL_LMAX + 1][KERNEL_LMAX + 1];
         for (size_t k = 0; k + 1 < topo.pairs.size(); k += 2) {
             int A = topo.pairs[k], B = topo.pairs[k + 1];
@@ -63,27 +228,113 @@ void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, h
             bk.push_back(A); bk.push_back(B);
         }
 #define SCHWARZ_CASE(a, b)                                                                                   \
-    launch_schwarz_class<a, b>(bv, bucket[a][b].data(), (int)bucket[a][b].size() / 2, d_list + off, Q, s);   \
+    launch_schwarz_class<a, b>(bv, bucket[a][b].data(), (int)bucket[a][b].size() / 2, d_pairs + off, Q, s);   \
     off += bucket[a][b].size();
         SCHWARZ_CASE(0, 0) SCHWARZ_CASE(1, 0) SCHWARZ_CASE(1, 1)
         SCHWARZ_CASE(2, 0) SCHWARZ_CASE(2, 1) SCHWARZ_CASE(2, 2)
 #undef SCHWARZ_CASE
         (void)hipStreamSynchronize(s);     // the bucket vectors go out of scope
     }
-    // twin-shell cut (exact ERIs without Schwarz screening): twin entries first, then the uncovered rest
+
+    // twin-shell cut and block sharing apply to the unscreened build only
     const bool twins = (schwarz_tol <= 0.0) && !twin_blocks_disabled();
-    for (auto& cl : topo.classes) {
-        if (twins && !cl.twin_entries.empty()) {
-            const int nt = (int)cl.twin_entries.size() / 4, nr = (int)cl.rest.size() / 4;
-#define TWIN_CASE(a, b, c, d)                                                                          \
-    if (cl.la == a && cl.lb == b && cl.lc == c && cl.ld == d) {                                         \
-        launch_eri_twin_class<a, b, c, d>(bv, cl.twin_entries.data(), nt, d_list + off, s);             \
-        launch_eri_class<a, b, c, d>(bv, cl.rest.data(), nr, d_list + off + cl.twin_entries.size(), nullptr, 0.0, s); \
+    const bool may_share = schwarz_tol <= 0.0 && !block_sharing_disabled() && host_xyz != nullptr;
+
+    // ---- list cache lookup: key = topology, fragment count, switches, every coordinate bit
+    uint64_t key = (uint64_t)std::hash<std::string>{}(topo.key) ^ 0x243F6A8885A308D3ull;
+    key = hash_words(&key, 8, (uint64_t)bv.nfrag * 0x100000001B3ull + (twins ? 1 : 0) + (may_share ? 2 : 0) + topo.key.size() * 8 + topo.nao * 131071ull);
+    if (may_share) key = hash_words(host_xyz, sizeof(double) * (size_t)bv.nfrag * topo.natoms * 3, key);
+    EriListCache* cc = nullptr;
+    for (auto& c : st.cache) if (c.valid && c.key == key) cc = &c;
+    if (!cc) {
+        cc = &st.cache[st.next];
+        st.next = (st.next + 1) % ERI_CACHE_WAYS;
+        cc->valid = false;
+        SharePlan plan;
+        if (may_share) plan_sharing(topo, host_xyz, bv.nfrag, plan);
+        // stage every list of this call in ONE host buffer: per launch (dense entries | shared entries + tasks)
+        std::vector<int>& hb = cc->host;
+        hb.clear();
+        cc->launches.clear();
+        auto stage = [&](int ci, bool twin, const std::vector<int>& ents, const std::vector<int>& sets) {
+            EriLaunch L{ci, twin, 0, 0, 0, 0, 0, 0};
+            const size_t nent = ents.size() / 4;
+            if (nent == 0) return;
+            if (!plan.on) {
+                L.dense_off = hb.size(); L.dense_n = (int)nent;
+                hb.insert(hb.end(), ents.begin(), ents.end());
+                cc->launches.push_back(L);
+                return;
+            }
+            std::vector<int> shared_ents, tasks;
+            L.dense_off = hb.size();
+            for (size_t e = 0; e < nent; ++e) {
+                if (plan.shared_row[sets[e]] < 0) { hb.insert(hb.end(), ents.begin() + 4 * e, ents.begin() + 4 * e + 4); ++L.dense_n; continue; }
+                const int local = (int)(shared_ents.size() / 4);
+                shared_ents.insert(shared_ents.end(), ents.begin() + 4 * e, ents.begin() + 4 * e + 4);
+                for (int u : plan.uniq[sets[e]]) { tasks.push_back(local); tasks.push_back(u); }
+            }
+            L.sh_off = hb.size(); L.sh_n = (int)(shared_ents.size() / 4);
+            hb.insert(hb.end(), shared_ents.begin(), shared_ents.end());
+            L.task_off = hb.size(); L.ntasks = (int)(tasks.size() / 2);
+            hb.insert(hb.end(), tasks.begin(), tasks.end());
+            cc->launches.push_back(L);
+        };
+        for (size_t ci = 0; ci < topo.classes.size(); ++ci) {
+            const auto& cl = topo.classes[ci];
+            if (twins && !cl.twin_entries.empty()) {
+                stage((int)ci, true, cl.twin_entries, cl.set_twin);
+                stage((int)ci, false, cl.rest, cl.set_rest);
+            } else {
+                stage((int)ci, false, cl.quartets, cl.set_quartets);
+            }
+        }
+        cc->shared = plan.on;
+        if (plan.on) {
+            // AO pair -> atom pair, (atom pair, atom pair) -> shared row, representative table
+            std::vector<int> ao_atom(topo.nao);
+            for (auto& sh : topo.shells) for (int m = 0; m < 2 * sh.l + 1; ++m) ao_atom[sh.aoff + m] = sh.atom;
+            cc->pair_off = hb.size();
+            for (int i = 0; i < topo.nao; ++i) for (int j = 0; j <= i; ++j) hb.push_back(apair_index(ao_atom[i], ao_atom[j]));
+            cc->pp_off = hb.size();
+            hb.insert(hb.end(), plan.pp_row.begin(), plan.pp_row.end());
+            cc->any_off = hb.size();
+            hb.resize(hb.size() + (plan.nap + 3) / 4, 0);
+            for (int a = 0; a < plan.nap; ++a) ((unsigned char*)&hb[cc->any_off])[a] = (unsigned char)plan.apair_any[a];
+            cc->rep_off = hb.size();
+            hb.insert(hb.end(), plan.rep_table.begin(), plan.rep_table.end());
+            cc->nap = plan.nap;
+        }
+        int* dnew = (int*)cc->pool.ensure((hb.size() + 16) * sizeof(int));
+        (void)hipMemcpyAsync(dnew, hb.data(), hb.size() * sizeof(int), hipMemcpyHostToDevice, s);
+        cc->key = key;
+        cc->valid = true;
     }
+    const int* d = (const int*)cc->pool.ensure(0);
+
+    // ---- launches: dense lists on the caller's stream; the task-list launches of shared entries (few, long
+    // threads: one wave per entry and distinct geometry) on a side stream so that they fill gaps instead of
+    // serialising; both join before the copy kernel
+    if (cc->shared) {
+        (void)hipEventRecord(st.fork, s);
+        for (int k = 0; k < ERI_SIDE_STREAMS; ++k) (void)hipStreamWaitEvent(st.side[k], st.fork, 0);
+    }
+    int rr = 0;
+#define ERI_CASE(a, b, c, d_)                                                                                         \
+    if (cl.la == a && cl.lb == b && cl.lc == c && cl.ld == d_) {                                                      \
+        launch_eri_class<a, b, c, d_>(bv, d + L.dense_off, L.dense_n, nullptr, 0, Q, thresh, s);                      \
+        launch_eri_class<a, b, c, d_>(bv, d + L.sh_off, L.sh_n, d + L.task_off, L.ntasks, Q, thresh, st.side[rr++ % ERI_SIDE_STREAMS]); \
+    }
+#define TWIN_CASE(a, b, c, d_)                                                                                        \
+    if (cl.la == a && cl.lb == b && cl.lc == c && cl.ld == d_) {                                                      \
+        launch_eri_twin_class<a, b, c, d_>(bv, d + L.dense_off, L.dense_n, nullptr, 0, s);                            \
+        launch_eri_twin_class<a, b, c, d_>(bv, d + L.sh_off, L.sh_n, d + L.task_off, L.ntasks, st.side[rr++ % ERI_SIDE_STREAMS]); \
+    }
+    for (const EriLaunch& L : cc->launches) {
+        const auto& cl = topo.classes[L.cls];
+        if (L.twin) {
             TWIN_CASE(0, 0, 0, 0) TWIN_CASE(1, 0, 0, 0) TWIN_CASE(1, 0, 1, 0) TWIN_CASE(1, 1, 0, 0)
             TWIN_CASE(1, 1, 1, 0) TWIN_CASE(2, 0, 0, 0) TWIN_CASE(2, 0, 1, 0) TWIN_CASE(2, 1, 0, 0)
-#undef TWIN_CASE
-            off += cl.quartets.size();      // twin entries + rest never exceed the full list
             continue;
         }
         ERI_CASE(0, 0, 0, 0)
@@ -93,7 +344,16 @@ void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, h
         ERI_CASE(2, 1, 0, 0) ERI_CASE(2, 1, 1, 0) ERI_CASE(2, 1, 1, 1) ERI_CASE(2, 1, 2, 0) ERI_CASE(2, 1, 2, 1)
         ERI_CASE(2, 2, 0, 0) ERI_CASE(2, 2, 1, 0) ERI_CASE(2, 2, 1, 1) ERI_CASE(2, 2, 2, 0) ERI_CASE(2, 2, 2, 1)
         ERI_CASE(2, 2, 2, 2)
-        off += cl.quartets.size();
+    }
+#undef ERI_CASE
+#undef TWIN_CASE
+    if (cc->shared) {
+        for (int k = 0; k < ERI_SIDE_STREAMS; ++k) {
+            (void)hipEventRecord(st.join[k], st.side[k]);
+            (void)hipStreamWaitEvent(s, st.join[k], 0);
+        }
+        hipLaunchKernelGGL(eri_broadcast_kernel, dim3((unsigned)np, (unsigned)bv.nfrag), dim3(256), 0, s, bv,
+                           d + cc->pair_off, d + cc->pp_off, cc->nap, (const unsigned char*)(d + cc->any_off), d + cc->rep_off);
     }
 }
 

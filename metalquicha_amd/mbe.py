@@ -156,22 +156,57 @@ class MbeRun:
     errors: List[str]
 
 
+def build_fragment_groups(system: FragmentedSystem, term_list: Sequence[Tuple[int, ...]]):
+    """The fragments of `term_list` as engine batches: terms of one order whose atoms carry the same element
+    sequence form one FragmentGroup (coordinates gathered with one fancy index).  Returns (groups, positions)
+    where positions[g][k] is the index into term_list of the k-th fragment of group g."""
+    from .methods import FragmentGroup
+    coords = np.ascontiguousarray(system.coordinates.T)           # (n_atoms, 3)
+    by_shape: Dict[Tuple[int, ...], List[int]] = {}
+    for pos, t in enumerate(term_list):
+        by_shape.setdefault(tuple(len(system.monomers[m]) for m in t), []).append(pos)
+    groups, positions = [], []
+    for shape, plist in by_shape.items():
+        plist = np.asarray(plist)
+        if len(set(shape)) == 1 and all(len(m) == shape[0] for m in system.monomers):
+            mono = np.asarray(system.monomers)                                 # (n_monomers, atoms per monomer)
+            atoms = mono[np.array([term_list[p] for p in plist])].reshape(len(plist), -1)
+        else:
+            atoms = np.array([np.concatenate([system.monomers[m] for m in term_list[p]]) for p in plist])   # (nt, na)
+        zs = system.element_numbers[atoms]
+        uniq, inverse = np.unique(zs, axis=0, return_inverse=True)
+        inverse = np.asarray(inverse).reshape(-1)
+        if system.charges is None:
+            charges = np.zeros(len(plist), dtype=np.int32)
+        else:
+            ch = np.asarray(system.charges)
+            charges = np.array([int(sum(ch[m] for m in term_list[p])) for p in plist], dtype=np.int32)
+        for u in range(len(uniq)):
+            sel = np.nonzero(inverse == u)[0]
+            groups.append(FragmentGroup(uniq[u].astype(np.int32), coords[atoms[sel]], charges[sel]))
+            positions.append(plist[sel])
+    return groups, positions
+
+
 def run_mbe(system: FragmentedSystem, settings: ScfSettings, level: int = 2,
             cutoffs: Optional[Dict[int, float]] = None, rank: int = 0, world: int = 1,
             terms: Optional[List[Tuple[int, ...]]] = None) -> MbeRun:
+    from .methods import run_hip_scf_groups
     terms = terms if terms is not None else generate_mbe_term_list(system, level, cutoffs)
     owned = partition_terms(len(terms), rank, world)
-    frags = [build_fragment(system, terms[i]) for i in owned]
-    results = run_hip_scf_batch(settings, frags)
+    groups, positions = build_fragment_groups(system, [terms[i] for i in owned])
+    owned_arr = np.asarray(owned)
     energies = np.zeros(len(terms))
     iters = np.zeros(len(terms), dtype=np.int64)
     errors = []
-    for i, r in zip(owned, results):
-        if r.has_error:
-            errors.append("term %s: %s" % (terms[i], r.error_message))
-            continue
-        energies[i] = r.energy.scf
-        iters[i] = r.scf_iterations
+    for pos, rec in zip(positions, run_hip_scf_groups(settings, groups)):
+        tix = owned_arr[pos]
+        ok = rec["has_error"] == 0
+        energies[tix[ok]] = rec["e_total"][ok]
+        iters[tix[ok]] = rec["iterations"][ok]
+        for k in np.nonzero(~ok)[0]:
+            msg = bytes(rec["message"][k]).split(b"\0", 1)[0].decode(errors="replace")
+            errors.append("term %s: %s" % (terms[tix[k]], msg))
     return MbeRun(terms, energies, iters, owned, errors)
 
 

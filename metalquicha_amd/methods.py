@@ -185,12 +185,16 @@ class _Marshalled:
 _BASIS_CACHE = {}
 
 
-def _flat_basis(name: str, fragment: PhysicalFragment) -> FlatBasis:
+def _flat_basis_z(name: str, element_numbers) -> FlatBasis:
     # flattened shells cached per (basis, element sequence): SURVEY.md 8f item 4
-    key = (name.lower(), tuple(int(z) for z in fragment.element_numbers))
+    key = (name.lower(), tuple(int(z) for z in element_numbers))
     if key not in _BASIS_CACHE:
-        _BASIS_CACHE[key] = build_flat_basis(name, fragment.element_numbers)
+        _BASIS_CACHE[key] = build_flat_basis(name, element_numbers)
     return _BASIS_CACHE[key]
+
+
+def _flat_basis(name: str, fragment: PhysicalFragment) -> FlatBasis:
+    return _flat_basis_z(name, fragment.element_numbers)
 
 
 def _fill(result: CalculationResult, r: capi.ScfResult, eps: Optional[np.ndarray]) -> CalculationResult:
@@ -256,16 +260,50 @@ def _basis_record(fb: FlatBasis, n_atoms: int):
             fb.shell_nprim.ctypes.data, fb.exps.ctypes.data, fb.coefs.ctypes.data)
 
 
-def run_hip_scf_batch(settings: ScfSettings, fragments: Sequence[PhysicalFragment]) -> List[CalculationResult]:
-    """Many independent fragments in one call (mqc_hip_scf_run_batch).
+def _struct_dtype(struct) -> np.dtype:
+    """numpy view of a ctypes struct (pointers as u8, char arrays as bytes) with the C offsets."""
+    names, formats, offsets = [], [], []
+    for name, ctype in struct._fields_:
+        size = C.sizeof(ctype)
+        if ctype is C.c_double:
+            fmt = "<f8"
+        elif ctype is C.c_int32:
+            fmt = "<i4"
+        elif ctype is C.c_int64:
+            fmt = "<i8"
+        elif issubclass(ctype, C.Array) and ctype._type_ is C.c_char:
+            fmt = "S%d" % size
+        else:
+            fmt = "<u8"          # pointers
+        names.append(name); formats.append(fmt); offsets.append(getattr(struct, name).offset)
+    return np.dtype({"names": names, "formats": formats, "offsets": offsets, "itemsize": C.sizeof(struct)})
+
+
+_RES_DTYPE = _struct_dtype(capi.ScfResult)
+
+
+@dataclass
+class FragmentGroup:
+    """Fragments that share their element sequence: the unit the engine batches over."""
+    element_numbers: np.ndarray            # (n_atoms,)
+    xyz: np.ndarray                        # (m, n_atoms, 3) Bohr
+    charge: np.ndarray                     # (m,)
+    multiplicity: Optional[np.ndarray] = None
+    ghost: Optional[np.ndarray] = None     # (n_atoms,) bool, same for the whole group
+    nelec: Optional[np.ndarray] = None     # (m,), default sum(Z of real atoms) - charge
+
+
+def run_hip_scf_groups(settings: ScfSettings, groups: Sequence[FragmentGroup]) -> List[np.ndarray]:
+    """All fragments of all groups in ONE mqc_hip_scf_run_batch call; returns, per group, a structured array
+    viewing the engine's result records (fields of capi.ScfResult: e_total, iterations, has_error, message ...).
 
     The C structs are filled as numpy structured arrays with the header's exact layout
     (tests/test_host_logic.py checks the sizes), so marshalling a few thousand fragments is a
     handful of vector operations rather than a Python loop over ctypes objects."""
-    n = len(fragments)
-    results = [CalculationResult() for _ in range(n)]
+    sizes = [int(g.xyz.shape[0]) for g in groups]
+    n = int(sum(sizes))
     if n == 0:
-        return results
+        return [np.zeros(0, dtype=_RES_DTYPE) for _ in groups]
     lib = capi.load_library()
     ctx = capi.get_context(settings.device_rank)
     opts = _options(settings, False)
@@ -274,41 +312,95 @@ def run_hip_scf_batch(settings: ScfSettings, fragments: Sequence[PhysicalFragmen
     bass = np.zeros(n, dtype=_BAS_DTYPE)
     auxs = np.zeros(n, dtype=_BAS_DTYPE) if df else None
     keep = []                                   # arrays the structs point into
-    groups = {}
-    for i, f in enumerate(fragments):
-        key = (f.element_numbers.tobytes(), None if f.ghost is None else f.ghost.tobytes())
-        groups.setdefault(key, []).append(i)
-    for key, idx in groups.items():
-        idx = np.asarray(idx)
-        f0 = fragments[idx[0]]
-        na = f0.n_atoms
-        z = np.ascontiguousarray(f0.element_numbers, dtype=np.int32)
-        ghost = None if f0.ghost is None else np.ascontiguousarray(f0.ghost, dtype=np.uint8)
-        xyz = np.ascontiguousarray(np.stack([fragments[i].coordinates.T for i in idx]), dtype=np.float64)   # (m, na, 3)
-        fb = _flat_basis(settings.basis_set, f0)
+    lo = 0
+    for g, m in zip(groups, sizes):
+        sl = slice(lo, lo + m)
+        lo += m
+        if m == 0:
+            continue
+        z = np.ascontiguousarray(g.element_numbers, dtype=np.int32)
+        na = int(len(z))
+        ghost = None if g.ghost is None else np.ascontiguousarray(g.ghost, dtype=np.uint8)
+        xyz = np.ascontiguousarray(g.xyz, dtype=np.float64)
+        if xyz.shape != (m, na, 3):
+            raise ValueError("FragmentGroup.xyz must be (m, n_atoms, 3) in Bohr")
+        charge = np.broadcast_to(np.asarray(g.charge, dtype=np.int32), (m,))
+        if g.nelec is None:
+            zsum = int(np.sum(z if ghost is None else z[ghost == 0]))
+            nelec = zsum - charge                                        # compute_nelec, :73-83
+        else:
+            nelec = np.asarray(g.nelec, dtype=np.int32)
+        fb = _flat_basis_z(settings.basis_set, z)
         keep += [z, ghost, xyz, fb]
-        mols["n_atoms"][idx] = na
-        mols["atomic_numbers"][idx] = z.ctypes.data
-        mols["xyz"][idx] = xyz.ctypes.data + np.arange(len(idx), dtype=np.uint64) * np.uint64(na * 3 * 8)
-        mols["ghost"][idx] = 0 if ghost is None else ghost.ctypes.data
-        mols["charge"][idx] = [fragments[i].charge for i in idx]
-        mols["multiplicity"][idx] = [fragments[i].multiplicity for i in idx]
-        mols["nelec"][idx] = [fragments[i].nelec for i in idx]
-        bass[idx] = _basis_record(fb, na)
+        mols["n_atoms"][sl] = na
+        mols["atomic_numbers"][sl] = z.ctypes.data
+        mols["xyz"][sl] = xyz.ctypes.data + np.arange(m, dtype=np.uint64) * np.uint64(na * 3 * 8)
+        mols["ghost"][sl] = 0 if ghost is None else ghost.ctypes.data
+        mols["charge"][sl] = charge
+        mols["multiplicity"][sl] = 1 if g.multiplicity is None else np.asarray(g.multiplicity, dtype=np.int32)
+        mols["nelec"][sl] = nelec
+        bass[sl] = _basis_record(fb, na)
         if df:
-            ab = _flat_basis(settings.aux_basis_set, f0)
+            ab = _flat_basis_z(settings.aux_basis_set, z)
             keep.append(ab)
-            auxs[idx] = _basis_record(ab, na)
+            auxs[sl] = _basis_record(ab, na)
     res = (capi.ScfResult * n)()
     rc = lib.mqc_hip_scf_run_batch(ctx, n, mols.ctypes.data_as(C.POINTER(capi.Molecule)),
                                    bass.ctypes.data_as(C.POINTER(capi.Basis)),
                                    auxs.ctypes.data_as(C.POINTER(capi.Basis)) if df else None, C.byref(opts), res)
-    if rc != capi.MQC_HIP_OK and not any(r.has_error for r in res):
+    rec = np.frombuffer(res, dtype=_RES_DTYPE)
+    if rc != capi.MQC_HIP_OK and not np.any(rec["has_error"]):
         capi.check(rc)
-    for out, r in zip(results, res):
-        _fill(out, r, None)
     del keep
+    out, lo = [], 0
+    for m in sizes:
+        out.append(rec[lo:lo + m])
+        lo += m
+    return out
+
+
+def run_hip_scf_batch(settings: ScfSettings, fragments: Sequence[PhysicalFragment]) -> List[CalculationResult]:
+    """Many independent fragments in one call (mqc_hip_scf_run_batch), results as CalculationResult objects."""
+    n = len(fragments)
+    results = [CalculationResult() for _ in range(n)]
+    if n == 0:
+        return results
+    by_key = {}
+    for i, f in enumerate(fragments):
+        key = (f.element_numbers.tobytes(), None if f.ghost is None else f.ghost.tobytes())
+        by_key.setdefault(key, []).append(i)
+    groups, index = [], []
+    for idx in by_key.values():
+        f0 = fragments[idx[0]]
+        groups.append(FragmentGroup(f0.element_numbers, np.stack([fragments[i].coordinates.T for i in idx]),
+                                    np.array([fragments[i].charge for i in idx], dtype=np.int32),
+                                    np.array([fragments[i].multiplicity for i in idx], dtype=np.int32),
+                                    f0.ghost, np.array([fragments[i].nelec for i in idx], dtype=np.int32)))
+        index.append(idx)
+    for idx, rec in zip(index, run_hip_scf_groups(settings, groups)):
+        for i, r in zip(idx, rec):
+            _fill_record(results[i], r)
     return results
+
+
+def _fill_record(result: CalculationResult, r) -> CalculationResult:
+    """_fill for one row of the structured result view."""
+    result.scf_status = int(r["scf_status"])
+    result.scf_iterations = int(r["iterations"])
+    if r["has_error"]:
+        result.has_error = True
+        result.error_code = capi.ERR_GENERIC
+        result.error_message = bytes(r["message"]).split(b"\0", 1)[0].decode(errors="replace")
+        result.has_energy = False
+        return result
+    result.energy.scf = float(r["e_total"])
+    result.e_nuclear = float(r["e_nuclear"])
+    result.e_electronic = float(r["e_electronic"])
+    result.has_energy = True
+    result.homo = float(r["homo"])
+    result.lumo = float(r["lumo"])
+    result.has_orbitals = bool(r["has_orbitals"])
+    return result
 
 
 class HFMethod:

@@ -380,3 +380,44 @@ def test_chunked_two_slot_batches_match_the_single_chunk_result(extra):
     assert not one["err"] and not five["err"], (one["err"], five["err"])
     assert one["it"] == five["it"]
     assert np.max(np.abs(np.array(one["e"]) - np.array(five["e"]))) < 1e-11
+
+
+# ---- block sharing between fragments with identical atoms ------------------------------------------
+_SHARE_CHILD = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from metalquicha_amd import methods
+from tests.helpers import fragment_bohr, water_at
+rng = np.random.default_rng(11)
+ws = [water_at(rng, [5.9 * i, 0.5 * (i % 3), -0.4 * (i % 2)]) for i in range(7)]
+# 21 dimers built from 7 monomers (every monomer geometry repeats bit for bit in 6 dimers) + 3 odd ones out
+frags = [fragment_bohr([8, 1, 1, 8, 1, 1], np.vstack([ws[i], ws[j]])) for i in range(7) for j in range(i + 1, 7)]
+frags += [fragment_bohr([8, 1, 1, 8, 1, 1], np.vstack([water_at(rng, [0, 9.0 + k, 0]), water_at(rng, [5.5, 9.0 + k, 1.0])])) for k in range(3)]
+kw = dict(basis_set=sys.argv[2], energy_tol=1e-9, density_tol=1e-7, guess="gwh", eri_mode="incore")
+res = methods.run_hip_scf_batch(methods.ScfSettings(**kw), frags)
+print(json.dumps({"e": [r.energy.scf for r in res], "it": [r.scf_iterations for r in res],
+                  "err": [r.error_message for r in res if r.has_error]}))
+"""
+
+
+@pytest.mark.parametrize("basis", ["sto-3g", "cc-pvdz"])
+def test_block_sharing_gives_the_unshared_result(basis):
+    """A batch whose dimers repeat their monomers bit for bit: the engine forms the intra-monomer integral
+    blocks once per distinct monomer and copies them (kern_eri.hip, block sharing).  Against the same batch
+    with MQC_HIP_NO_BLOCK_SHARING=1 and MQC_HIP_NO_TWIN_BLOCKS=1 (every fragment forms everything with the
+    segmented kernels): same iteration counts, energies within summation-order noise."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(env_extra):
+        env = dict(os.environ, **env_extra)
+        out = subprocess.run([sys.executable, "-c", _SHARE_CHILD, root, basis], env=env, check=True,
+                             capture_output=True, text=True, timeout=600).stdout.strip().splitlines()[-1]
+        return json.loads(out)
+
+    shared = run({})
+    plain = run({"MQC_HIP_NO_BLOCK_SHARING": "1", "MQC_HIP_NO_TWIN_BLOCKS": "1"})
+    assert not shared["err"] and not plain["err"], (shared["err"], plain["err"])
+    assert shared["it"] == plain["it"]
+    assert np.max(np.abs(np.array(shared["e"]) - np.array(plain["e"]))) < 1e-10
