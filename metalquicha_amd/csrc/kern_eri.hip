@@ -315,19 +315,24 @@ void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, h
     // ---- launches: dense lists on the caller's stream; the task-list launches of shared entries (few, long
     // threads: one wave per entry and distinct geometry) on a side stream so that they fill gaps instead of
     // serialising; both join before the copy kernel
-    if (cc->shared) {
+    // Small batches (a few dozen monomers) give every class launch only a handful of long-running waves: the
+    // classes are then spread over the side streams as well, so their critical paths overlap instead of adding up.
+    const bool spread = bv.nfrag <= 256;
+    const bool forked = cc->shared || spread;
+    if (forked) {
         (void)hipEventRecord(st.fork, s);
         for (int k = 0; k < ERI_SIDE_STREAMS; ++k) (void)hipStreamWaitEvent(st.side[k], st.fork, 0);
     }
-    int rr = 0;
+    int rr = 0, rd = 0;
+    auto dense_stream = [&]() { if (!spread) return s; const int k = rd++ % (ERI_SIDE_STREAMS + 1); return k == 0 ? s : st.side[k - 1]; };
 #define ERI_CASE(a, b, c, d_)                                                                                         \
     if (cl.la == a && cl.lb == b && cl.lc == c && cl.ld == d_) {                                                      \
-        launch_eri_class<a, b, c, d_>(bv, d + L.dense_off, L.dense_n, nullptr, 0, Q, thresh, s);                      \
+        launch_eri_class<a, b, c, d_>(bv, d + L.dense_off, L.dense_n, nullptr, 0, Q, thresh, dense_stream());         \
         launch_eri_class<a, b, c, d_>(bv, d + L.sh_off, L.sh_n, d + L.task_off, L.ntasks, Q, thresh, st.side[rr++ % ERI_SIDE_STREAMS]); \
     }
 #define TWIN_CASE(a, b, c, d_)                                                                                        \
     if (cl.la == a && cl.lb == b && cl.lc == c && cl.ld == d_) {                                                      \
-        launch_eri_twin_class<a, b, c, d_>(bv, d + L.dense_off, L.dense_n, nullptr, 0, s);                            \
+        launch_eri_twin_class<a, b, c, d_>(bv, d + L.dense_off, L.dense_n, nullptr, 0, dense_stream());               \
         launch_eri_twin_class<a, b, c, d_>(bv, d + L.sh_off, L.sh_n, d + L.task_off, L.ntasks, st.side[rr++ % ERI_SIDE_STREAMS]); \
     }
     for (const EriLaunch& L : cc->launches) {
@@ -347,11 +352,13 @@ void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, h
     }
 #undef ERI_CASE
 #undef TWIN_CASE
-    if (cc->shared) {
+    if (forked) {
         for (int k = 0; k < ERI_SIDE_STREAMS; ++k) {
             (void)hipEventRecord(st.join[k], st.side[k]);
             (void)hipStreamWaitEvent(s, st.join[k], 0);
         }
+    }
+    if (cc->shared) {
         hipLaunchKernelGGL(eri_broadcast_kernel, dim3((unsigned)np, (unsigned)bv.nfrag), dim3(256), 0, s, bv,
                            d + cc->pair_off, d + cc->pp_off, cc->nap, (const unsigned char*)(d + cc->any_off), d + cc->rep_off);
     }
