@@ -13,6 +13,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <thread>
 
 namespace mqc {
 const std::string& last_error_string();
@@ -34,7 +36,7 @@ struct TopoDevHolder {
     TopologyDev dev;
 };
 
-static int upload_topology(mqc_hip_context* ctx, const Topology& topo, TopologyDev& td, DevicePool* pool = nullptr)
+static int upload_topology(mqc_hip_context* ctx, const Topology& topo, TopologyDev& td, DevicePool* pool = nullptr, hipStream_t stream = nullptr)
 {
     if (!pool) pool = &ctx->pool_topo;
     const int ns = (int)topo.shells.size();
@@ -54,7 +56,7 @@ static int upload_topology(mqc_hip_context* ctx, const Topology& topo, TopologyD
     td.exps = (double*)take(sizeof(double) * nprim); td.coefs = (double*)take(sizeof(double) * nprim);
     td.zeff = (double*)take(sizeof(double) * topo.natoms);
     td.nshell = ns; td.nao = topo.nao; td.npair = topo.npair; td.natoms = topo.natoms;
-    hipStream_t s = ctx->stream;
+    hipStream_t s = stream ? stream : ctx->stream;
     HIP_CHECK_RET(hipMemcpyAsync(td.sh_l, l.data(), ib, hipMemcpyHostToDevice, s));
     HIP_CHECK_RET(hipMemcpyAsync(td.sh_nprim, np.data(), ib, hipMemcpyHostToDevice, s));
     HIP_CHECK_RET(hipMemcpyAsync(td.sh_poff, po.data(), ib, hipMemcpyHostToDevice, s));
@@ -157,8 +159,13 @@ static void fill_error(mqc_hip_scf_result_t* r, const std::string& msg)
 }
 
 int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, const std::vector<const double*>& xyz_in,
-              const mqc_hip_scf_options_t& opts, std::vector<mqc_hip_scf_result_t*>& results_in)
+              const mqc_hip_scf_options_t& opts, std::vector<mqc_hip_scf_result_t*>& results_in, int lane)
 {
+    // statistics are gathered locally and merged at the end (two lanes may run at once)
+    struct StatsCtx { Stats stats; } local;
+    StatsCtx* const sx = &local;
+    const bool second = lane == 1;
+    hipStream_t const lane_stream = second ? ctx->stream2 : ctx->stream;
     const double t_begin = now_s();
     const int ntot = (int)xyz_in.size();
     // Order the batch by compactness (nuclear repulsion, most compact first).  Lanes of a wave are
@@ -178,9 +185,8 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         for (auto* r : results) { fill_error(r, msg); r->scf_status = MQC_HIP_SCF_NOT_RUN; }
         return fail(rc, msg);
     }
-    hipStream_t s = ctx->stream;
     TopologyDev td;
-    rc = upload_topology(ctx, topo, td);
+    rc = upload_topology(ctx, topo, td, second ? &ctx->pool_topo2 : &ctx->pool_topo, lane_stream);
     if (rc != MQC_HIP_OK) return rc;
     const bool use_df = opts.density_fitting != 0;
     // exact-ERI path selection (mqc_libcint_bridge.f90:819-892 with an HBM budget instead of 2 GB of host memory)
@@ -195,7 +201,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
             for (auto* r : results) { fill_error(r, m); r->scf_status = MQC_HIP_SCF_NOT_RUN; }
             return fail(MQC_HIP_ERR_VALIDATION, m);
         }
-        rc = upload_topology(ctx, *aux, tdx, &ctx->pool_aux);
+        rc = upload_topology(ctx, *aux, tdx, second ? &ctx->pool_aux2 : &ctx->pool_aux, lane_stream);
         if (rc != MQC_HIP_OK) return rc;
         naux = aux->nao;
     }
@@ -234,16 +240,17 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         const size_t b_xyz = (sizeof(double) * txyz.size() + 255) & ~size_t(255);
         const size_t b_w = (sizeof(double) * tw.size() + 255) & ~size_t(255);
         const size_t b_sb = (sizeof(double) * sb.size() + 255) & ~size_t(255);
-        char* gb = (char*)ctx->pool_grid.ensure(2 * b_int + b_xyz + b_w + b_sb + 1024);
+        char* gb = (char*)(second ? ctx->pool_grid2 : ctx->pool_grid).ensure(2 * b_int + b_xyz + b_w + b_sb + 1024);
         if (!gb) return fail(MQC_HIP_ERR_DEVICE, "out of device memory (grid templates)");
         int* d_pa = (int*)gb; int* d_pt = (int*)(gb + b_int);
         double* d_x = (double*)(gb + 2 * b_int); double* d_w = (double*)(gb + 2 * b_int + b_xyz);
         double* d_sb = (double*)(gb + 2 * b_int + b_xyz + b_w);
-        HIP_CHECK_RET(hipMemcpy(d_pa, pt_atom.data(), sizeof(int) * pt_atom.size(), hipMemcpyHostToDevice));
-        HIP_CHECK_RET(hipMemcpy(d_pt, pt_tmpl.data(), sizeof(int) * pt_tmpl.size(), hipMemcpyHostToDevice));
-        HIP_CHECK_RET(hipMemcpy(d_x, txyz.data(), sizeof(double) * txyz.size(), hipMemcpyHostToDevice));
-        HIP_CHECK_RET(hipMemcpy(d_w, tw.data(), sizeof(double) * tw.size(), hipMemcpyHostToDevice));
-        HIP_CHECK_RET(hipMemcpy(d_sb, sb.data(), sizeof(double) * sb.size(), hipMemcpyHostToDevice));
+        HIP_CHECK_RET(hipMemcpyAsync(d_pa, pt_atom.data(), sizeof(int) * pt_atom.size(), hipMemcpyHostToDevice, lane_stream));
+        HIP_CHECK_RET(hipMemcpyAsync(d_pt, pt_tmpl.data(), sizeof(int) * pt_tmpl.size(), hipMemcpyHostToDevice, lane_stream));
+        HIP_CHECK_RET(hipMemcpyAsync(d_x, txyz.data(), sizeof(double) * txyz.size(), hipMemcpyHostToDevice, lane_stream));
+        HIP_CHECK_RET(hipMemcpyAsync(d_w, tw.data(), sizeof(double) * tw.size(), hipMemcpyHostToDevice, lane_stream));
+        HIP_CHECK_RET(hipMemcpyAsync(d_sb, sb.data(), sizeof(double) * sb.size(), hipMemcpyHostToDevice, lane_stream));
+        HIP_CHECK_RET(hipStreamSynchronize(lane_stream));     // the host vectors go out of scope
         grid.pt_atom = d_pa; grid.pt_tmpl = d_pt; grid.tmpl_xyz = d_x; grid.tmpl_w = d_w; grid.sqrt_bragg = d_sb;
     }
 
@@ -255,13 +262,14 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
     (void)hipMemGetInfo(&free_b, &total_b);
     free_b += ctx->pool_main.capacity() + ctx->pool_eri.capacity() + ctx->pool_df.capacity() + ctx->pool_gridw.capacity()
             + ctx->pool_main2.capacity() + ctx->pool_eri2.capacity() + ctx->pool_df2.capacity() + ctx->pool_gridw2.capacity();
-    size_t budget = (size_t)(0.80 * (double)free_b);
+    // a lane shares the card with the other lane's batch: 40 % each instead of 80 %
+    size_t budget = (size_t)((lane < 0 ? 0.80 : 0.40) * (double)free_b);
     if (ctx->hbm_budget_bytes && ctx->hbm_budget_bytes < budget) budget = ctx->hbm_budget_bytes;
     // Chunking.  Small batches run as one chunk on slot 0.  Large ones are cut into >= 4 chunks that
     // alternate between the two slots (each slot may hold half of the budget).
-    const bool pipelined = ctx->pipeline_chunks > 1 && ntot >= ctx->pipeline_min_fragments;
+    const bool pipelined = lane < 0 && ctx->pipeline_chunks > 1 && ntot >= ctx->pipeline_min_fragments;
     long chunk = (long)(budget / per_frag);
-    if (pipelined || chunk < ntot) {
+    if (lane < 0 && (pipelined || chunk < ntot)) {
         // more than one chunk: two are resident at a time
         chunk = (long)(budget / 2 / per_frag);
         const long want = pipelined ? (ntot + ctx->pipeline_chunks - 1) / ctx->pipeline_chunks : ntot;
@@ -290,8 +298,8 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
 
     // drains both streams before an error return hands the pools back
     auto bail = [&](int code) {
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipStreamSynchronize(ctx->stream2);
+        if (lane != 1) (void)hipStreamSynchronize(ctx->stream);
+        if (lane != 0) (void)hipStreamSynchronize(ctx->stream2);
         (void)hipHostFree(h_counter);
         return code;
     };
@@ -326,7 +334,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         HIP_CHECK_RET(hipMemcpyAsync(bv.xyz, job.hx.data(), sizeof(double) * job.hx.size(), hipMemcpyHostToDevice, s));
         HIP_CHECK_RET(hipMemsetAsync(bv.istate, 0, sizeof(int) * (size_t)nf * 4, s));
         const double t1 = now_s();
-        ctx->stats.t_setup += t1 - t0;
+        sx->stats.t_setup += t1 - t0;
 
         launch_int1e(bv, topo, s);
         if ((rc = stage_check("int1e")) != MQC_HIP_OK) return rc;
@@ -335,7 +343,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         if (xc.ncomp > 0) launch_becke_weights(bv, s);
         if ((rc = stage_check("grid weights")) != MQC_HIP_OK) return rc;
         const double t2 = now_s();
-        ctx->stats.t_int1e += t2 - t1;
+        sx->stats.t_int1e += t2 - t1;
 
         HIP_CHECK_RET(hipEventRecord(sl.q0, s));
         if (use_df) launch_df_build(bv, topo, *aux, s);
@@ -343,10 +351,10 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         else launch_eri(bv, topo, stol, s, job.hx.data());
         HIP_CHECK_RET(hipEventRecord(sl.q1, s));
         if ((rc = stage_check("two-electron setup")) != MQC_HIP_OK) return rc;
-        ctx->stats.eri_quartets += topo.n_quartets * nf;
+        sx->stats.eri_quartets += topo.n_quartets * nf;
         launch_guess(bv, opts.guess == MQC_HIP_GUESS_CORE ? MQC_HIP_GUESS_CORE : MQC_HIP_GUESS_GWH, s);
         if ((rc = stage_check("guess")) != MQC_HIP_OK) return rc;
-        ctx->stats.t_eri += now_s() - t2;      // host time to enqueue; the kernels are timed by q0/q1
+        sx->stats.t_eri += now_s() - t2;      // host time to enqueue; the kernels are timed by q0/q1
         return MQC_HIP_OK;
     };
 
@@ -362,7 +370,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         {
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, sl.q0, sl.q1);
-            ctx->stats.eri_kernel_seconds += ms * 1e-3;
+            sx->stats.eri_kernel_seconds += ms * 1e-3;
         }
         int remaining = nf;
         int guard = 0;
@@ -383,22 +391,22 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
             HIP_CHECK_RET(hipStreamSynchronize(s));
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, sl.e0, sl.e1);
-            ctx->stats.fock_kernel_seconds += ms * 1e-3;
-            ctx->stats.fock_bytes += use_df ? (double)remaining * 2.0 * (double)naux * (double)np * 8.0
+            sx->stats.fock_kernel_seconds += ms * 1e-3;
+            sx->stats.fock_bytes += use_df ? (double)remaining * 2.0 * (double)naux * (double)np * 8.0
                                             : (double)remaining * (double)np * (double)np * 8.0;
-            ctx->stats.fock_launches += 1;
+            sx->stats.fock_launches += 1;
             if (xc.ncomp > 0) {
                 float mx = 0.f;
                 (void)hipEventElapsedTime(&mx, sl.e2, sl.e3);
-                ctx->stats.xc_kernel_seconds += mx * 1e-3;
-                ctx->stats.xc_points += (double)remaining * grid.npts;
+                sx->stats.xc_kernel_seconds += mx * 1e-3;
+                sx->stats.xc_points += (double)remaining * grid.npts;
             }
             remaining = sl.h_counter[0];
             ++guard;
         }
         if ((rc = stage_check("SCF loop")) != MQC_HIP_OK) return rc;
         const double t4 = now_s();
-        ctx->stats.t_fock += t4 - t3;
+        sx->stats.t_fock += t4 - t3;
 
         std::vector<double> scal((size_t)nf * 8), eps((size_t)nf * n);
         std::vector<int> ist((size_t)nf * 4);
@@ -438,22 +446,42 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
             else if (!std::isfinite(r->e_total)) fill_error(r, "SCF produced a non-finite energy");
             else if (!conv && !opts.allow_crap_scf)
                 fill_error(r, "SCF did not converge in " + std::to_string(r->iterations) + " iterations");
-            ctx->stats.scf_iterations_total += r->iterations;
+            sx->stats.scf_iterations_total += r->iterations;
         }
-        ctx->stats.t_scf_step += now_s() - t4;
+        sx->stats.t_scf_step += now_s() - t4;
         return MQC_HIP_OK;
     };
 
     const int njobs = (int)jobs.size();
-    if ((rc = prepare(slots[0], jobs[0])) != MQC_HIP_OK) return bail(rc);
-    for (int k = 0; k < njobs; ++k) {
-        // chunk k+1's integrals go onto the other stream before the host starts iterating chunk k
-        if (k + 1 < njobs && (rc = prepare(slots[(k + 1) & 1], jobs[k + 1])) != MQC_HIP_OK) return bail(rc);
-        if ((rc = iterate_and_fetch(slots[k & 1], jobs[k])) != MQC_HIP_OK) return bail(rc);
-        std::vector<double>().swap(jobs[k].hx);
+    if (lane >= 0) {
+        // one slot only: chunks strictly one after the other
+        Slot& sl = slots[lane & 1];
+        for (int k = 0; k < njobs; ++k) {
+            if ((rc = prepare(sl, jobs[k])) != MQC_HIP_OK) return bail(rc);
+            if ((rc = iterate_and_fetch(sl, jobs[k])) != MQC_HIP_OK) return bail(rc);
+            std::vector<double>().swap(jobs[k].hx);
+        }
+    } else {
+        if ((rc = prepare(slots[0], jobs[0])) != MQC_HIP_OK) return bail(rc);
+        for (int k = 0; k < njobs; ++k) {
+            // chunk k+1's integrals go onto the other stream before the host starts iterating chunk k
+            if (k + 1 < njobs && (rc = prepare(slots[(k + 1) & 1], jobs[k + 1])) != MQC_HIP_OK) return bail(rc);
+            if ((rc = iterate_and_fetch(slots[k & 1], jobs[k])) != MQC_HIP_OK) return bail(rc);
+            std::vector<double>().swap(jobs[k].hx);
+        }
     }
     (void)hipHostFree(h_counter);
-    ctx->stats.t_total += now_s() - t_begin;
+    sx->stats.t_total += now_s() - t_begin;
+    {
+        std::lock_guard<std::mutex> lock(ctx->stats_mutex);
+        Stats& g = ctx->stats;
+        const Stats& l = sx->stats;
+        g.t_setup += l.t_setup; g.t_int1e += l.t_int1e; g.t_eri += l.t_eri; g.t_fock += l.t_fock; g.t_scf_step += l.t_scf_step;
+        g.t_total += l.t_total; g.fock_launches += l.fock_launches; g.eri_quartets += l.eri_quartets;
+        g.scf_iterations_total += l.scf_iterations_total; g.fock_kernel_seconds += l.fock_kernel_seconds;
+        g.fock_bytes += l.fock_bytes; g.eri_kernel_seconds += l.eri_kernel_seconds;
+        g.xc_kernel_seconds += l.xc_kernel_seconds; g.xc_points += l.xc_points;
+    }
     return MQC_HIP_OK;
 }
 
@@ -529,6 +557,8 @@ int mqc_hip_context_get(int32_t local_rank, mqc_hip_context** out)
     // chip, co-running them only slows both), so it is off unless MQC_HIP_PIPELINE_CHUNKS asks for it.
     // Batches that exceed the HBM budget still alternate between the two slots.
     ctx->pipeline_chunks = 1;
+    // MQC_HIP_CONCURRENT_GROUPS=0: topology groups of a batch call run one after the other
+    if (const char* cg = std::getenv("MQC_HIP_CONCURRENT_GROUPS")) ctx->concurrent_groups = std::atoi(cg) != 0;
     if (const char* pc = std::getenv("MQC_HIP_PIPELINE_CHUNKS")) ctx->pipeline_chunks = std::max(1, std::atoi(pc));
     if (const char* pm = std::getenv("MQC_HIP_PIPELINE_MIN_FRAGMENTS")) ctx->pipeline_min_fragments = std::max(2, std::atoi(pm));
     g_ctx = ctx;
@@ -542,6 +572,7 @@ int mqc_hip_finalize(void)
     (void)hipSetDevice(g_ctx->device);
     (void)hipStreamSynchronize(g_ctx->stream);
     (void)hipStreamSynchronize(g_ctx->stream2);
+    g_ctx->pool_topo2.release(); g_ctx->pool_aux2.release(); g_ctx->pool_grid2.release();
     g_ctx->pool_main2.release(); g_ctx->pool_eri2.release(); g_ctx->pool_misc2.release(); g_ctx->pool_gridw2.release(); g_ctx->pool_df2.release();
     g_ctx->pool_main.release(); g_ctx->pool_eri.release(); g_ctx->pool_topo.release(); g_ctx->pool_misc.release();
     g_ctx->pool_grid.release(); g_ctx->pool_gridw.release(); g_ctx->pool_aux.release(); g_ctx->pool_df.release();
@@ -598,6 +629,9 @@ int mqc_hip_scf_run_batch(mqc_hip_context* ctx, int64_t nfrag, const mqc_hip_mol
     for (int64_t i = 0; i < nfrag; ++i) init_result(&results[i]);
     // group by topology
     std::map<std::string, std::vector<int64_t>> groups;
+    int64_t last = -1;
+    std::string last_key;
+    std::vector<int64_t>* last_group = nullptr;
     for (int64_t i = 0; i < nfrag; ++i) {
         if (!mols[i].atomic_numbers || !mols[i].xyz || mols[i].n_atoms <= 0 || !orbitals[i].shell_l ||
             !orbitals[i].nshell_per_atom || !orbitals[i].shell_nprim || !orbitals[i].exponents || !orbitals[i].coefficients) {
@@ -605,44 +639,99 @@ int mqc_hip_scf_run_batch(mqc_hip_context* ctx, int64_t nfrag, const mqc_hip_mol
             std::snprintf(results[i].message, sizeof(results[i].message), "fragment has no geometry or basis");
             continue;
         }
-        std::string key = topology_key(mols[i], orbitals[i]);
-        if (opts->density_fitting && auxes) key += "//" + topology_key(mols[i], auxes[i]);
-        groups[key].push_back(i);
+        // consecutive fragments that point at the very same element and basis arrays share their key
+        const bool same_as_last = last >= 0 && mols[i].n_atoms == mols[last].n_atoms && mols[i].atomic_numbers == mols[last].atomic_numbers &&
+                                  mols[i].ghost == mols[last].ghost && mols[i].nelec == mols[last].nelec && mols[i].charge == mols[last].charge &&
+                                  mols[i].multiplicity == mols[last].multiplicity &&
+                                  std::memcmp(&orbitals[i], &orbitals[last], sizeof(mqc_hip_basis_t)) == 0 &&
+                                  (!(opts->density_fitting && auxes) || std::memcmp(&auxes[i], &auxes[last], sizeof(mqc_hip_basis_t)) == 0);
+        if (!same_as_last) {
+            last_key = topology_key(mols[i], orbitals[i]);
+            if (opts->density_fitting && auxes) last_key += "//" + topology_key(mols[i], auxes[i]);
+            last_group = &groups[last_key];
+        }
+        last = i;
+        last_group->push_back(i);
     }
     int worst = MQC_HIP_OK;
+    // ---- per topology group: topology from the cache (or built now), then the batch.  With several groups
+    // (monomers and dimers of an MBE list) two run at a time, each on its own slot: the small group's
+    // latency-bound stages hide behind the large one.
+    struct Work {
+        const std::vector<int64_t>* idx;
+        std::shared_ptr<Topology> topo, aux;
+        std::vector<const double*> xyz;
+        std::vector<mqc_hip_scf_result_t*> res;
+        int rc = MQC_HIP_OK;
+        std::string msg;
+    };
+    std::vector<Work> work;
+    auto cached_topology = [&](const std::string& key, const mqc_hip_molecule_t& mol, const mqc_hip_basis_t& bas, int max_l,
+                               bool quartets, std::shared_ptr<Topology>& out, std::string& err) -> int {
+        const std::string k = key + (quartets ? "|q" : "|n") + std::to_string(max_l);
+        auto it = ctx->topo_cache.find(k);
+        if (it != ctx->topo_cache.end()) { out = it->second; return MQC_HIP_OK; }
+        auto t = std::make_shared<Topology>();
+        const int rc = build_topology(mol, bas, *t, err, max_l, quartets);
+        if (rc != MQC_HIP_OK) return rc;
+        if (ctx->topo_cache.size() >= 16) ctx->topo_cache.clear();
+        ctx->topo_cache[k] = t;
+        out = t;
+        return MQC_HIP_OK;
+    };
     for (auto& kv : groups) {
         const auto& idx = kv.second;
-        Topology topo;
+        Work w;
+        w.idx = &idx;
         std::string err;
         const bool need_quartets = !(opts->density_fitting && auxes);
-        int rc = build_topology(mols[idx[0]], orbitals[idx[0]], topo, err, KERNEL_LMAX, need_quartets);
+        int rc = cached_topology(topology_key(mols[idx[0]], orbitals[idx[0]]), mols[idx[0]], orbitals[idx[0]], KERNEL_LMAX, need_quartets, w.topo, err);
         if (rc != MQC_HIP_OK) {
             for (auto i : idx) { results[i].has_error = 1; std::snprintf(results[i].message, sizeof(results[i].message), "%s", err.c_str()); }
             set_error(err);
             worst = rc;
             continue;
         }
-        Topology auxt;
-        const Topology* auxp = nullptr;
         if (opts->density_fitting && auxes) {
-            rc = build_topology(mols[idx[0]], auxes[idx[0]], auxt, err, AUX_LMAX, false);
+            rc = cached_topology(topology_key(mols[idx[0]], auxes[idx[0]]), mols[idx[0]], auxes[idx[0]], AUX_LMAX, false, w.aux, err);
             if (rc != MQC_HIP_OK) {
                 for (auto i : idx) { results[i].has_error = 1; std::snprintf(results[i].message, sizeof(results[i].message), "auxiliary basis: %s", err.c_str()); }
                 set_error(err);
                 worst = rc;
                 continue;
             }
-            auxp = &auxt;
         }
-        std::vector<const double*> xyz;
-        std::vector<mqc_hip_scf_result_t*> res;
-        for (auto i : idx) { xyz.push_back(mols[i].xyz); res.push_back(&results[i]); }
-        rc = run_batch(ctx, topo, auxp, xyz, *opts, res);
-        if (rc != MQC_HIP_OK) {
-            worst = rc;
-            for (auto* r : res)
-                if (!r->has_error) { r->has_error = 1; std::snprintf(r->message, sizeof(r->message), "%s", mqc_hip_last_error()); }
-        }
+        for (auto i : idx) { w.xyz.push_back(mols[i].xyz); w.res.push_back(&results[i]); }
+        work.push_back(std::move(w));
+    }
+    auto run_one = [&](Work& w, int lane) {
+        (void)hipSetDevice(ctx->device);
+        w.rc = run_batch(ctx, *w.topo, w.aux.get(), w.xyz, *opts, w.res, lane);
+        if (w.rc != MQC_HIP_OK) w.msg = mqc_hip_last_error();      // the error text is thread-local
+    };
+    if (work.size() >= 2 && ctx->concurrent_groups) {
+        // largest group first on lane 0; the others queue up on lane 1, then lane 0 helps with what is left
+        std::sort(work.begin(), work.end(), [](const Work& a, const Work& b) { return a.xyz.size() > b.xyz.size(); });
+        std::atomic<size_t> next{0};
+        auto worker = [&](int lane) {
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= work.size()) return;
+                run_one(work[k], lane);
+            }
+        };
+        std::thread t1(worker, 1);
+        worker(0);
+        t1.join();
+    } else {
+        for (auto& w : work) run_one(w, -1);
+    }
+    for (auto& w : work) {
+        if (w.rc == MQC_HIP_OK) continue;
+        worst = w.rc;
+        set_error(w.msg);
+        for (auto* r : w.res)
+            if (!r->has_error) { r->has_error = 1; std::snprintf(r->message, sizeof(r->message), "%s", w.msg.c_str()); }
     }
     // single-fragment calls report the fragment's failure as the call's status, like run_cuest_scf
     if (nfrag == 1 && worst != MQC_HIP_OK) return worst;

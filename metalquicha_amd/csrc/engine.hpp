@@ -15,6 +15,7 @@
 #include <vector>
 #include <map>
 #include <memory>
+#include <mutex>
 #include "../../include/mqc_hip.h"
 
 namespace mqc {
@@ -151,7 +152,7 @@ struct mqc_hip_context {
     int c2s_off[8];
     mqc::DevicePool pool_main, pool_eri, pool_topo, pool_misc, pool_grid, pool_gridw, pool_aux, pool_df;
     // second pipeline slot: the next chunk's integrals are formed while the current chunk iterates
-    mqc::DevicePool pool_main2, pool_eri2, pool_misc2, pool_gridw2, pool_df2;
+    mqc::DevicePool pool_main2, pool_eri2, pool_misc2, pool_gridw2, pool_df2, pool_topo2, pool_aux2, pool_grid2;
     hipStream_t stream2 = nullptr;
     hipEvent_t evb0 = nullptr, evb1 = nullptr, evb2 = nullptr, evb3 = nullptr;
     hipEvent_t evq0 = nullptr, evq1 = nullptr, evq2 = nullptr, evq3 = nullptr;   // integral-stage timing per slot
@@ -159,6 +160,10 @@ struct mqc_hip_context {
     int pipeline_min_fragments = 256;   // batches below this run as one chunk
     double* d_unit = nullptr;
     mqc::Stats stats;
+    std::mutex stats_mutex;
+    // topologies of recent calls (shell tables, quartet class lists): an MBE driver sends the same few again and again
+    std::map<std::string, std::shared_ptr<mqc::Topology>> topo_cache;
+    int concurrent_groups = 1;          // 1: topology groups of one batch call run two at a time (one per slot)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     size_t hbm_budget_bytes = 0;
 };
@@ -175,8 +180,10 @@ int build_topology(const mqc_hip_molecule_t& mol, const mqc_hip_basis_t& bas, To
 std::string topology_key(const mqc_hip_molecule_t& mol, const mqc_hip_basis_t& bas);
 double nuclear_repulsion(const Topology& topo, const double* xyz);
 
+// lane < 0: the batch owns both slots (chunks alternate, next chunk prepared ahead); lane 0/1: it runs on that
+// slot only, so that two topology groups can be driven by two host threads at once
 int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, const std::vector<const double*>& xyz,
-              const mqc_hip_scf_options_t& opts, std::vector<mqc_hip_scf_result_t*>& results);
+              const mqc_hip_scf_options_t& opts, std::vector<mqc_hip_scf_result_t*>& results, int lane = -1);
 
 // kernel launchers (kern_*.hip)
 void launch_int1e(const BatchView& bv, const Topology& topo, hipStream_t s);
