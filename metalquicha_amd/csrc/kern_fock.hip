@@ -56,27 +56,70 @@ __device__ __forceinline__ void row_exchange(const double* __restrict__ rowbuf, 
 {
 #pragma unroll
     for (int c = 0; c < KCH; ++c) { acc_i[c] = 0.0; acc_j[c] = 0.0; }
-    double di_reg = 0.0, dj_reg = 0.0;
-    if (DREG) {
-        const int ll = lane < n ? lane : n - 1;
-        di_reg = Di[ll]; dj_reg = Dj[ll];
-    }
-    int lbase = 0;
-#pragma unroll 12
-    for (int l = 0; l < n; ++l) {
-        const double dil = DREG ? readlane_f64(di_reg, l) : Di[l];
-        const double djl = DREG ? readlane_f64(dj_reg, l) : Dj[l];
+    // DREG: Di, Dj are wave-uniform global rows (the caller made i, j scalar): D[i,l], D[j,l] arrive through
+    // the scalar cache (s_load) and enter the FMAs as SGPR operands -- no VALU work, no v_readlane.
+    // l runs in blocks of U: the U LDS reads of a block are issued back to back and only then consumed
+    // (the compiler leaves a rolled loop with one read and a full lgkmcnt(0) wait per l otherwise, and the
+    // kernel spends its time on LDS latency instead of streaming).  Lanes beyond n read a valid (clamped)
+    // address and are discarded at the flush; l beyond n reads element (n-1, .) and is weighted by zero.
+    constexpr int U = 8;
+    int kk[KCH], tri[KCH];
 #pragma unroll
-        for (int c = 0; c < KCH; ++c) {
-            const int k = lane + 64 * c;
-            // lanes beyond n read a valid (clamped) address and are discarded at the flush
-            const int kk = k < n ? k : n - 1;
-            const int idx = kk >= l ? (kk * (kk + 1) / 2 + l) : (lbase + kk);
-            const double v = rowbuf[idx];
-            acc_i[c] += v * djl;
-            acc_j[c] += v * dil;
+    for (int c = 0; c < KCH; ++c) {
+        const int k = lane + 64 * c;
+        kk[c] = k < n ? k : n - 1;
+        tri[c] = kk[c] * (kk[c] + 1) / 2;
+    }
+    for (int l0 = 0; l0 < n; l0 += U) {
+        double v[U][KCH];
+        const bool full = l0 + U <= n;                          // uniform
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int l = (l0 + u < n) ? l0 + u : n - 1;       // uniform
+            const int lbase = l * (l + 1) / 2;                  // uniform
+#pragma unroll
+            for (int c = 0; c < KCH; ++c) {
+                const int idx = kk[c] >= l ? tri[c] + l : lbase + kk[c];
+                v[u][c] = rowbuf[idx];
+            }
         }
-        lbase += l + 1;
+        double dil[U], djl[U];
+        if constexpr (DREG) {
+            // constant address space + uniform address = s_load (one s_load_dwordx16 per row and block):
+            // D is read-only for the whole kernel and the scalar cache is invalidated at kernel start
+            typedef double double8 __attribute__((ext_vector_type(8)));
+            typedef const double8 __attribute__((address_space(4))) * scalar_ptr8;
+            typedef const double __attribute__((address_space(4))) * scalar_ptr;
+            if (full) {
+                const double8 a = *(scalar_ptr8)(Di + l0), b = *(scalar_ptr8)(Dj + l0);
+#pragma unroll
+                for (int u = 0; u < U; ++u) { dil[u] = a[u]; djl[u] = b[u]; }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool live = l0 + u < n;
+                    const int lr = live ? l0 + u : n - 1;
+                    dil[u] = live ? ((scalar_ptr)Di)[lr] : 0.0;
+                    djl[u] = live ? ((scalar_ptr)Dj)[lr] : 0.0;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool live = l0 + u < n;
+                const int lr = live ? l0 + u : n - 1;
+                dil[u] = live ? Di[lr] : 0.0;
+                djl[u] = live ? Dj[lr] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int c = 0; c < KCH; ++c) {
+                acc_i[c] += v[u][c] * djl[u];
+                acc_j[c] += v[u][c] * dil[u];
+            }
+        }
     }
 }
 
@@ -145,7 +188,10 @@ __global__ void __launch_bounds__(64 * NW) jk_incore_kernel(BatchView bv, int on
             accj = wave_sum(accj);
             if (lane == 0) { Jg[i * n + j] = accj; Jg[j * n + i] = accj; }
             double acc_i[KCH], acc_j[KCH];
-            row_exchange<KCH, DREG>(rowbuf, Dsrc + i * n, Dsrc + j * n, n, lane, acc_i, acc_j);
+            {
+                const int iu = __builtin_amdgcn_readfirstlane(i), ju = __builtin_amdgcn_readfirstlane(j);
+                row_exchange<KCH, DREG>(rowbuf, Dsrc + iu * n, Dsrc + ju * n, n, lane, acc_i, acc_j);
+            }
 #pragma unroll
             for (int c = 0; c < KCH; ++c) {
                 const int k = lane + 64 * c;
