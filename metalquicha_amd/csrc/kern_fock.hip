@@ -50,7 +50,7 @@ __device__ __forceinline__ double readlane_f64(double x, int l)
 // One wave's K work for the row held in `rowbuf` (packed lower triangle of V^{ij}).
 // DREG (n <= 64): lane l holds D[i,l] and D[j,l] in registers and the loop broadcasts them with
 // v_readlane; otherwise the two density rows are read through the pointers Di, Dj.
-template <int KCH, bool DREG>
+template <int KCH, bool DREG, bool FULL8>
 __device__ __forceinline__ void row_exchange(const double* __restrict__ rowbuf, const double* __restrict__ Di,
                                              const double* __restrict__ Dj, int n, int lane, double* acc_i, double* acc_j)
 {
@@ -72,15 +72,30 @@ __device__ __forceinline__ void row_exchange(const double* __restrict__ rowbuf, 
     }
     for (int l0 = 0; l0 < n; l0 += U) {
         double v[U][KCH];
-        const bool full = l0 + U <= n;                          // uniform
+        const bool full = FULL8 || l0 + U <= n;                 // uniform; FULL8: n is a multiple of 8, no tail code at all
+        if (full) {
+            // scalar bookkeeping kept to one add per l: tri(l+1) = tri(l) + l + 1
+            int lbase = l0 * (l0 + 1) / 2;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int l = (l0 + u < n) ? l0 + u : n - 1;       // uniform
-            const int lbase = l * (l + 1) / 2;                  // uniform
+            for (int u = 0; u < U; ++u) {
+                const int l = l0 + u;
 #pragma unroll
-            for (int c = 0; c < KCH; ++c) {
-                const int idx = kk[c] >= l ? tri[c] + l : lbase + kk[c];
-                v[u][c] = rowbuf[idx];
+                for (int c = 0; c < KCH; ++c) {
+                    const int idx = kk[c] >= l ? tri[c] + l : lbase + kk[c];
+                    v[u][c] = rowbuf[idx];
+                }
+                lbase += l + 1;
+            }
+        } else if constexpr (!FULL8) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int l = (l0 + u < n) ? l0 + u : n - 1;       // uniform
+                const int lbase = l * (l + 1) / 2;                  // uniform
+#pragma unroll
+                for (int c = 0; c < KCH; ++c) {
+                    const int idx = kk[c] >= l ? tri[c] + l : lbase + kk[c];
+                    v[u][c] = rowbuf[idx];
+                }
             }
         }
         double dil[U], djl[U];
@@ -94,7 +109,7 @@ __device__ __forceinline__ void row_exchange(const double* __restrict__ rowbuf, 
                 const double8 a = *(scalar_ptr8)(Di + l0), b = *(scalar_ptr8)(Dj + l0);
 #pragma unroll
                 for (int u = 0; u < U; ++u) { dil[u] = a[u]; djl[u] = b[u]; }
-            } else {
+            } else if constexpr (!FULL8) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const bool live = l0 + u < n;
@@ -127,12 +142,12 @@ __device__ __forceinline__ void row_exchange(const double* __restrict__ rowbuf, 
 // MAXU == 0: generic variant, the row is loaded in chunks of 16 x 64.
 // KCH = ceil(n / 64).  KLDS: the K accumulator lives in LDS; DREG: density rows through registers
 // (n <= 64), else a copy of D sits in LDS next to K (KLDS) or is read from global memory.
-template <int KCH, bool KLDS, int NW, int MAXU, bool DREG>
+template <int KCH, bool KLDS, int NW, int MAXU, bool DREG, bool FULL8 = false>
 __global__ void __launch_bounds__(64 * NW) jk_incore_kernel(BatchView bv, int only_active)
 {
     extern __shared__ double lds[];
     const int f = blockIdx.y;
-    if (only_active && bv.istate[4 * f] == ST_DONE) return;
+    if ((only_active & 1) && bv.istate[4 * f] == ST_DONE) return;
     const int n = bv.n, np = bv.npair;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -142,8 +157,13 @@ __global__ void __launch_bounds__(64 * NW) jk_incore_kernel(BatchView bv, int on
     double* __restrict__ Kg = bv.K + (size_t)f * n * n;
     const double* __restrict__ M = bv.eri + (size_t)f * np * np;
 
-    double* rowbuf = lds + (size_t)wave * np;        // NW private row buffers
-    double* Dp = lds + (size_t)NW * np;               // packed (2 - delta) D
+    // FULL8 (the tuned dimer variant): row buffers padded to MAXU*64 so that staging needs no bounds test,
+    // and the packed density this lane multiplies with sits in registers for the whole workgroup lifetime
+    constexpr bool TUNED = FULL8 && MAXU > 0;
+    constexpr int MAXU2 = (MAXU + 1) / 2;             // TUNED: 16-byte loads, chunks of 128 doubles (np is even)
+    const int rs = TUNED ? MAXU2 * 128 : np;
+    double* rowbuf = lds + (size_t)wave * rs;        // NW private row buffers
+    double* Dp = lds + (size_t)NW * rs;               // packed (2 - delta) D
     double* Dl = Dp + np;                             // n*n (KLDS && !DREG)
     double* Kl = Dl + ((KLDS && !DREG) ? n * n : 0);  // n*n (KLDS)
 
@@ -163,34 +183,59 @@ __global__ void __launch_bounds__(64 * NW) jk_incore_kernel(BatchView bv, int on
     int row = blockIdx.x * NW + wave;
 
     if constexpr (MAXU > 0) {
-        double v[MAXU];
-        if (row < np) {
-            const double* __restrict__ src = M + (size_t)row * np;
+        typedef double double2v __attribute__((ext_vector_type(2)));
+        double v[TUNED ? 1 : MAXU];
+        double2v v2[TUNED ? MAXU2 : 1], dp2[TUNED ? MAXU2 : 1];
+        auto load_row = [&](int r) {
+            const double* __restrict__ src = M + (size_t)r * np;
+            if constexpr (TUNED) {
 #pragma unroll
-            for (int u = 0; u < MAXU; ++u) { const int idx = lane + 64 * u; v[u] = idx < np ? src[idx] : 0.0; }
+                for (int u = 0; u < MAXU2; ++u) {
+                    const int idx = 2 * lane + 128 * u;
+                    v2[u] = idx < np ? *(const double2v*)(src + idx) : (double2v){0.0, 0.0};
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < MAXU; ++u) { const int idx = lane + 64 * u; v[u] = idx < np ? src[idx] : 0.0; }
+            }
+        };
+        if constexpr (TUNED) {
+#pragma unroll
+            for (int u = 0; u < MAXU2; ++u) {
+                const int idx = 2 * lane + 128 * u;
+                dp2[u] = idx < np ? *(const double2v*)(Dp + idx) : (double2v){0.0, 0.0};
+            }
         }
+        if (row < np) load_row(row);
         while (row < np) {
             int i, j;
             unpack_pair(row, i, j);
             double accj = 0.0;
+            if constexpr (TUNED) {
 #pragma unroll
-            for (int u = 0; u < MAXU; ++u) {
-                const int idx = lane + 64 * u;
-                if (idx < np) { rowbuf[idx] = v[u]; accj += v[u] * Dp[idx]; }
+                for (int u = 0; u < MAXU2; ++u) {
+                    *(double2v*)(rowbuf + 2 * lane + 128 * u) = v2[u];
+                    accj += v2[u][0] * dp2[u][0] + v2[u][1] * dp2[u][1];
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < MAXU; ++u) {
+                    const int idx = lane + 64 * u;
+                    if (idx < np) { rowbuf[idx] = v[u]; accj += v[u] * Dp[idx]; }
+                }
             }
             // issue the next row's loads now; they complete while this row is being contracted
             const int nrow = row + stride;
-            if (nrow < np) {
-                const double* __restrict__ src = M + (size_t)nrow * np;
-#pragma unroll
-                for (int u = 0; u < MAXU; ++u) { const int idx = lane + 64 * u; v[u] = idx < np ? src[idx] : 0.0; }
-            }
+            if (nrow < np) load_row(nrow);
             accj = wave_sum(accj);
             if (lane == 0) { Jg[i * n + j] = accj; Jg[j * n + i] = accj; }
             double acc_i[KCH], acc_j[KCH];
-            {
+            if (only_active & 2) {       // measurement switch (MQC_HIP_JK_SKIP_EXCHANGE=1): stream + J only, K is wrong
+#pragma unroll
+                for (int c = 0; c < KCH; ++c) { acc_i[c] = 0.0; acc_j[c] = 0.0; }
+            } else {
                 const int iu = __builtin_amdgcn_readfirstlane(i), ju = __builtin_amdgcn_readfirstlane(j);
-                row_exchange<KCH, DREG>(rowbuf, Dsrc + iu * n, Dsrc + ju * n, n, lane, acc_i, acc_j);
+                row_exchange<KCH, DREG, FULL8>(rowbuf, Dsrc + iu * n, Dsrc + ju * n, n, lane, acc_i, acc_j);
             }
 #pragma unroll
             for (int c = 0; c < KCH; ++c) {
@@ -223,7 +268,7 @@ __global__ void __launch_bounds__(64 * NW) jk_incore_kernel(BatchView bv, int on
             accj = wave_sum(accj);
             if (lane == 0) { Jg[i * n + j] = accj; Jg[j * n + i] = accj; }
             double acc_i[KCH], acc_j[KCH];
-            row_exchange<KCH, DREG>(rowbuf, Dsrc + i * n, Dsrc + j * n, n, lane, acc_i, acc_j);
+            row_exchange<KCH, DREG, false>(rowbuf, Dsrc + i * n, Dsrc + j * n, n, lane, acc_i, acc_j);
 #pragma unroll
             for (int c = 0; c < KCH; ++c) {
                 const int k = lane + 64 * c;
@@ -255,10 +300,10 @@ static int jk_grid_x(const BatchView& bv, int nw)
     return want;
 }
 
-template <int KCH, bool KLDS, int NW, int MAXU, bool DREG>
+template <int KCH, bool KLDS, int NW, int MAXU, bool DREG, bool FULL8 = false>
 static void jk_launch(const BatchView& bv, int oa, size_t lds, hipStream_t s)
 {
-    auto kern = jk_incore_kernel<KCH, KLDS, NW, MAXU, DREG>;
+    auto kern = jk_incore_kernel<KCH, KLDS, NW, MAXU, DREG, FULL8>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid(jk_grid_x(bv, NW), bv.nfrag), block(64 * NW);
     hipLaunchKernelGGL(kern, grid, block, lds, s, bv, oa);
@@ -269,7 +314,8 @@ void launch_jk_incore(const BatchView& bv, bool only_active, hipStream_t s)
     const int n = bv.n, np = bv.npair;
     (void)hipMemsetAsync(bv.K, 0, sizeof(double) * (size_t)bv.nfrag * n * n, s);
     const int kch = (n + 63) / 64;
-    const int oa = only_active ? 1 : 0;
+    static const int skip_exchange = [] { const char* e = std::getenv("MQC_HIP_JK_SKIP_EXCHANGE"); return (e && e[0] == '1') ? 2 : 0; }();
+    const int oa = (only_active ? 1 : 0) | skip_exchange;
     const size_t LDS_MAX = 160 * 1024 - 1024;
     const size_t lds_reg = sizeof(double) * ((size_t)5 * np + (size_t)n * n);      // 4 waves, K in LDS, D in registers
     const size_t lds4k = sizeof(double) * ((size_t)5 * np + 2 * (size_t)n * n);   // 4 waves, D and K in LDS
@@ -280,6 +326,8 @@ void launch_jk_incore(const BatchView& bv, bool only_active, hipStream_t s)
         // dimer-sized fragments in a large batch: one 12-wave workgroup per CU (141 KB of LDS for n = 48)
         // keeps 12 x 9.4 KB of row loads in flight per CU instead of 8 x
         if (np <= 10 * 64) jk_launch<1, true, 12, 10, true>(bv, oa, lds_reg12, s);
+        else if (n % 8 == 0 && np % 2 == 0 && sizeof(double) * ((size_t)12 * 10 * 128 + np + (size_t)n * n) <= LDS_MAX)
+            jk_launch<1, true, 12, 19, true, true>(bv, oa, sizeof(double) * ((size_t)12 * 10 * 128 + np + (size_t)n * n), s);
         else jk_launch<1, true, 12, 19, true>(bv, oa, lds_reg12, s);
     } else if (n <= 64 && lds_reg <= LDS_MAX) {
         // the fragment sizes of an MBE run (n = 48: 65.5 KB -> two workgroups per CU)
