@@ -72,6 +72,56 @@ __device__ void wg_gemm(int M, int N, int K, const double* __restrict__ A, int l
     __syncthreads();
 }
 
+// ---------------------------------------------------------------------------------------
+// Workgroup GEMM on the FP64 matrix cores: C = op(A) op(B), one 16 x 16 output tile per wave at a time
+// (v_mfma_f64_16x16x4_f64; operand layout of the guide: A[i = lane&15][k = lane>>4],
+// B[k = lane>>4][j = lane&15], C[row = (lane>>4) + 4 r][col = lane&15]).  Operands are read straight from
+// where they live (global/L2 or LDS): every lane fetches one element per operand and k-step, sixteen k at a
+// time so that eight loads are in flight before the four MFMAs that consume them.  Edges are zero-filled.
+//   TA: A is stored K x M (A[k*lda + i]) instead of M x K;  TB: B is stored N x K (B[j*ldb + k]).
+//   store(i, j, value) receives every element of the M x N result once.
+// The scalar loops this replaces spent ~17 VALU instructions per multiply-add on addressing.
+typedef double v4f64_t __attribute__((ext_vector_type(4)));
+
+template <bool TA, bool TB, class Store>
+__device__ __forceinline__ void wg_gemm_mfma(int M, int N, int K, const double* A, int lda, const double* B, int ldb, Store store)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lo = lane & 15, hi = lane >> 4;
+    const int mt = (M + 15) >> 4, nt = (N + 15) >> 4;
+    for (int t = wave; t < mt * nt; t += NT / 64) {
+        const int ti = t / nt, tj = t - ti * nt;
+        const int i = 16 * ti + lo, j = 16 * tj + lo;
+        const bool iok = i < M, jok = j < N;
+        const int ic = iok ? i : 0, jc = jok ? j : 0;
+        v4f64_t acc = {0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < K; k0 += 16) {
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + 4 * u + hi;
+                const bool kok = k < K;
+                const int kc = kok ? k : 0;
+                const double av = TA ? A[kc * lda + ic] : A[ic * lda + kc];
+                const double bv_ = TB ? B[jc * ldb + kc] : B[kc * ldb + jc];
+                a[u] = (iok && kok) ? av : 0.0;
+                b[u] = (jok && kok) ? bv_ : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * ti + hi + 4 * r, col = 16 * tj + lo;
+            if (row < M && col < N) store(row, col, acc[r]);
+        }
+    }
+    __syncthreads();
+}
+
+// 1: rotation sets in which no pair exceeds the threshold skip their update phases (MQC_HIP_JACOBI_SKIP=0 turns it off)
+__device__ int g_jacobi_skip_idle_sets = 1;
+
 struct JacobiLds {
     double* A;      // mp x lda
     double* V;      // mp x lda (LDS) or global m x ldv
@@ -80,7 +130,7 @@ struct JacobiLds {
     int* rp;        // mp/2
     int* rq;        // mp/2
     double* red;    // 8
-    int* flag;      // 2
+    int* flag;      // 4: sweep flag + three rotating per-set flags
     int lda;
 };
 
@@ -143,9 +193,13 @@ __device__ void jacobi_eig(JacobiLds& jl, int m, int ldv, const double* __restri
     __syncthreads();
 
     for (int sweep = 0; sweep < JACOBI_MAX_SWEEPS; ++sweep) {
-        if (tid == 0) jl.flag[0] = 0;
+        if (tid == 0) { jl.flag[0] = 0; jl.flag[1] = 0; jl.flag[2] = 0; jl.flag[3] = 0; }
         __syncthreads();
         for (int r = 0; r < mp - 1; ++r) {
+            // flag[1 + r % 3]: does this rotation set rotate anything?  With a warm start most sets of the late
+            // sweeps do not, and their two update phases (and barriers) are skipped.  Three slots in rotation:
+            // the slot reset here was last read two sets ago, i.e. before a barrier every thread has passed.
+            if (tid == 0) jl.flag[1 + (r + 1) % 3] = 0;
             if (tid < half) {
                 int p, q;
                 if (tid == 0) { p = mp - 1; q = r; }
@@ -160,10 +214,12 @@ __device__ void jacobi_eig(JacobiLds& jl, int m, int ldv, const double* __restri
                     c = 1.0 / sqrt(t * t + 1.0);
                     s = t * c;
                     jl.flag[0] = 1;
+                    jl.flag[1 + r % 3] = 1;
                 }
                 jl.rc[tid] = c; jl.rs[tid] = s; jl.rp[tid] = p; jl.rq[tid] = q;
             }
             __syncthreads();
+            if (g_jacobi_skip_idle_sets && jl.flag[1 + r % 3] == 0) continue;
             // rows: A <- J^T A
             for (int idx = tid; idx < half * mp; idx += NT) {
                 const int k = idx / mp, col = idx - k * mp;
@@ -281,33 +337,16 @@ __device__ void diagonalize_and_density(const BatchView& bv, FragPtrs& p, Jacobi
     const int mp = even_up(m), lda = jl.lda;
     const int ldv = VLDS ? lda : m;
     if (!VLDS) jl.V = Vg;
-    wg_gemm<false>(n, m, n, p.F, n, p.X, n, T, n);
+    wg_gemm_mfma<false, false>(n, m, n, p.F, n, p.X, n, [&](int i, int j, double v) { T[i * n + j] = v; });
     for (int idx = tid; idx < mp * lda; idx += NT) jl.A[idx] = 0.0;
     __syncthreads();
     // F' = X^T (F X) straight into LDS
-    for (int idx = tid; idx < m * m; idx += NT) {
-        const int i = idx / m, j = idx - i * m;
-        double s = 0.0;
-        for (int k = 0; k < n; ++k) s += p.X[k * n + i] * T[k * n + j];
-        jl.A[i * lda + j] = s;
-    }
-    __syncthreads();
+    double* const Alds = jl.A;
+    wg_gemm_mfma<true, false>(m, m, n, p.X, n, T, n, [&](int i, int j, double v) { Alds[i * lda + j] = v; });
     if (WARM) {
         // T = F' Vp  (m x m, ld n), then F'' = Vp^T T back into LDS
-        for (int idx = tid; idx < m * m; idx += NT) {
-            const int i = idx / m, j = idx - i * m;
-            double s = 0.0;
-            for (int k = 0; k < m; ++k) s += jl.A[i * lda + k] * Vp[k * n + j];
-            T[i * n + j] = s;
-        }
-        __syncthreads();
-        for (int idx = tid; idx < m * m; idx += NT) {
-            const int i = idx / m, j = idx - i * m;
-            double s = 0.0;
-            for (int k = 0; k < m; ++k) s += Vp[k * n + i] * T[k * n + j];
-            jl.A[i * lda + j] = s;
-        }
-        __syncthreads();
+        wg_gemm_mfma<false, false>(m, m, m, Alds, lda, Vp, n, [&](int i, int j, double v) { T[i * n + j] = v; });
+        wg_gemm_mfma<true, false>(m, m, m, Vp, n, T, n, [&](int i, int j, double v) { Alds[i * lda + j] = v; });
     }
     // symmetrise (F' is symmetric up to rounding; Jacobi assumes exact symmetry)
     for (int idx = tid; idx < m * m; idx += NT) {
@@ -332,23 +371,12 @@ __device__ void diagonalize_and_density(const BatchView& bv, FragPtrs& p, Jacobi
         p.eps[r] = jl.A[i * lda + i];
     }
     __syncthreads();
-    for (int idx = tid; idx < n * m; idx += NT) {
-        const int r = idx / m, i = idx - r * m;    // C[r][rank[i]] = sum_k X[r][k] V[k][i]
-        double s = 0.0;
-        for (int k = 0; k < m; ++k) s += p.X[r * n + k] * jl.V[k * ldv + i];
-        p.C[r * n + rank[i]] = s;
-    }
-    __syncthreads();
+    // C[r][rank[i]] = sum_k X[r][k] V[k][i]
+    double* const Cg = p.C;
+    wg_gemm_mfma<false, false>(n, m, m, p.X, n, jl.V, ldv, [&](int r, int i, double v) { Cg[r * n + rank[i]] = v; });
     // D = 2 C_occ C_occ^T
-    const int nocc = bv.nocc;
-    for (int idx = tid; idx < n * n; idx += NT) {
-        const int i = idx / n, j = idx - i * n;
-        if (j > i) continue;
-        double s = 0.0;
-        for (int o = 0; o < nocc; ++o) s += p.C[i * n + o] * p.C[j * n + o];
-        p.D[i * n + j] = 2.0 * s; p.D[j * n + i] = 2.0 * s;
-    }
-    __syncthreads();
+    double* const Dg = p.D;
+    wg_gemm_mfma<false, true>(n, n, bv.nocc, Cg, n, Cg, n, [&](int i, int j, double v) { Dg[i * n + j] = 2.0 * v; });
 }
 
 // Starting Fock (core or GWH, guess_fock mqc_libcint_rhf.f90:1354-1380), then the first density.
@@ -463,15 +491,15 @@ __global__ void __launch_bounds__(NT) scf_step_kernel(BatchView bv)
 
     // ---- DIIS error e = X^T (F D S - S D F) X   (commutator :1326-1352)
     double* W0 = p.W; double* W1 = p.W + nn; double* W2 = p.W + 2 * nn; double* Err = p.W + 5 * nn;
-    wg_gemm<false>(n, n, n, p.F, n, p.D, n, W0, n);          // F D
-    wg_gemm<false>(n, n, n, W0, n, p.S, n, W1, n);           // F D S
+    wg_gemm_mfma<false, false>(n, n, n, p.F, n, p.D, n, [&](int i, int j, double v) { W0[i * n + j] = v; });     // F D
+    wg_gemm_mfma<false, false>(n, n, n, W0, n, p.S, n, [&](int i, int j, double v) { W1[i * n + j] = v; });       // F D S
     for (int idx = tid; idx < n * n; idx += NT) {            // A - A^T  (S D F = (F D S)^T)
         const int i = idx / n, j = idx - i * n;
         W0[idx] = W1[idx] - W1[j * n + i];
     }
     __syncthreads();
-    wg_gemm<false>(n, m, n, W0, n, p.X, n, W2, n);           // (.) X      n x m
-    wg_gemm<true>(m, m, n, p.X, n, W2, n, Err, m);           // X^T (.)    m x m, ld m
+    wg_gemm_mfma<false, false>(n, m, n, W0, n, p.X, n, [&](int i, int j, double v) { W2[i * n + j] = v; });       // (.) X      n x m
+    wg_gemm_mfma<true, false>(m, m, n, p.X, n, W2, n, [&](int i, int j, double v) { Err[i * m + j] = v; });       // X^T (.)    m x m, ld m
 
     // ---- DIIS push / extrapolate (mqc_diis.f90:113-162; RHF extrapolates from the first iteration)
     const int maxv = bv.diis_size;
@@ -583,8 +611,19 @@ void launch_guess(const BatchView& bv, int guess_kind, hipStream_t s)
     else launch_wg(guess_kernel<false>, bv.nfrag, lds, s, bv, guess_kind);
 }
 
+static void apply_jacobi_env()
+{
+    static const bool done = [] {
+        const char* e = std::getenv("MQC_HIP_JACOBI_SKIP");
+        if (e && e[0] == '0') { const int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_jacobi_skip_idle_sets), &z, sizeof(int)); }
+        return true;
+    }();
+    (void)done;
+}
+
 void launch_scf_step(const BatchView& bv, hipStream_t s)
 {
+    apply_jacobi_env();
     const size_t lds = scf_lds_bytes(bv.n);
     if (v_in_lds(bv.n)) launch_wg(scf_step_kernel<true>, bv.nfrag, lds, s, bv);
     else launch_wg(scf_step_kernel<false>, bv.nfrag, lds, s, bv);
