@@ -792,6 +792,8 @@ int mqc_hip_eri_packed(mqc_hip_context* ctx, const mqc_hip_molecule_t* mol, cons
     StageBatch sb;
     int rc = stage_setup(ctx, mol, bas, true, sb);
     if (rc != MQC_HIP_OK) return rc;
+    // stage-level check of the tensor: poison it first, so that an element no class list covers shows up as NaN
+    HIP_CHECK_RET(hipMemsetAsync(sb.bv.eri, 0xFF, sizeof(double) * (size_t)sb.topo.npair * sb.topo.npair, ctx->stream));
     launch_eri(sb.bv, sb.topo, schwarz_tol, ctx->stream);
     HIP_CHECK_RET(hipStreamSynchronize(ctx->stream));
     HIP_CHECK_RET(hipGetLastError());
