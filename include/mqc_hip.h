@@ -187,6 +187,9 @@ typedef struct {
     double eri_kernel_seconds;
     double xc_kernel_seconds;     /* HIP-event time of the XC quadrature kernel, last batch */
     double xc_points;             /* grid points it integrated (fragments x points, summed over launches) */
+    /* the same three J/K figures restricted to launches that streamed >= 1 GiB (the dominant kernel of a large batch) */
+    int64_t fock_big_launches;
+    double fock_big_seconds, fock_big_bytes;
 } mqc_hip_stats_t;
 int mqc_hip_get_stats(mqc_hip_context *ctx, mqc_hip_stats_t *stats);
 int mqc_hip_device_name(mqc_hip_context *ctx, char *buf, int32_t len);

@@ -63,7 +63,8 @@ class Stats(C.Structure):
                 ("fock_launches", C.c_int64), ("eri_quartets", C.c_int64),
                 ("scf_iterations_total", C.c_int64), ("fock_kernel_seconds", C.c_double),
                 ("fock_bytes", C.c_double), ("eri_kernel_seconds", C.c_double),
-                ("xc_kernel_seconds", C.c_double), ("xc_points", C.c_double)]
+                ("xc_kernel_seconds", C.c_double), ("xc_points", C.c_double),
+                ("fock_big_launches", C.c_int64), ("fock_big_seconds", C.c_double), ("fock_big_bytes", C.c_double)]
 
 
 DECLARED_SYMBOLS = [

@@ -391,10 +391,14 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
             HIP_CHECK_RET(hipStreamSynchronize(s));
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, sl.e0, sl.e1);
+            const double launch_bytes = use_df ? (double)remaining * 2.0 * (double)naux * (double)np * 8.0
+                                               : (double)remaining * (double)np * (double)np * 8.0;
             sx->stats.fock_kernel_seconds += ms * 1e-3;
-            sx->stats.fock_bytes += use_df ? (double)remaining * 2.0 * (double)naux * (double)np * 8.0
-                                            : (double)remaining * (double)np * (double)np * 8.0;
+            sx->stats.fock_bytes += launch_bytes;
             sx->stats.fock_launches += 1;
+            if (launch_bytes >= 1073741824.0) {
+                sx->stats.fock_big_launches += 1; sx->stats.fock_big_seconds += ms * 1e-3; sx->stats.fock_big_bytes += launch_bytes;
+            }
             if (xc.ncomp > 0) {
                 float mx = 0.f;
                 (void)hipEventElapsedTime(&mx, sl.e2, sl.e3);
@@ -481,6 +485,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         g.scf_iterations_total += l.scf_iterations_total; g.fock_kernel_seconds += l.fock_kernel_seconds;
         g.fock_bytes += l.fock_bytes; g.eri_kernel_seconds += l.eri_kernel_seconds;
         g.xc_kernel_seconds += l.xc_kernel_seconds; g.xc_points += l.xc_points;
+        g.fock_big_launches += l.fock_big_launches; g.fock_big_seconds += l.fock_big_seconds; g.fock_big_bytes += l.fock_big_bytes;
     }
     return MQC_HIP_OK;
 }
@@ -606,6 +611,8 @@ int mqc_hip_get_stats(mqc_hip_context* ctx, mqc_hip_stats_t* st)
     st->fock_kernel_seconds = ctx->stats.fock_kernel_seconds; st->fock_bytes = ctx->stats.fock_bytes;
     st->eri_kernel_seconds = ctx->stats.eri_kernel_seconds;
     st->xc_kernel_seconds = ctx->stats.xc_kernel_seconds; st->xc_points = ctx->stats.xc_points;
+    st->fock_big_launches = ctx->stats.fock_big_launches; st->fock_big_seconds = ctx->stats.fock_big_seconds;
+    st->fock_big_bytes = ctx->stats.fock_big_bytes;
     ctx->stats = Stats();
     return MQC_HIP_OK;
 }

@@ -138,6 +138,8 @@ struct Stats {
     double t_setup = 0, t_int1e = 0, t_eri = 0, t_fock = 0, t_scf_step = 0, t_total = 0;
     int64_t fock_launches = 0, eri_quartets = 0, scf_iterations_total = 0;
     double fock_kernel_seconds = 0, fock_bytes = 0, eri_kernel_seconds = 0, xc_kernel_seconds = 0, xc_points = 0;
+    int64_t fock_big_launches = 0;
+    double fock_big_seconds = 0, fock_big_bytes = 0;
 };
 
 }  // namespace mqc

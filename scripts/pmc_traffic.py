@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turns two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs as the MI355X guide
 prescribes) of `python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline` into
-profiles/r01_pmc_traffic.json for the dominant kernel (jk_incore_kernel, dimer variant).
+profiles/r01_pmc_traffic.json for the dominant kernel (jk_incore_kernel, 12-wave dimer variant).
 
 gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B per 128-B request on wide
 coalesced streams -> doubled; both counters are in KiB.
@@ -17,7 +17,7 @@ import sys
 
 
 def per_launch(directory, counter, kernel_substr):
-    f = glob.glob(os.path.join(directory, "*", "*counter_collection.csv"))[0]
+    f = (glob.glob(os.path.join(directory, "*counter_collection.csv")) + glob.glob(os.path.join(directory, "*", "*counter_collection.csv")))[0]
     tot, disp = 0.0, set()
     for r in csv.DictReader(open(f)):
         if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter:
@@ -27,7 +27,7 @@ def per_launch(directory, counter, kernel_substr):
 
 def main():
     fetch_dir, write_dir = sys.argv[1], sys.argv[2]
-    kern = "jk_incore_kernel<1, true, 4, 19, true>"
+    kern = "jk_incore_kernel<1, true, 12, 19, true, true>"      # the 12-wave tuned dimer variant
     fetch_kib, nf = per_launch(fetch_dir, "FETCH_SIZE", kern)
     write_kib, nw = per_launch(write_dir, "WRITE_SIZE", kern)
     out = {
