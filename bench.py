@@ -2,7 +2,8 @@
 """bench.py -- the reference's headline workload on MI355X.
 
 Workload (BASELINE.json metric "SCF iterations/sec per GPU; MBE-2 wall-time @64 frags",
-configs[2]): the (H2O)64 cluster, MBE level 2, RHF/cc-pVDZ, exact ERIs, no distance cutoff:
+configs[2]): the (H2O)64 cluster, MBE level 2, RHF/cc-pVDZ, exact four-centre ERIs held in HBM (Schwarz-screened at
+1e-12 by default -- the north star's wavefront-level screening; --schwarz-tol 0 forms every quartet), no distance cutoff:
 64 monomer + 2016 dimer SCFs = 2080 fragments.  One "step" = one complete MBE-2 energy
 evaluation: every owned fragment through the engine (int1e -> ERI -> SCF to convergence with
 the reference's dE / rms(dD) test and final rebuild), then ONE all-reduce of the zero-padded
@@ -48,6 +49,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=20, help="dimers in the CPU-baseline sample")
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra B3LYP and DF measurements")
+    ap.add_argument("--schwarz-tol", type=float, default=1e-12,
+                    help="Schwarz threshold of the in-core ERI build (0 = every quartet); 1e-12 moves a fragment energy by < 1e-11 Eh")
     return ap.parse_args()
 
 
@@ -106,7 +109,7 @@ def main():
     terms = mbe.generate_mbe_term_list(system, 2)
     settings = methods.ScfSettings(basis_set=args.basis, functional=args.functional, guess="gwh", energy_tol=1e-8,
                                    density_tol=1e-6, device_rank=local_rank, density_fitting=args.df,
-                                   aux_basis_set="mqc-even-tempered-jkfit")
+                                   aux_basis_set="mqc-even-tempered-jkfit", schwarz_tol=args.schwarz_tol)
 
     def barrier():
         if world > 1:
@@ -160,7 +163,7 @@ def main():
         for label, kw in (("b3lyp_exact_eri", dict(functional="b3lyp")),
                           ("rhf_density_fitted", dict(density_fitting=True)),
                           ("b3lyp_density_fitted", dict(functional="b3lyp", density_fitting=True))):
-            s2 = methods.ScfSettings(basis_set=args.basis, guess="gwh", energy_tol=1e-8, density_tol=1e-6,
+            s2 = methods.ScfSettings(basis_set=args.basis, guess="gwh", energy_tol=1e-8, density_tol=1e-6, schwarz_tol=args.schwarz_tol,
                                      device_rank=local_rank, aux_basis_set="mqc-even-tempered-jkfit", **kw)
             mbe.run_mbe(system, s2, level=2, rank=rank, world=world, terms=terms)
             methods.get_stats()
@@ -193,7 +196,7 @@ def main():
         if big_n == 0:       # small workloads (--side 2): fall back to all launches
             big_s, big_b, big_n = st.fock_kernel_seconds, st.fock_bytes, int(st.fock_launches)
         eri_s = st.eri_kernel_seconds
-        traffic = pmc_traffic_bytes_per_launch() if (args.side == 4 and args.basis == "cc-pvdz" and not args.df) else None
+        traffic = pmc_traffic_bytes_per_launch() if (args.side == 4 and args.basis == "cc-pvdz" and not args.df and world == 1) else None
         roof = {"bound": "hbm", "kernel": "jk_incore_kernel", "achieved": (big_b / big_s / 1e9) if big_s > 0 else None,
                 "peak": 8000.0, "unit": "GB/s", "frac": (big_b / big_s / 1e9 / 8000.0) if big_s > 0 else None,
                 "traffic": traffic, "kernel_seconds": big_s, "launches": big_n,
@@ -217,7 +220,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "(H2O)%d MBE-2 %s/%s, %s, %d SCFs (%d monomers + %d dimers), GWH guess, e_tol 1e-8 d_tol 1e-6%s"
                                    % (system.n_monomers, (args.functional.upper() or "RHF"), args.basis,
-                                      "density-fitted J/K (even-tempered aux)" if args.df else "exact in-core ERIs",
+                                      "density-fitted J/K (even-tempered aux)" if args.df else
+                                      ("exact in-core ERIs, Schwarz-screened at %.0e" % args.schwarz_tol if args.schwarz_tol > 0 else "exact in-core ERIs, unscreened"),
                                       len(terms), system.n_monomers, len(terms) - system.n_monomers,
                                       ", grid level 3 (pruned)" if args.functional else ""),
                        "fragments": len(terms), "parallelism": "fragments round-robin over %d GPU(s)" % world},

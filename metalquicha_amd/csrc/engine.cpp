@@ -336,6 +336,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         const double t1 = now_s();
         sx->stats.t_setup += t1 - t0;
 
+        if (!use_df && !use_direct) launch_eri_bounds(bv, topo, stol, s);     // screened build: bounds run next to the 1e stage
         launch_int1e(bv, topo, s);
         if ((rc = stage_check("int1e")) != MQC_HIP_OK) return rc;
         launch_orthogonalizer(bv, s);

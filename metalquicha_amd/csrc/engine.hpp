@@ -191,6 +191,8 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
 void launch_int1e(const BatchView& bv, const Topology& topo, hipStream_t s);
 // host_xyz (optional, [nfrag][natoms][3] as uploaded): enables block sharing between fragments with identical atoms
 void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, hipStream_t s, const double* host_xyz = nullptr);
+// optional head start of the screened build (bounds + zero fill on side streams); launch_eri joins it
+void launch_eri_bounds(const BatchView& bv, const Topology& topo, double schwarz_tol, hipStream_t s);
 void launch_jk_incore(const BatchView& bv, bool only_active, hipStream_t s);
 void launch_direct_setup(const BatchView& bv, const Topology& topo, hipStream_t s);
 void launch_jk_direct(const BatchView& bv, const Topology& topo, double thresh, bool only_active, hipStream_t s);

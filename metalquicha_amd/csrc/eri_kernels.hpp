@@ -208,16 +208,32 @@ constexpr int TWIN_FLAG = 1 << 16;
 
 template <int LA, int LB, int LC, int LD>
 __global__ void __launch_bounds__(64) eri_twin_kernel(BatchView bv, const int* __restrict__ quartets, int nquart,
-                                                      const int* __restrict__ tasks, int ntasks)
+                                                      const int* __restrict__ tasks, int ntasks,
+                                                      const double* __restrict__ Q, double thresh)
 {
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = tasks ? (long)ntasks : (long)nquart * bv.nfrag;
-    if (tid >= total) return;
-    const int iq = tasks ? tasks[2 * tid] : (int)(tid / bv.nfrag), f = tasks ? tasks[2 * tid + 1] : (int)(tid % bv.nfrag);
+    const bool live = tid < total;
+    const long t = live ? tid : total - 1;
+    const int iq = tasks ? tasks[2 * t] : (int)(t / bv.nfrag), f = tasks ? tasks[2 * t + 1] : (int)(t % bv.nfrag);
     const int eA = quartets[4 * iq], eB = quartets[4 * iq + 1], eC = quartets[4 * iq + 2], eD = quartets[4 * iq + 3];
     const int A = eA & (TWIN_FLAG - 1), B = eB & (TWIN_FLAG - 1), C = eC & (TWIN_FLAG - 1), D = eD & (TWIN_FLAG - 1);
     const bool tA = (eA & TWIN_FLAG) != 0, tB = (eB & TWIN_FLAG) != 0, tC = (eC & TWIN_FLAG) != 0, tD = (eD & TWIN_FLAG) != 0;
     const TopologyDev& tp = bv.topo;
+    bool keep = live;
+    if (Q != nullptr) {
+        // Schwarz bound of the entry = the largest bound of its member combinations
+        const int ns = tp.nshell;
+        const double* q = Q + (size_t)f * ns * ns;
+        double qab = 0.0, qcd = 0.0;
+        for (int ma = 0; ma <= (tA ? 1 : 0); ++ma)
+            for (int mb = 0; mb <= (tB ? 1 : 0); ++mb) qab = fmax(qab, q[(A + ma) * ns + B + mb]);
+        for (int mc = 0; mc <= (tC ? 1 : 0); ++mc)
+            for (int md = 0; md <= (tD ? 1 : 0); ++md) qcd = fmax(qcd, q[(C + mc) * ns + D + md]);
+        keep = live && (qab * qcd >= thresh);
+    }
+    if (__ballot(keep) == 0ull) return;
+    if (!keep) return;
     const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
     const ShellRef sa = make_shell(tp, xyz, A), sb = make_shell(tp, xyz, B), sc = make_shell(tp, xyz, C), sd = make_shell(tp, xyz, D);
     TwinCoefs tw;
@@ -496,11 +512,12 @@ void launch_eri_class(const BatchView& bv, const int* d_list, int nq, const int*
 }
 
 template <int LA, int LB, int LC, int LD>
-void launch_eri_twin_class(const BatchView& bv, const int* d_list, int nq, const int* d_tasks, int ntasks, hipStream_t s)
+void launch_eri_twin_class(const BatchView& bv, const int* d_list, int nq, const int* d_tasks, int ntasks,
+                           const double* Q, double thresh, hipStream_t s)
 {
     const long total = d_tasks ? (long)ntasks : (long)nq * bv.nfrag;
     if (nq == 0 || total == 0) return;
-    hipLaunchKernelGGL((eri_twin_kernel<LA, LB, LC, LD>), dim3((int)((total + 63) / 64)), dim3(64), 0, s, bv, d_list, nq, d_tasks, ntasks);
+    hipLaunchKernelGGL((eri_twin_kernel<LA, LB, LC, LD>), dim3((int)((total + 63) / 64)), dim3(64), 0, s, bv, d_list, nq, d_tasks, ntasks, Q, thresh);
 }
 
 template <int LA, int LB>

@@ -19,7 +19,7 @@ ERI_DECL(2, 0, 0, 0) ERI_DECL(2, 0, 1, 0) ERI_DECL(2, 0, 1, 1) ERI_DECL(2, 0, 2,
 ERI_DECL(2, 1, 0, 0) ERI_DECL(2, 1, 1, 0) ERI_DECL(2, 1, 1, 1) ERI_DECL(2, 1, 2, 0) ERI_DECL(2, 1, 2, 1)
 ERI_DECL(2, 2, 0, 0) ERI_DECL(2, 2, 1, 0) ERI_DECL(2, 2, 1, 1) ERI_DECL(2, 2, 2, 0) ERI_DECL(2, 2, 2, 1) ERI_DECL(2, 2, 2, 2)
 #define TWIN_DECL(a, b, c, d) \
-    extern template void launch_eri_twin_class<a, b, c, d>(const BatchView&, const int*, int, const int*, int, hipStream_t);
+    extern template void launch_eri_twin_class<a, b, c, d>(const BatchView&, const int*, int, const int*, int, const double*, double, hipStream_t);
 TWIN_DECL(0, 0, 0, 0) TWIN_DECL(1, 0, 0, 0) TWIN_DECL(1, 0, 1, 0) TWIN_DECL(1, 1, 0, 0)
 TWIN_DECL(1, 1, 1, 0) TWIN_DECL(2, 0, 0, 0) TWIN_DECL(2, 0, 1, 0) TWIN_DECL(2, 1, 0, 0)
 SCHWARZ_DECL(0, 0) SCHWARZ_DECL(1, 0) SCHWARZ_DECL(1, 1) SCHWARZ_DECL(2, 0) SCHWARZ_DECL(2, 1) SCHWARZ_DECL(2, 2)
@@ -185,6 +185,12 @@ constexpr int ERI_SIDE_STREAMS = 4;    // task-list launches of different classe
 struct EriSlotState {
     EriListCache cache[ERI_CACHE_WAYS];
     int next = 0;
+    // Schwarz bounds + zero fill started ahead of the one-electron stage (launch_eri_bounds), joined by launch_eri
+    bool bounds_pending = false;
+    double* Q = nullptr;
+    double bounds_tol = 0.0;
+    std::vector<int> bucket[KERNEL_LMAX + 1][KERNEL_LMAX + 1];   // shell pairs by class, kept alive for the async upload
+    DevicePool qpool, pairs;
     hipStream_t side[ERI_SIDE_STREAMS] = {};
     hipEvent_t fork = nullptr, join[ERI_SIDE_STREAMS] = {};
 };
@@ -197,12 +203,10 @@ static uint64_t hash_words(const void* p, size_t bytes, uint64_t h)
     return h;
 }
 
-void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, hipStream_t s, const double* host_xyz)
+static EriSlotState& eri_slot_state(int slot)
 {
-    static DevicePool qpool_slot[2], pairs_slot[2];
     static EriSlotState state_slot[2];
-    DevicePool& qpool = qpool_slot[bv.slot & 1];
-    EriSlotState& st = state_slot[bv.slot & 1];
+    EriSlotState& st = state_slot[slot & 1];
     if (!st.fork) {
         (void)hipEventCreateWithFlags(&st.fork, hipEventDisableTiming);
         for (int k = 0; k < ERI_SIDE_STREAMS; ++k) {
@@ -210,37 +214,66 @@ void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, h
             (void)hipEventCreateWithFlags(&st.join[k], hipEventDisableTiming);
         }
     }
+    return st;
+}
+
+// Screened build, part 1: Schwarz bounds of every shell pair and the zero fill of the tensor, put on the side
+// streams as soon as the geometry is on the device (call it right after the upload, before the one-electron
+// stage): the six class kernels are latency-bound -- (dd|dd) alone is 6 k threads for 4.7 ms -- and run next to
+// each other and next to int1e / the orthogonaliser.  launch_eri joins them.
+void launch_eri_bounds(const BatchView& bv, const Topology& topo, double schwarz_tol, hipStream_t s)
+{
+    EriSlotState& st = eri_slot_state(bv.slot);
+    st.bounds_pending = false;
+    if (!(schwarz_tol > 0.0)) return;
+    const size_t np = (size_t)bv.npair;
+    st.Q = (double*)st.qpool.ensure(sizeof(double) * (size_t)bv.nfrag * topo.shells.size() * topo.shells.size());
+    st.bounds_tol = schwarz_tol;
+    int* d_pairs = (int*)st.pairs.ensure((topo.pairs.size() + 16) * sizeof(int));
+    for (auto& row : st.bucket) for (auto& b : row) b.clear();
+    for (size_t k = 0; k + 1 < topo.pairs.size(); k += 2) {
+        int A = topo.pairs[k], B = topo.pairs[k + 1];
+        if (topo.shells[A].l < topo.shells[B].l) std::swap(A, B);
+        auto& bk = st.bucket[topo.shells[A].l][topo.shells[B].l];
+        bk.push_back(A); bk.push_back(B);
+    }
+    (void)hipEventRecord(st.fork, s);
+    for (int k = 0; k < ERI_SIDE_STREAMS; ++k) (void)hipStreamWaitEvent(st.side[k], st.fork, 0);
+    size_t off = 0;
+    int rr = 0;
+    double* Q = st.Q;
+    // most expensive class first; the zero fill shares the last stream
+#define SCHWARZ_CASE(a, b)                                                                                                      \
+    launch_schwarz_class<a, b>(bv, st.bucket[a][b].data(), (int)st.bucket[a][b].size() / 2, d_pairs + off, Q, st.side[rr++ % ERI_SIDE_STREAMS]); \
+    off += st.bucket[a][b].size();
+    SCHWARZ_CASE(2, 2) SCHWARZ_CASE(0, 0) SCHWARZ_CASE(2, 1) SCHWARZ_CASE(1, 1)
+    SCHWARZ_CASE(1, 0) SCHWARZ_CASE(2, 0)
+#undef SCHWARZ_CASE
+    if (bv.eri) (void)hipMemsetAsync(bv.eri, 0, sizeof(double) * np * np * bv.nfrag, st.side[ERI_SIDE_STREAMS - 1]);
+    for (int k = 0; k < ERI_SIDE_STREAMS; ++k) (void)hipEventRecord(st.join[k], st.side[k]);
+    st.bounds_pending = true;
+}
+
+void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, hipStream_t s, const double* host_xyz)
+{
+    EriSlotState& st = eri_slot_state(bv.slot);
     const size_t np = (size_t)bv.npair;
     // The class lists cover every element of the pair matrix, so the unscreened build overwrites the whole
     // tensor and needs no zero fill (22 GB for the (H2O)64 dimers); a screened build leaves skipped blocks at zero.
-    if (schwarz_tol > 0.0) (void)hipMemsetAsync(bv.eri, 0, sizeof(double) * np * np * bv.nfrag, s);
-
     double* Q = nullptr;
     double thresh = 0.0;
     if (schwarz_tol > 0.0) {
-        Q = (double*)qpool.ensure(sizeof(double) * (size_t)bv.nfrag * topo.shells.size() * topo.shells.size());
+        if (!st.bounds_pending || st.bounds_tol != schwarz_tol) launch_eri_bounds(bv, topo, schwarz_tol, s);
+        for (int k = 0; k < ERI_SIDE_STREAMS; ++k) (void)hipStreamWaitEvent(s, st.join[k], 0);
+        st.bounds_pending = false;
+        Q = st.Q;
         thresh = schwarz_tol;
-        int* d_pairs = (int*)pairs_slot[bv.slot & 1].ensure((topo.pairs.size() + 16) * sizeof(int));
-        size_t off = 0;
-        std::vector<int> bucket[KERNEL_LMAX + 1][KERNEL_LMAX + 1];
-        for (size_t k = 0; k + 1 < topo.pairs.size(); k += 2) {
-            int A = topo.pairs[k], B = topo.pairs[k + 1];
-            if (topo.shells[A].l < topo.shells[B].l) std::swap(A, B);
-            auto& bk = bucket[topo.shells[A].l][topo.shells[B].l];
-            bk.push_back(A); bk.push_back(B);
-        }
-#define SCHWARZ_CASE(a, b)                                                                                   \
-    launch_schwarz_class<a, b>(bv, bucket[a][b].data(), (int)bucket[a][b].size() / 2, d_pairs + off, Q, s);   \
-    off += bucket[a][b].size();
-        SCHWARZ_CASE(0, 0) SCHWARZ_CASE(1, 0) SCHWARZ_CASE(1, 1)
-        SCHWARZ_CASE(2, 0) SCHWARZ_CASE(2, 1) SCHWARZ_CASE(2, 2)
-#undef SCHWARZ_CASE
-        (void)hipStreamSynchronize(s);     // the bucket vectors go out of scope
     }
 
-    // twin-shell cut and block sharing apply to the unscreened build only
-    const bool twins = (schwarz_tol <= 0.0) && !twin_blocks_disabled();
-    const bool may_share = schwarz_tol <= 0.0 && !block_sharing_disabled() && host_xyz != nullptr;
+    // twin-shell cut and block sharing combine with Schwarz screening (a twin entry is kept when any member
+    // combination passes; shared entries are tested with their representative's bounds)
+    const bool twins = !twin_blocks_disabled();
+    const bool may_share = !block_sharing_disabled() && host_xyz != nullptr;
 
     // ---- list cache lookup: key = topology, fragment count, switches, every coordinate bit
     uint64_t key = (uint64_t)std::hash<std::string>{}(topo.key) ^ 0x243F6A8885A308D3ull;
@@ -334,8 +367,8 @@ void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, h
     }
 #define TWIN_CASE(a, b, c, d_)                                                                                        \
     if (cl.la == a && cl.lb == b && cl.lc == c && cl.ld == d_) {                                                      \
-        launch_eri_twin_class<a, b, c, d_>(bv, d + L.dense_off, L.dense_n, nullptr, 0, dense_stream());               \
-        launch_eri_twin_class<a, b, c, d_>(bv, d + L.sh_off, L.sh_n, d + L.task_off, L.ntasks, st.side[rr++ % ERI_SIDE_STREAMS]); \
+        launch_eri_twin_class<a, b, c, d_>(bv, d + L.dense_off, L.dense_n, nullptr, 0, Q, thresh, dense_stream());    \
+        launch_eri_twin_class<a, b, c, d_>(bv, d + L.sh_off, L.sh_n, d + L.task_off, L.ntasks, Q, thresh, st.side[rr++ % ERI_SIDE_STREAMS]); \
     }
     for (const EriLaunch& L : cc->launches) {
         const auto& cl = topo.classes[L.cls];

@@ -8,7 +8,7 @@ namespace mqc {
 #define DIG_INST(a, b, c, d) \
     template void launch_eri_digest_class<a, b, c, d>(const BatchView&, const int*, int, const double*, const double*, double, double*, double*, int, hipStream_t);
 #define TWIN_INST(a, b, c, d) \
-    template void launch_eri_twin_class<a, b, c, d>(const BatchView&, const int*, int, const int*, int, hipStream_t);
+    template void launch_eri_twin_class<a, b, c, d>(const BatchView&, const int*, int, const int*, int, const double*, double, hipStream_t);
 #define SCHWARZ_INST(a, b) \
     template void launch_schwarz_class<a, b>(const BatchView&, const int*, int, int*, double*, hipStream_t);
 

@@ -446,3 +446,11 @@ def test_large_batch_jk_variant_matches_small_batch_variant_and_oracle():
         o = so.run_rhf(oracle_mol("cc-pvdz", frags[k]), 20, 100, 1e-9, 1e-7)
         assert abs(big[k].energy.scf - o.energy) < 1e-8
         assert big[k].scf_iterations == o.iterations
+    # the screened build bench.py uses (Schwarz 1e-12, together with twin blocks and block sharing): every
+    # fragment within 1e-10 Eh of the unscreened result, same iteration counts
+    scr = methods.run_hip_scf_batch(methods.ScfSettings(basis_set="cc-pvdz", energy_tol=1e-9, density_tol=1e-7, guess="gwh",
+                                                        eri_mode="incore", schwarz_tol=1e-12), frags)
+    for a, b in zip(big, scr):
+        assert not b.has_error, b.error_message
+        assert a.scf_iterations == b.scf_iterations
+        assert abs(a.energy.scf - b.energy.scf) < 1e-10
