@@ -77,6 +77,7 @@ DECLARED_SYMBOLS = [
 _lib = None
 
 
+
 class HipBackendError(RuntimeError):
     def __init__(self, code, message):
         super().__init__("mqc_hip error %d: %s" % (code, message))

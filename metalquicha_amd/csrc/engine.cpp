@@ -536,8 +536,14 @@ int mqc_hip_context_get(int32_t local_rank, mqc_hip_context** out)
     ctx->device = ((local_rank % ndev) + ndev) % ndev;    // mqc_cuest_context.f90:188
     HIP_CHECK_RET(hipSetDevice(ctx->device));
     HIP_CHECK_RET(hipGetDeviceProperties(&ctx->prop, ctx->device));
+    // creation order matters: streams take the 4 hardware queues round-robin, so each lane's main stream and its
+    // three side streams land on four different queues
     HIP_CHECK_RET(hipStreamCreate(&ctx->stream));
+    for (int k = 0; k < 3; ++k) HIP_CHECK_RET(hipStreamCreateWithFlags(&ctx->side[0][k], hipStreamNonBlocking));
     HIP_CHECK_RET(hipStreamCreate(&ctx->stream2));
+    for (int k = 0; k < 3; ++k) HIP_CHECK_RET(hipStreamCreateWithFlags(&ctx->side[1][k], hipStreamNonBlocking));
+    eri_set_side_streams(0, ctx->side[0], 3);
+    eri_set_side_streams(1, ctx->side[1], 3);
     for (hipEvent_t* e : {&ctx->evb0, &ctx->evb1, &ctx->evb2, &ctx->evb3, &ctx->evq0, &ctx->evq1, &ctx->evq2, &ctx->evq3})
         HIP_CHECK_RET(hipEventCreate(e));
     HIP_CHECK_RET(hipEventCreate(&ctx->ev0));

@@ -156,6 +156,7 @@ struct mqc_hip_context {
     // second pipeline slot: the next chunk's integrals are formed while the current chunk iterates
     mqc::DevicePool pool_main2, pool_eri2, pool_misc2, pool_gridw2, pool_df2, pool_topo2, pool_aux2, pool_grid2;
     hipStream_t stream2 = nullptr;
+    hipStream_t side[2][3] = {};        // per lane: side streams of the ERI stage, created right after the lane's main stream
     hipEvent_t evb0 = nullptr, evb1 = nullptr, evb2 = nullptr, evb3 = nullptr;
     hipEvent_t evq0 = nullptr, evq1 = nullptr, evq2 = nullptr, evq3 = nullptr;   // integral-stage timing per slot
     int pipeline_chunks = 4;            // chunks a large batch is cut into
@@ -193,6 +194,7 @@ void launch_int1e(const BatchView& bv, const Topology& topo, hipStream_t s);
 void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, hipStream_t s, const double* host_xyz = nullptr);
 // optional head start of the screened build (bounds + zero fill on side streams); launch_eri joins it
 void launch_eri_bounds(const BatchView& bv, const Topology& topo, double schwarz_tol, hipStream_t s);
+void eri_set_side_streams(int slot, const hipStream_t* streams, int count);
 void launch_jk_incore(const BatchView& bv, bool only_active, hipStream_t s);
 void launch_direct_setup(const BatchView& bv, const Topology& topo, hipStream_t s);
 void launch_jk_direct(const BatchView& bv, const Topology& topo, double thresh, bool only_active, hipStream_t s);

@@ -181,7 +181,10 @@ struct EriListCache {
     int nap = 0;
 };
 constexpr int ERI_CACHE_WAYS = 4;
-constexpr int ERI_SIDE_STREAMS = 4;    // task-list launches of different classes are independent: round-robin
+constexpr int ERI_SIDE_STREAMS = 3;    // task-list launches of different classes are independent: round-robin.
+// Three, not more: ROCm maps streams onto 4 hardware queues in creation order, and a lane's main stream plus its
+// three side streams (created back to back in mqc_hip_context_get) then sit on four different queues; a fourth
+// side stream shares the main stream's queue and its kernels wait behind the orthogonaliser.
 struct EriSlotState {
     EriListCache cache[ERI_CACHE_WAYS];
     int next = 0;
@@ -203,6 +206,14 @@ static uint64_t hash_words(const void* p, size_t bytes, uint64_t h)
     return h;
 }
 
+static hipStream_t g_preset_side[2][ERI_SIDE_STREAMS] = {};
+
+// side streams created by the context right after the lane's main stream (hardware-queue placement, see above)
+void eri_set_side_streams(int slot, const hipStream_t* streams, int count)
+{
+    for (int k = 0; k < ERI_SIDE_STREAMS && k < count; ++k) g_preset_side[slot & 1][k] = streams[k];
+}
+
 static EriSlotState& eri_slot_state(int slot)
 {
     static EriSlotState state_slot[2];
@@ -210,7 +221,8 @@ static EriSlotState& eri_slot_state(int slot)
     if (!st.fork) {
         (void)hipEventCreateWithFlags(&st.fork, hipEventDisableTiming);
         for (int k = 0; k < ERI_SIDE_STREAMS; ++k) {
-            (void)hipStreamCreateWithFlags(&st.side[k], hipStreamNonBlocking);
+            if (g_preset_side[slot & 1][k]) st.side[k] = g_preset_side[slot & 1][k];
+            else (void)hipStreamCreateWithFlags(&st.side[k], hipStreamNonBlocking);
             (void)hipEventCreateWithFlags(&st.join[k], hipEventDisableTiming);
         }
     }
