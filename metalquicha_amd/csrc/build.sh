@@ -16,7 +16,7 @@ stale() { # obj src
 pids=()
 njobs=0
 run() { ( "$@" ) & pids+=($!); njobs=$((njobs+1)); if [ $njobs -ge 8 ]; then wait ${pids[0]}; pids=("${pids[@]:1}"); njobs=$((njobs-1)); fi; }
-for g in 15 6 12 4 13 5 14 10 2 11 3 9 1 8 0 7 16 17; do
+for g in 15 18 6 12 4 13 5 14 10 2 11 3 9 19 1 8 0 7 16 17; do
   o=_obj/kern_eri_inst_$g.o
   if stale "$o" kern_eri_inst.hip; then run hipcc $FLAGS -DERI_GROUP=$g -x hip -c kern_eri_inst.hip -o "$o"; fi
 done

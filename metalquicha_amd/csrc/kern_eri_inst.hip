@@ -30,7 +30,11 @@ ERI_INST(2, 2, 2, 1)
 #elif ERI_GROUP == 15
 ERI_INST(2, 2, 2, 2)
 #elif ERI_GROUP == 7
-SCHWARZ_INST(0, 0) SCHWARZ_INST(1, 0) SCHWARZ_INST(1, 1) SCHWARZ_INST(2, 0) SCHWARZ_INST(2, 1) SCHWARZ_INST(2, 2)
+SCHWARZ_INST(0, 0) SCHWARZ_INST(1, 0) SCHWARZ_INST(1, 1) SCHWARZ_INST(2, 0)
+#elif ERI_GROUP == 18
+SCHWARZ_INST(2, 2)
+#elif ERI_GROUP == 19
+SCHWARZ_INST(2, 1)
 #elif ERI_GROUP == 8
 DIG_INST(0, 0, 0, 0) DIG_INST(1, 0, 0, 0) DIG_INST(1, 0, 1, 0) DIG_INST(1, 1, 0, 0) DIG_INST(1, 1, 1, 0) DIG_INST(1, 1, 1, 1)
 DIG_INST(2, 0, 0, 0) DIG_INST(2, 0, 1, 0) DIG_INST(2, 0, 1, 1) DIG_INST(2, 0, 2, 0)

@@ -826,10 +826,11 @@ MQC_HD constexpr int eri_pass_chunk(int la, int lb, int lc, int ld)
     return ch;
 }
 
-// Schwarz diagonal blocks (ab|ab): a handful per fragment, so only the cheap-to-compile ones use passes
+// Schwarz diagonal blocks (ab|ab): the one-shot kernel keeps a (dd|dd) block in scratch (4 KB per lane, 4.7 ms for
+// 6 k threads), so the d classes use passes too; their instantiations sit in translation units of their own
 MQC_HD constexpr bool schwarz_uses_passes(int la, int lb)
 {
-    return (la == 1 && lb == 1) || (la == 2 && lb == 0);
+    return (la == 1 && lb == 1) || la == 2;
 }
 
 // classes that go through the pass kernel (everything that spilled in the one-shot register kernel)
