@@ -339,8 +339,16 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         if (!use_df && !use_direct) launch_eri_bounds(bv, topo, stol, s);     // screened build: bounds run next to the 1e stage
         launch_int1e(bv, topo, s);
         if ((rc = stage_check("int1e")) != MQC_HIP_OK) return rc;
-        launch_orthogonalizer(bv, s);
+        // The orthogonaliser and the starting guess need S and H only and are latency-bound (one workgroup per
+        // fragment, Jacobi sweeps): they run on a side stream next to the compute-bound two-electron stage
+        hipStream_t so = ctx->side[sl.id & 1][2];
+        HIP_CHECK_RET(hipEventRecord(ctx->evo[sl.id & 1][0], s));
+        HIP_CHECK_RET(hipStreamWaitEvent(so, ctx->evo[sl.id & 1][0], 0));
+        launch_orthogonalizer(bv, so);
         if ((rc = stage_check("orthogonalizer")) != MQC_HIP_OK) return rc;
+        launch_guess(bv, opts.guess == MQC_HIP_GUESS_CORE ? MQC_HIP_GUESS_CORE : MQC_HIP_GUESS_GWH, so);
+        if ((rc = stage_check("guess")) != MQC_HIP_OK) return rc;
+        HIP_CHECK_RET(hipEventRecord(ctx->evo[sl.id & 1][1], so));
         if (xc.ncomp > 0) launch_becke_weights(bv, s);
         if ((rc = stage_check("grid weights")) != MQC_HIP_OK) return rc;
         const double t2 = now_s();
@@ -353,8 +361,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         HIP_CHECK_RET(hipEventRecord(sl.q1, s));
         if ((rc = stage_check("two-electron setup")) != MQC_HIP_OK) return rc;
         sx->stats.eri_quartets += topo.n_quartets * nf;
-        launch_guess(bv, opts.guess == MQC_HIP_GUESS_CORE ? MQC_HIP_GUESS_CORE : MQC_HIP_GUESS_GWH, s);
-        if ((rc = stage_check("guess")) != MQC_HIP_OK) return rc;
+        HIP_CHECK_RET(hipStreamWaitEvent(s, ctx->evo[sl.id & 1][1], 0));      // join: X, C, D of the guess are ready
         sx->stats.t_eri += now_s() - t2;      // host time to enqueue; the kernels are timed by q0/q1
         return MQC_HIP_OK;
     };
@@ -542,6 +549,7 @@ int mqc_hip_context_get(int32_t local_rank, mqc_hip_context** out)
     for (int k = 0; k < 3; ++k) HIP_CHECK_RET(hipStreamCreateWithFlags(&ctx->side[0][k], hipStreamNonBlocking));
     HIP_CHECK_RET(hipStreamCreate(&ctx->stream2));
     for (int k = 0; k < 3; ++k) HIP_CHECK_RET(hipStreamCreateWithFlags(&ctx->side[1][k], hipStreamNonBlocking));
+    for (int l = 0; l < 2; ++l) for (int k = 0; k < 2; ++k) HIP_CHECK_RET(hipEventCreateWithFlags(&ctx->evo[l][k], hipEventDisableTiming));
     eri_set_side_streams(0, ctx->side[0], 3);
     eri_set_side_streams(1, ctx->side[1], 3);
     for (hipEvent_t* e : {&ctx->evb0, &ctx->evb1, &ctx->evb2, &ctx->evb3, &ctx->evq0, &ctx->evq1, &ctx->evq2, &ctx->evq3})

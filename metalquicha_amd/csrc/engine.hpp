@@ -157,6 +157,7 @@ struct mqc_hip_context {
     mqc::DevicePool pool_main2, pool_eri2, pool_misc2, pool_gridw2, pool_df2, pool_topo2, pool_aux2, pool_grid2;
     hipStream_t stream2 = nullptr;
     hipStream_t side[2][3] = {};        // per lane: side streams of the ERI stage, created right after the lane's main stream
+    hipEvent_t evo[2][2] = {};          // per lane: one-electron stage done / orthogonaliser + guess done
     hipEvent_t evb0 = nullptr, evb1 = nullptr, evb2 = nullptr, evb3 = nullptr;
     hipEvent_t evq0 = nullptr, evq1 = nullptr, evq2 = nullptr, evq3 = nullptr;   // integral-stage timing per slot
     int pipeline_chunks = 4;            // chunks a large batch is cut into
