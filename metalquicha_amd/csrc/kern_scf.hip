@@ -121,6 +121,8 @@ __device__ __forceinline__ void wg_gemm_mfma(int M, int N, int K, const double* 
 
 // 1: rotation sets in which no pair exceeds the threshold skip their update phases (MQC_HIP_JACOBI_SKIP=0 turns it off)
 __device__ int g_jacobi_skip_idle_sets = 1;
+// measurement switch (MQC_HIP_JACOBI_MAX_SWEEPS): caps the sweeps; wrong eigenvectors below ~6
+__device__ int g_jacobi_max_sweeps = 1000;
 
 struct JacobiLds {
     double* A;      // mp x lda
@@ -192,7 +194,10 @@ __device__ void jacobi_eig(JacobiLds& jl, int m, int ldv, const double* __restri
     const double thresh = JACOBI_SKIP * dmax;
     __syncthreads();
 
-    for (int sweep = 0; sweep < JACOBI_MAX_SWEEPS; ++sweep) {
+    const int max_sweeps = min(JACOBI_MAX_SWEEPS, g_jacobi_max_sweeps);
+    // (k, col) of this thread's first work item and the step between its items: no division inside the sweeps
+    const int k0 = tid / mp, c0 = tid - k0 * mp, dk = NT / mp, dc = NT - dk * mp;
+    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
         if (tid == 0) { jl.flag[0] = 0; jl.flag[1] = 0; jl.flag[2] = 0; jl.flag[3] = 0; }
         __syncthreads();
         for (int r = 0; r < mp - 1; ++r) {
@@ -203,7 +208,10 @@ __device__ void jacobi_eig(JacobiLds& jl, int m, int ldv, const double* __restri
             if (tid < half) {
                 int p, q;
                 if (tid == 0) { p = mp - 1; q = r; }
-                else { p = (r + tid) % (mp - 1); q = (r - tid + (mp - 1)) % (mp - 1); }
+                else {      // (r + tid) mod (mp - 1) and (r - tid) mod (mp - 1) without integer division
+                    p = r + tid; if (p >= mp - 1) p -= mp - 1;
+                    q = r - tid; if (q < 0) q += mp - 1;
+                }
                 if (p > q) { const int t = p; p = q; q = t; }
                 const double apq = A[p * lda + q];
                 double c = 1.0, s = 0.0;
@@ -221,8 +229,7 @@ __device__ void jacobi_eig(JacobiLds& jl, int m, int ldv, const double* __restri
             __syncthreads();
             if (g_jacobi_skip_idle_sets && jl.flag[1 + r % 3] == 0) continue;
             // rows: A <- J^T A
-            for (int idx = tid; idx < half * mp; idx += NT) {
-                const int k = idx / mp, col = idx - k * mp;
+            for (int idx = tid, k = k0, col = c0; idx < half * mp; idx += NT) {
                 const double s = jl.rs[k];
                 if (s != 0.0) {
                     const double c = jl.rc[k];
@@ -231,11 +238,13 @@ __device__ void jacobi_eig(JacobiLds& jl, int m, int ldv, const double* __restri
                     A[p * lda + col] = c * ap - s * aq;
                     A[q * lda + col] = s * ap + c * aq;
                 }
+                k += dk; col += dc;
+                if (col >= mp) { col -= mp; ++k; }
             }
             __syncthreads();
             // columns: A <- A J, V <- V J
-            for (int idx = tid; idx < half * mp; idx += NT) {
-                const int k = idx / mp, row = idx - k * mp;
+            for (int idx = tid, k = k0, row = c0; idx < half * mp; idx += NT, k += dk, row += dc) {
+                if (row >= mp) { row -= mp; ++k; }
                 const double s = jl.rs[k];
                 if (s != 0.0) {
                     const double c = jl.rc[k];
@@ -616,6 +625,7 @@ static void apply_jacobi_env()
     static const bool done = [] {
         const char* e = std::getenv("MQC_HIP_JACOBI_SKIP");
         if (e && e[0] == '0') { const int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_jacobi_skip_idle_sets), &z, sizeof(int)); }
+        if (const char* m = std::getenv("MQC_HIP_JACOBI_MAX_SWEEPS")) { const int v = std::atoi(m); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_jacobi_max_sweeps), &v, sizeof(int)); }
         return true;
     }();
     (void)done;
