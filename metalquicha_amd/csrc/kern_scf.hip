@@ -197,6 +197,7 @@ __device__ void jacobi_eig(JacobiLds& jl, int m, int ldv, const double* __restri
     const int max_sweeps = min(JACOBI_MAX_SWEEPS, g_jacobi_max_sweeps);
     // (k, col) of this thread's first work item and the step between its items: no division inside the sweeps
     const int k0 = tid / mp, c0 = tid - k0 * mp, dk = NT / mp, dc = NT - dk * mp;
+    const int kb0 = tid / half, lb0 = tid - kb0 * half, dkb = NT / half, dlb = NT - dkb * half;      // same for the 2 x 2 blocks
     for (int sweep = 0; sweep < max_sweeps; ++sweep) {
         if (tid == 0) { jl.flag[0] = 0; jl.flag[1] = 0; jl.flag[2] = 0; jl.flag[3] = 0; }
         __syncthreads();
@@ -228,35 +229,36 @@ __device__ void jacobi_eig(JacobiLds& jl, int m, int ldv, const double* __restri
             }
             __syncthreads();
             if (g_jacobi_skip_idle_sets && jl.flag[1 + r % 3] == 0) continue;
-            // rows: A <- J^T A
-            for (int idx = tid, k = k0, col = c0; idx < half * mp; idx += NT) {
-                const double s = jl.rs[k];
-                if (s != 0.0) {
-                    const double c = jl.rc[k];
-                    const int p = jl.rp[k], q = jl.rq[k];
-                    const double ap = A[p * lda + col], aq = A[q * lda + col];
-                    A[p * lda + col] = c * ap - s * aq;
-                    A[q * lda + col] = s * ap + c * aq;
+            // A <- J^T A J in ONE phase: the rotation pairs partition the indices, so the 2 x 2 blocks
+            // A[{p_k, q_k}][{p_l, q_l}] are disjoint and each is transformed from both sides by one thread
+            // (one read and one write per element, no barrier between the row and the column half)
+            for (int idx = tid, k = kb0, l = lb0; idx < half * half; idx += NT) {
+                const double s1 = jl.rs[k], s2 = jl.rs[l];
+                if (s1 != 0.0 || s2 != 0.0) {
+                    const double c1 = jl.rc[k], c2 = jl.rc[l];
+                    const int p1 = jl.rp[k], q1 = jl.rq[k], p2 = jl.rp[l], q2 = jl.rq[l];
+                    const double b00 = A[p1 * lda + p2], b01 = A[p1 * lda + q2];
+                    const double b10 = A[q1 * lda + p2], b11 = A[q1 * lda + q2];
+                    const double t00 = c1 * b00 - s1 * b10, t01 = c1 * b01 - s1 * b11;
+                    const double t10 = s1 * b00 + c1 * b10, t11 = s1 * b01 + c1 * b11;
+                    A[p1 * lda + p2] = c2 * t00 - s2 * t01;
+                    A[p1 * lda + q2] = s2 * t00 + c2 * t01;
+                    A[q1 * lda + p2] = c2 * t10 - s2 * t11;
+                    A[q1 * lda + q2] = s2 * t10 + c2 * t11;
                 }
-                k += dk; col += dc;
-                if (col >= mp) { col -= mp; ++k; }
+                k += dkb; l += dlb;
+                if (l >= half) { l -= half; ++k; }
             }
-            __syncthreads();
-            // columns: A <- A J, V <- V J
+            // V <- V J
             for (int idx = tid, k = k0, row = c0; idx < half * mp; idx += NT, k += dk, row += dc) {
                 if (row >= mp) { row -= mp; ++k; }
                 const double s = jl.rs[k];
-                if (s != 0.0) {
+                if (s != 0.0 && (VLDS || row < m)) {
                     const double c = jl.rc[k];
                     const int p = jl.rp[k], q = jl.rq[k];
-                    const double ap = A[row * lda + p], aq = A[row * lda + q];
-                    A[row * lda + p] = c * ap - s * aq;
-                    A[row * lda + q] = s * ap + c * aq;
-                    if (VLDS || row < m) {
-                        const double vp = V[row * ldv + p], vq = V[row * ldv + q];
-                        V[row * ldv + p] = c * vp - s * vq;
-                        V[row * ldv + q] = s * vp + c * vq;
-                    }
+                    const double vp = V[row * ldv + p], vq = V[row * ldv + q];
+                    V[row * ldv + p] = c * vp - s * vq;
+                    V[row * ldv + q] = s * vp + c * vq;
                 }
             }
             __syncthreads();
