@@ -119,6 +119,22 @@ __device__ __forceinline__ void wg_gemm_mfma(int M, int N, int K, const double* 
     __syncthreads();
 }
 
+__device__ __forceinline__ double jacobi_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double jacobi_rsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = fma(y, fma(-hx * y, y, 0.5), y);
+    y = fma(y, fma(-hx * y, y, 0.5), y);
+    return y;
+}
+
 // 1: rotation sets in which no pair exceeds the threshold skip their update phases (MQC_HIP_JACOBI_SKIP=0 turns it off)
 __device__ int g_jacobi_skip_idle_sets = 1;
 // measurement switch (MQC_HIP_JACOBI_MAX_SWEEPS): caps the sweeps; wrong eigenvectors below ~6
@@ -218,9 +234,12 @@ __device__ void jacobi_eig(JacobiLds& jl, int m, int ldv, const double* __restri
                 double c = 1.0, s = 0.0;
                 if (fabs(apq) > thresh) {
                     const double app = A[p * lda + p], aqq = A[q * lda + q];
-                    const double theta = (aqq - app) / (2.0 * apq);
-                    const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                    c = 1.0 / sqrt(t * t + 1.0);
+                    // hardware-seeded reciprocal / rsqrt + two Newton steps (<= 1 ulp): this serial prologue of every
+                    // rotation set costs as much as the update it precedes when written with IEEE division and sqrt
+                    const double theta = (aqq - app) * jacobi_rcp(2.0 * apq);
+                    const double h2 = theta * theta + 1.0;
+                    const double t = (theta >= 0.0 ? 1.0 : -1.0) * jacobi_rcp(fabs(theta) + h2 * jacobi_rsqrt(h2));
+                    c = jacobi_rsqrt(t * t + 1.0);
                     s = t * c;
                     jl.flag[0] = 1;
                     jl.flag[1 + r % 3] = 1;
