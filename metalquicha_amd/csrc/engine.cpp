@@ -47,7 +47,55 @@ static int upload_topology(mqc_hip_context* ctx, const Topology& topo, TopologyD
     }
     const size_t ib = sizeof(int) * (size_t)ns;
     const size_t nprim = topo.exps.size();
-    const size_t bytes = 5 * ((ib + 255) & ~size_t(255)) + 3 * ((sizeof(double) * (nprim + topo.natoms) + 255) & ~size_t(255)) + 1024;
+    // radial groups (see TopologyDev)
+    std::vector<int> gfirst, gcount, gnprim, gpoff, gcoff;
+    std::vector<double> gex, gco;
+    for (int sidx = 0; sidx < ns; ++sidx) {
+        const auto& sh = topo.shells[sidx];
+        bool joined = false;
+        if (!gfirst.empty()) {
+            const int g = (int)gfirst.size() - 1;
+            const auto& lead = topo.shells[gfirst[g]];
+            if (gfirst[g] + gcount[g] == sidx && gcount[g] < XC_GROUP_MAX && lead.atom == sh.atom && lead.l == sh.l) {
+                std::vector<int> where(sh.nprim, -1);
+                bool all = true;
+                for (int i = 0; i < sh.nprim && all; ++i) {
+                    for (int k = 0; k < lead.nprim; ++k)
+                        if (topo.exps[lead.poff + k] == topo.exps[sh.poff + i]) { where[i] = k; break; }
+                    all = where[i] >= 0;
+                }
+                if (all) {
+                    gco.resize(gco.size() + lead.nprim, 0.0);
+                    double* row = gco.data() + gcoff[g] + (size_t)gcount[g] * lead.nprim;
+                    for (int i = 0; i < sh.nprim; ++i) row[where[i]] += topo.coefs[sh.poff + i];
+                    gcount[g] += 1;
+                    joined = true;
+                }
+            }
+        }
+        if (!joined) {
+            gfirst.push_back(sidx); gcount.push_back(1); gnprim.push_back(sh.nprim);
+            gpoff.push_back((int)gex.size()); gcoff.push_back((int)gco.size());
+            for (int i = 0; i < sh.nprim; ++i) { gex.push_back(topo.exps[sh.poff + i]); gco.push_back(topo.coefs[sh.poff + i]); }
+        }
+    }
+    const int ng = (int)gfirst.size();
+    {
+        // deepest groups first: the lanes of a wave take consecutive groups (16 points each), so groups of equal
+        // primitive count side by side keep the primitive loop's trip count uniform inside a wave
+        std::vector<int> order(ng);
+        for (int g = 0; g < ng; ++g) order[g] = g;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+            if (gnprim[a] != gnprim[b]) return gnprim[a] > gnprim[b];
+            return gcount[a] > gcount[b];
+        });
+        auto permute = [&](std::vector<int>& v) { std::vector<int> t(ng); for (int g = 0; g < ng; ++g) t[g] = v[order[g]]; v.swap(t); };
+        permute(gfirst); permute(gcount); permute(gnprim); permute(gpoff); permute(gcoff);
+    }
+    const size_t gib = sizeof(int) * (size_t)ng;
+    const size_t bytes = 5 * ((ib + 255) & ~size_t(255)) + 3 * ((sizeof(double) * (nprim + topo.natoms) + 255) & ~size_t(255)) + 1024
+                       + 5 * ((gib + 255) & ~size_t(255)) + ((sizeof(double) * gex.size() + 255) & ~size_t(255))
+                       + ((sizeof(double) * gco.size() + 255) & ~size_t(255));
     char* base = (char*)pool->ensure(bytes);
     if (!base) return fail(MQC_HIP_ERR_DEVICE, "out of device memory (topology)");
     auto take = [&base](size_t b) { char* p = base; base += (b + 255) & ~size_t(255); return p; };
@@ -55,6 +103,10 @@ static int upload_topology(mqc_hip_context* ctx, const Topology& topo, TopologyD
     td.sh_atom = (int*)take(ib); td.sh_aoff = (int*)take(ib);
     td.exps = (double*)take(sizeof(double) * nprim); td.coefs = (double*)take(sizeof(double) * nprim);
     td.zeff = (double*)take(sizeof(double) * topo.natoms);
+    td.grp_first = (int*)take(gib); td.grp_count = (int*)take(gib); td.grp_nprim = (int*)take(gib);
+    td.grp_poff = (int*)take(gib); td.grp_coff = (int*)take(gib);
+    td.gexps = (double*)take(sizeof(double) * gex.size()); td.gcoefs = (double*)take(sizeof(double) * gco.size());
+    td.ngroup = ng;
     td.nshell = ns; td.nao = topo.nao; td.npair = topo.npair; td.natoms = topo.natoms;
     hipStream_t s = stream ? stream : ctx->stream;
     HIP_CHECK_RET(hipMemcpyAsync(td.sh_l, l.data(), ib, hipMemcpyHostToDevice, s));
@@ -65,6 +117,13 @@ static int upload_topology(mqc_hip_context* ctx, const Topology& topo, TopologyD
     HIP_CHECK_RET(hipMemcpyAsync(td.exps, topo.exps.data(), sizeof(double) * nprim, hipMemcpyHostToDevice, s));
     HIP_CHECK_RET(hipMemcpyAsync(td.coefs, topo.coefs.data(), sizeof(double) * nprim, hipMemcpyHostToDevice, s));
     HIP_CHECK_RET(hipMemcpyAsync(td.zeff, topo.zeff.data(), sizeof(double) * topo.natoms, hipMemcpyHostToDevice, s));
+    HIP_CHECK_RET(hipMemcpyAsync(td.grp_first, gfirst.data(), gib, hipMemcpyHostToDevice, s));
+    HIP_CHECK_RET(hipMemcpyAsync(td.grp_count, gcount.data(), gib, hipMemcpyHostToDevice, s));
+    HIP_CHECK_RET(hipMemcpyAsync(td.grp_nprim, gnprim.data(), gib, hipMemcpyHostToDevice, s));
+    HIP_CHECK_RET(hipMemcpyAsync(td.grp_poff, gpoff.data(), gib, hipMemcpyHostToDevice, s));
+    HIP_CHECK_RET(hipMemcpyAsync(td.grp_coff, gcoff.data(), gib, hipMemcpyHostToDevice, s));
+    HIP_CHECK_RET(hipMemcpyAsync(td.gexps, gex.data(), sizeof(double) * gex.size(), hipMemcpyHostToDevice, s));
+    HIP_CHECK_RET(hipMemcpyAsync(td.gcoefs, gco.data(), sizeof(double) * gco.size(), hipMemcpyHostToDevice, s));
     HIP_CHECK_RET(hipStreamSynchronize(s));   // the host vectors go out of scope
     return MQC_HIP_OK;
 }

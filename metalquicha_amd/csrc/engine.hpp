@@ -100,7 +100,15 @@ struct TopologyDev {
     int *sh_l, *sh_nprim, *sh_poff, *sh_atom, *sh_aoff;
     double *exps, *coefs, *zeff;
     int nshell, nao, npair, natoms;
+    // radial groups for the AO evaluation on the grid (kern_xc.hip): consecutive shells of one atom and one l whose
+    // primitives all belong to the first shell's list (general contraction: cc-pVDZ oxygen 1s/2s/3s share nine
+    // exponents) evaluate their exponentials once.  gcoefs holds grp_count rows of grp_nprim coefficients (zeros
+    // where a shell does not use a primitive).
+    int *grp_first, *grp_count, *grp_nprim, *grp_poff, *grp_coff;
+    double *gexps, *gcoefs;
+    int ngroup;
 };
+constexpr int XC_GROUP_MAX = 3;      // shells per radial group
 
 struct BatchView {      // plain pointers handed to kernels
     TopologyDev topo;

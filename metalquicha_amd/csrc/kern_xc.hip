@@ -209,26 +209,12 @@ void launch_becke_weights(const BatchView& bv, hipStream_t s)
 // ------------------------------------------------------------------ the per-iteration quadrature kernel
 constexpr int XC_NT = 256;
 
-// one (point, shell) work item: values (and gradients) of the shell's spherical functions
+// angular part of one shell at one point from its radial value and derivative factor
 template <bool GGA>
-__device__ __forceinline__ void eval_shell(const TopologyDev& tp, const double* __restrict__ xyz, int sh, double px, double py, double pz,
+__device__ __forceinline__ void emit_shell(int l, int ao, double dx, double dy, double dz, double rad, double drad,
                                            double* __restrict__ chi, double* __restrict__ gx, double* __restrict__ gy,
                                            double* __restrict__ gz, int ptp, int p)
 {
-    const int l = tp.sh_l[sh], at = tp.sh_atom[sh], ao = tp.sh_aoff[sh];
-    const double dx = px - xyz[3 * at], dy = py - xyz[3 * at + 1], dz = pz - xyz[3 * at + 2];
-    const double r2 = dx * dx + dy * dy + dz * dz;
-    const double* e = tp.exps + tp.sh_poff[sh];
-    const double* c = tp.coefs + tp.sh_poff[sh];
-    double rad = 0.0, drad = 0.0;
-    const int np = tp.sh_nprim[sh];
-    for (int i = 0; i < np; ++i) {
-        const double ar2 = e[i] * r2;
-        if (ar2 < XC_EXP_CUTOFF) {           // exp(-46) = 1e-20: tight primitives vanish a fraction of a bohr from their nucleus
-            const double t = c[i] * exp(-ar2);
-            rad += t; drad -= 2.0 * e[i] * t;
-        }
-    }
     if (l == 0) {
         chi[ao * ptp + p] = rad;
         if (GGA) { gx[ao * ptp + p] = dx * drad; gy[ao * ptp + p] = dy * drad; gz[ao * ptp + p] = dz * drad; }
@@ -259,6 +245,55 @@ __device__ __forceinline__ void eval_shell(const TopologyDev& tp, const double* 
                 gy[(ao + m) * ptp + p] = ay * rad + v * dy * drad;
                 gz[(ao + m) * ptp + p] = az * rad + v * dz * drad;
             }
+        }
+    }
+}
+
+// one (point, radial group) work item: the exponentials of the group's primitives are formed once and contracted
+// with every member shell's coefficient row (TopologyDev::grp_*), then each member gets its angular part
+template <bool GGA>
+__device__ __forceinline__ void eval_group(const TopologyDev& tp, const double* __restrict__ xyz, int g, double px, double py, double pz,
+                                           double* __restrict__ chi, double* __restrict__ gx, double* __restrict__ gy,
+                                           double* __restrict__ gz, int ptp, int p)
+{
+    const int sh0 = tp.grp_first[g], nc = tp.grp_count[g], np = tp.grp_nprim[g];
+    const int l = tp.sh_l[sh0], at = tp.sh_atom[sh0];
+    const double dx = px - xyz[3 * at], dy = py - xyz[3 * at + 1], dz = pz - xyz[3 * at + 2];
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    const double* e = tp.gexps + tp.grp_poff[g];
+    const double* c = tp.gcoefs + tp.grp_coff[g];
+    double rad[XC_GROUP_MAX], drad[XC_GROUP_MAX];
+#pragma unroll
+    for (int k = 0; k < XC_GROUP_MAX; ++k) { rad[k] = 0.0; drad[k] = 0.0; }
+    for (int i = 0; i < np; ++i) {
+        const double ar2 = e[i] * r2;
+        if (ar2 < XC_EXP_CUTOFF) {           // exp(-46) = 1e-20: tight primitives vanish a fraction of a bohr from their nucleus
+            const double ex = exp(-ar2), m2e = -2.0 * e[i];
+#pragma unroll
+            for (int k = 0; k < XC_GROUP_MAX; ++k) {
+                if (k < nc) {
+                    const double t = c[k * np + i] * ex;
+                    rad[k] += t; drad[k] += m2e * t;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < XC_GROUP_MAX; ++k)
+        if (k < nc) emit_shell<GGA>(l, tp.sh_aoff[sh0 + k], dx, dy, dz, rad[k], drad[k], chi, gx, gy, gz, ptp, p);
+}
+
+// zero rows of a group for a point beyond the grid
+template <bool GGA>
+__device__ __forceinline__ void zero_group(const TopologyDev& tp, int g, double* __restrict__ chi, double* __restrict__ gx,
+                                           double* __restrict__ gy, double* __restrict__ gz, int ptp, int p)
+{
+    const int sh0 = tp.grp_first[g], nc = tp.grp_count[g], l = tp.sh_l[sh0];
+    for (int k = 0; k < nc; ++k) {
+        const int ao = tp.sh_aoff[sh0 + k];
+        for (int m = 0; m < 2 * l + 1; ++m) {
+            chi[(ao + m) * ptp + p] = 0.0;
+            if (GGA) { gx[(ao + m) * ptp + p] = 0.0; gy[(ao + m) * ptp + p] = 0.0; gz[(ao + m) * ptp + p] = 0.0; }
         }
     }
 }
@@ -300,19 +335,15 @@ __global__ void __launch_bounds__(XC_NT) xc_kernel(BatchView bv, int only_active
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int g0 = tile * PT;
         // 1. AO values for (point, shell) items, point fastest
-        for (int idx = tid; idx < tp.nshell * PT; idx += XC_NT) {
-            const int sh = idx / PT, p = idx - sh * PT;
+        for (int idx = tid; idx < tp.ngroup * PT; idx += XC_NT) {
+            const int rg = idx / PT, p = idx - rg * PT;
             const int g = g0 + p;
             if (g < gd.npts) {
                 const int oa = gd.pt_atom[g], it = gd.pt_tmpl[g];
-                eval_shell<GGA>(tp, xyz, sh, xyz[3 * oa] + gd.tmpl_xyz[3 * it], xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1],
+                eval_group<GGA>(tp, xyz, rg, xyz[3 * oa] + gd.tmpl_xyz[3 * it], xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1],
                                 xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2], chi, gx, gy, gz, PTP, p);
             } else {
-                const int l = tp.sh_l[sh], ao = tp.sh_aoff[sh];
-                for (int m = 0; m < 2 * l + 1; ++m) {
-                    chi[(ao + m) * PTP + p] = 0.0;
-                    if (GGA) { gx[(ao + m) * PTP + p] = 0.0; gy[(ao + m) * PTP + p] = 0.0; gz[(ao + m) * PTP + p] = 0.0; }
-                }
+                zero_group<GGA>(tp, rg, chi, gx, gy, gz, PTP, p);
             }
         }
         if (tid < PT) pw[tid] = (g0 + tid < gd.npts) ? wts[g0 + tid] : 0.0;
@@ -441,19 +472,15 @@ __global__ void __launch_bounds__(64 * XM_NW) xc_mfma_kernel(BatchView bv, int o
     for (int grp = blockIdx.x * XM_NW + wave; grp < ngroups; grp += gridDim.x * XM_NW) {
         const int g0 = grp * 16;
         // 1. AO values for (shell, point) items of this wave's 16 points
-        for (int idx = lane; idx < tp.nshell * 16; idx += 64) {
-            const int sh = idx >> 4, p = idx & 15;
+        for (int idx = lane; idx < tp.ngroup * 16; idx += 64) {
+            const int rg = idx >> 4, p = idx & 15;
             const int g = g0 + p;
             if (g < gd.npts) {
                 const int oa = gd.pt_atom[g], it = gd.pt_tmpl[g];
-                eval_shell<GGA>(tp, xyz, sh, xyz[3 * oa] + gd.tmpl_xyz[3 * it], xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1],
+                eval_group<GGA>(tp, xyz, rg, xyz[3 * oa] + gd.tmpl_xyz[3 * it], xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1],
                                 xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2], chi, gx, gy, gz, XM_RS, p);
             } else {
-                const int l = tp.sh_l[sh], ao = tp.sh_aoff[sh];
-                for (int m = 0; m < 2 * l + 1; ++m) {
-                    chi[(ao + m) * XM_RS + p] = 0.0;
-                    if (GGA) { gx[(ao + m) * XM_RS + p] = 0.0; gy[(ao + m) * XM_RS + p] = 0.0; gz[(ao + m) * XM_RS + p] = 0.0; }
-                }
+                zero_group<GGA>(tp, rg, chi, gx, gy, gz, XM_RS, p);
             }
         }
         const double w = (g0 + lo < gd.npts) ? wts[g0 + lo] : 0.0;
