@@ -32,9 +32,26 @@ __device__ __forceinline__ Dual operator+(Dual a, Dual b) { return {a.v + b.v, a
 __device__ __forceinline__ Dual operator-(Dual a, Dual b) { return {a.v - b.v, a.r - b.r, a.s - b.s}; }
 __device__ __forceinline__ Dual operator-(Dual a) { return {-a.v, -a.r, -a.s}; }
 __device__ __forceinline__ Dual operator*(Dual a, Dual b) { return {a.v * b.v, a.r * b.v + a.v * b.r, a.s * b.v + a.v * b.s}; }
+// hardware-seeded reciprocal and rsqrt + two Newton steps (<= 1 ulp): the functionals are division-heavy and are
+// evaluated once per wave and 16 points, so their instruction count is paid in full
+__device__ __forceinline__ double xc_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double xc_rsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = fma(y, fma(-hx * y, y, 0.5), y);
+    y = fma(y, fma(-hx * y, y, 0.5), y);
+    return y;
+}
 __device__ __forceinline__ Dual operator/(Dual a, Dual b)
 {
-    const double inv = 1.0 / b.v, q = a.v * inv;
+    const double inv = xc_rcp(b.v), q = a.v * inv;
     return {q, (a.r - q * b.r) * inv, (a.s - q * b.s) * inv};
 }
 __device__ __forceinline__ Dual operator+(Dual a, double b) { return {a.v + b, a.r, a.s}; }
@@ -43,27 +60,26 @@ __device__ __forceinline__ Dual operator-(Dual a, double b) { return {a.v - b, a
 __device__ __forceinline__ Dual operator-(double b, Dual a) { return {b - a.v, -a.r, -a.s}; }
 __device__ __forceinline__ Dual operator*(Dual a, double b) { return {a.v * b, a.r * b, a.s * b}; }
 __device__ __forceinline__ Dual operator*(double b, Dual a) { return {a.v * b, a.r * b, a.s * b}; }
-__device__ __forceinline__ Dual operator/(Dual a, double b) { const double i = 1.0 / b; return {a.v * i, a.r * i, a.s * i}; }
+__device__ __forceinline__ Dual operator/(Dual a, double b) { const double i = xc_rcp(b); return {a.v * i, a.r * i, a.s * i}; }
 __device__ __forceinline__ Dual operator/(double b, Dual a) { return mk(b) / a; }
 __device__ __forceinline__ Dual chain(Dual x, double f, double df) { return {f, df * x.r, df * x.s}; }
 __device__ __forceinline__ Dual dexp(Dual x) { const double f = exp(x.v); return chain(x, f, f); }
-__device__ __forceinline__ Dual dlog(Dual x) { return chain(x, log(x.v), 1.0 / x.v); }
-__device__ __forceinline__ Dual dsqrt(Dual x) { const double f = sqrt(x.v); return chain(x, f, 0.5 / f); }
-__device__ __forceinline__ Dual datan(Dual x) { return chain(x, atan(x.v), 1.0 / (1.0 + x.v * x.v)); }
-__device__ __forceinline__ Dual dasinh(Dual x) { return chain(x, asinh(x.v), 1.0 / sqrt(1.0 + x.v * x.v)); }
+__device__ __forceinline__ Dual dlog(Dual x) { return chain(x, log(x.v), xc_rcp(x.v)); }
+__device__ __forceinline__ Dual dsqrt(Dual x) { const double i = xc_rsqrt(x.v); return chain(x, x.v * i, 0.5 * i); }
+__device__ __forceinline__ Dual datan(Dual x) { return chain(x, atan(x.v), xc_rcp(1.0 + x.v * x.v)); }
+__device__ __forceinline__ Dual dasinh(Dual x) { return chain(x, asinh(x.v), xc_rsqrt(1.0 + x.v * x.v)); }
 __device__ __forceinline__ Dual dpow(Dual x, double p) { const double f = pow(x.v, p); return chain(x, f, p * f / x.v); }
-__device__ __forceinline__ Dual dcbrt(Dual x) { const double f = cbrt(x.v); return chain(x, f, f / (3.0 * x.v)); }
+__device__ __forceinline__ Dual dcbrt(Dual x) { const double f = cbrt(x.v); return chain(x, f, f * xc_rcp(3.0 * x.v)); }
 
 // ------------------------------------------------------------------ functionals: energy per volume
-__device__ __forceinline__ Dual f_lda_x(Dual rho)
+__device__ __forceinline__ Dual f_lda_x(Dual rho, Dual r13)
 {
-    const Dual r13 = dcbrt(rho);
     return -0.7385587663820224 * (rho * r13);                   // -(3/4)(3/pi)^(1/3) rho^(4/3)
 }
 
-__device__ __forceinline__ Dual f_vwn(Dual rho, double A, double x0, double b, double c)
+__device__ __forceinline__ Dual f_vwn(Dual rho, Dual r13, double A, double x0, double b, double c)
 {
-    const Dual rs = 0.6203504908994001 / dcbrt(rho);            // (3/(4 pi))^(1/3) rho^(-1/3)
+    const Dual rs = 0.6203504908994001 / r13;            // (3/(4 pi))^(1/3) rho^(-1/3)
     const Dual x = dsqrt(rs);
     const Dual X = x * x + b * x + c;
     const double X0 = x0 * x0 + b * x0 + c;
@@ -75,21 +91,21 @@ __device__ __forceinline__ Dual f_vwn(Dual rho, double A, double x0, double b, d
     return rho * ec;
 }
 
-__device__ __forceinline__ Dual f_b88(Dual rho, Dual sigma)
+__device__ __forceinline__ Dual f_b88(Dual rho, Dual r13, Dual sigma)
 {
     const double beta = 0.0042, cx = 0.9305257363491;             // (3/2)(3/(4 pi))^(1/3)
     const Dual rh = 0.5 * rho;
-    const Dual r43 = rh * dcbrt(rh);
+    const Dual r43 = rh * (0.7937005259840998 * r13);            // cbrt(rho/2) = 2^(-1/3) cbrt(rho)
     const Dual x = dsqrt(0.25 * sigma) / r43;
     const Dual e = -cx * r43 - beta * r43 * x * x / (1.0 + 6.0 * beta * x * dasinh(x));
     return 2.0 * e;
 }
 
-__device__ __forceinline__ Dual f_lyp(Dual rho, Dual sigma)
+__device__ __forceinline__ Dual f_lyp(Dual rho, Dual r13, Dual sigma)
 {
     const double a = 0.04918, b = 0.132, c = 0.2533, d = 0.349;
     const double cf = 2.871234000188191;                          // (3/10)(3 pi^2)^(2/3)
-    const Dual rm13 = 1.0 / dcbrt(rho);
+    const Dual rm13 = 1.0 / r13;
     const Dual den = 1.0 + d * rm13;
     const Dual delta = c * rm13 + d * rm13 / den;
     const Dual rm53 = rm13 * rm13 * rm13 * rm13 * rm13;
@@ -101,19 +117,17 @@ constexpr double PBE_GAMMA = 0.031090690869654895;                // (1 - ln 2)/
 constexpr double PBE_MU = 0.2195149727645171;
 constexpr double PBE_KAPPA = 0.804;
 
-__device__ __forceinline__ Dual f_pbe_x(Dual rho, Dual sigma)
+__device__ __forceinline__ Dual f_pbe_x(Dual rho, Dual r13, Dual sigma)
 {
-    const Dual r13 = dcbrt(rho);
     const Dual kf = 3.0936677262801355 * r13;                     // (3 pi^2)^(1/3) rho^(1/3)
     const Dual s2 = sigma / (4.0 * kf * kf * rho * rho);
     const Dual fx = (1.0 + PBE_KAPPA) - PBE_KAPPA / (1.0 + (PBE_MU / PBE_KAPPA) * s2);
-    return f_lda_x(rho) * fx;
+    return f_lda_x(rho, r13) * fx;
 }
 
-__device__ __forceinline__ Dual f_pbe_c(Dual rho, Dual sigma)
+__device__ __forceinline__ Dual f_pbe_c(Dual rho, Dual r13, Dual sigma)
 {
     const double A = 0.0310907, a1 = 0.21370, b1 = 7.5957, b2 = 3.5876, b3 = 1.6382, b4 = 0.49294;   // lda_c_pw_mod
-    const Dual r13 = dcbrt(rho);
     const Dual rs = 0.6203504908994001 / r13;
     const Dual srs = dsqrt(rs);
     const Dual q = 2.0 * A * (b1 * srs + b2 * rs + b3 * rs * srs + b4 * rs * rs);
@@ -134,16 +148,17 @@ __device__ __forceinline__ void eval_functional(const XcSpec& xc, double rho, do
     if (!(rho > XC_DENS_THRESHOLD)) return;
     const Dual R = {rho, 1.0, 0.0};
     const Dual S = {fmax(sigma, 1.0e-40), 0.0, 1.0};
+    const Dual R13 = dcbrt(R);          // every component needs rho^(1/3): formed once
     for (int k = 0; k < xc.ncomp; ++k) {
         Dual d;
         switch (xc.id[k]) {
-            case XC_LDA_X: d = f_lda_x(R); break;
-            case XC_LDA_C_VWN: d = f_vwn(R, 0.0310907, -0.10498, 3.72744, 12.9352); break;
-            case XC_LDA_C_VWN_RPA: d = f_vwn(R, 0.0310907, -0.409286, 13.0720, 42.7198); break;
-            case XC_GGA_X_B88: d = f_b88(R, S); break;
-            case XC_GGA_C_LYP: d = f_lyp(R, S); break;
-            case XC_GGA_X_PBE: d = f_pbe_x(R, S); break;
-            case XC_GGA_C_PBE: d = f_pbe_c(R, S); break;
+            case XC_LDA_X: d = f_lda_x(R, R13); break;
+            case XC_LDA_C_VWN: d = f_vwn(R, R13, 0.0310907, -0.10498, 3.72744, 12.9352); break;
+            case XC_LDA_C_VWN_RPA: d = f_vwn(R, R13, 0.0310907, -0.409286, 13.0720, 42.7198); break;
+            case XC_GGA_X_B88: d = f_b88(R, R13, S); break;
+            case XC_GGA_C_LYP: d = f_lyp(R, R13, S); break;
+            case XC_GGA_X_PBE: d = f_pbe_x(R, R13, S); break;
+            case XC_GGA_C_PBE: d = f_pbe_c(R, R13, S); break;
             default: d = mk(0.0);
         }
         f += xc.w[k] * d.v; vr += xc.w[k] * d.r; vs += xc.w[k] * d.s;
