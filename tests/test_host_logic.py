@@ -251,3 +251,35 @@ def test_vectorised_marshalling_layouts_match_ctypes():
         assert getattr(capi.Molecule, name).offset == methods._MOL_DTYPE.fields[name][1], name
     for name in methods._BAS_DTYPE.names:
         assert getattr(capi.Basis, name).offset == methods._BAS_DTYPE.fields[name][1], name
+
+
+# ---- vectorised MBE marshalling ------------------------------------------------------------------
+def test_fragment_groups_equal_fragment_by_fragment_construction():
+    """build_fragment_groups gathers whole MBE orders with one fancy index; every fragment must be exactly
+    what build_fragment makes for the same term (elements, coordinates bit for bit, charge)."""
+    system = mbe.water_cluster(3)
+    terms = mbe.generate_mbe_term_list(system, 2)
+    groups, positions = mbe.build_fragment_groups(system, terms)
+    seen = np.zeros(len(terms), dtype=int)
+    for grp, pos in zip(groups, positions):
+        assert grp.xyz.shape == (len(pos), len(grp.element_numbers), 3)
+        for k in range(0, len(pos), 7):
+            f = mbe.build_fragment(system, terms[pos[k]])
+            assert np.array_equal(f.element_numbers, grp.element_numbers)
+            assert np.array_equal(f.coordinates.T, grp.xyz[k])
+            assert int(grp.charge[k]) == f.charge
+        seen[pos] += 1
+    assert np.all(seen == 1)          # every term in exactly one group
+
+
+def test_result_record_view_matches_the_ctypes_struct():
+    """methods._RES_DTYPE is a numpy view of capi.ScfResult: same size, same field offsets."""
+    dt = methods._RES_DTYPE
+    assert dt.itemsize == ctypes.sizeof(capi.ScfResult)
+    for name, _ in capi.ScfResult._fields_:
+        assert dt.fields[name][1] == getattr(capi.ScfResult, name).offset
+    arr = (capi.ScfResult * 3)()
+    arr[1].e_total = -1.5; arr[1].iterations = 7; arr[2].has_error = 1; arr[2].message = b"boom"
+    rec = np.frombuffer(arr, dtype=dt)
+    assert rec["e_total"][1] == -1.5 and rec["iterations"][1] == 7
+    assert rec["has_error"][2] == 1 and bytes(rec["message"][2]).split(b"\0", 1)[0] == b"boom"
