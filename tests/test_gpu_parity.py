@@ -454,3 +454,44 @@ def test_large_batch_jk_variant_matches_small_batch_variant_and_oracle():
         assert not b.has_error, b.error_message
         assert a.scf_iterations == b.scf_iterations
         assert abs(a.energy.scf - b.energy.scf) < 1e-10
+
+
+# ---- concurrent topology groups ---------------------------------------------------------------------
+_LANES_CHILD = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from metalquicha_amd import methods
+from tests.helpers import fragment_bohr, water_at
+rng = np.random.default_rng(5)
+ws = [water_at(rng, [5.8 * i, 0.3 * (i % 2), 0.5 * (i % 3)]) for i in range(6)]
+frags = [fragment_bohr([8, 1, 1], w) for w in ws]
+frags += [fragment_bohr([8, 1, 1, 8, 1, 1], np.vstack([ws[i], ws[j]])) for i in range(6) for j in range(i + 1, 6)]
+frags += [fragment_bohr([8, 1, 1] * 3, np.vstack([ws[0], ws[1], ws[2]]))]
+kw = dict(basis_set="cc-pvdz", energy_tol=1e-9, density_tol=1e-7, guess="gwh")
+kw.update(json.loads(sys.argv[2]))
+res = methods.run_hip_scf_batch(methods.ScfSettings(**kw), frags)
+print(json.dumps({"e": [r.energy.scf for r in res], "it": [r.scf_iterations for r in res],
+                  "err": [r.error_message for r in res if r.has_error]}))
+"""
+
+
+@pytest.mark.parametrize("extra", [{}, {"functional": "b3lyp"}], ids=["rhf", "b3lyp"])
+def test_concurrent_topology_groups_match_sequential_execution(extra):
+    """Monomers, dimers and a trimer in one call = three topology groups; with MQC_HIP_CONCURRENT_GROUPS (default)
+    two host threads drive two of them at a time on separate slots.  Same iteration counts and energies as the
+    one-after-the-other execution."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(env_extra):
+        env = dict(os.environ, **env_extra)
+        out = subprocess.run([sys.executable, "-c", _LANES_CHILD, root, json.dumps(extra)], env=env, check=True,
+                             capture_output=True, text=True, timeout=600).stdout.strip().splitlines()[-1]
+        return json.loads(out)
+
+    both = run({})
+    seq = run({"MQC_HIP_CONCURRENT_GROUPS": "0"})
+    assert not both["err"] and not seq["err"], (both["err"], seq["err"])
+    assert both["it"] == seq["it"]
+    assert np.max(np.abs(np.array(both["e"]) - np.array(seq["e"]))) < 1e-10
