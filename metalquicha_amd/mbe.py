@@ -108,24 +108,51 @@ def build_fragment(system: FragmentedSystem, term: Sequence[int]) -> PhysicalFra
     return PhysicalFragment(system.element_numbers[atoms], system.coordinates[:, atoms].copy(), charge=charge)
 
 
+_MBE_PLAN_CACHE: Dict[Tuple[int, int], list] = {}
+
+
+def _mbe_plan(terms: Sequence[Tuple[int, ...]]):
+    """Per order k (ascending): indices of the k-body terms and, per term, the indices of all its proper
+    sub-terms.  Depends on the term list only, so it is cached (an MBE driver assembles the same list again
+    and again)."""
+    key = (len(terms), hash(tuple(map(tuple, terms))))
+    plan = _MBE_PLAN_CACHE.get(key)
+    if plan is not None:
+        return plan
+    lookup = {tuple(t): i for i, t in enumerate(terms)}
+    by_order: Dict[int, List[int]] = {}
+    for i, t in enumerate(terms):
+        by_order.setdefault(len(t), []).append(i)
+    plan = []
+    for k in sorted(by_order):
+        idx = np.asarray(by_order[k])
+        subs = []
+        for i in idx:
+            t = terms[i]
+            row = []
+            for m in range(1, k):
+                for sub in itertools.combinations(t, m):
+                    j = lookup.get(sub)
+                    if j is None:
+                        raise KeyError("Subset not found in bottom-up MBE: %s of %s" % (sub, t))
+                    row.append(j)
+            subs.append(row)
+        plan.append((k, idx, np.asarray(subs, dtype=np.int64).reshape(len(idx), -1)))
+    if len(_MBE_PLAN_CACHE) >= 8:
+        _MBE_PLAN_CACHE.clear()
+    _MBE_PLAN_CACHE[key] = plan
+    return plan
+
+
 def compute_mbe(terms: Sequence[Tuple[int, ...]], energies: Sequence[float]):
     """Bottom-up many-body deltas; returns (total, per-order sums, delta per term)."""
-    lookup = {tuple(t): i for i, t in enumerate(terms)}
-    order = sorted(range(len(terms)), key=lambda i: len(terms[i]))
+    e = np.asarray(energies, dtype=np.float64)
     delta = np.zeros(len(terms))
-    for i in order:
-        t = terms[i]
-        d = energies[i]
-        for k in range(1, len(t)):
-            for sub in itertools.combinations(t, k):
-                j = lookup.get(sub)
-                if j is None:
-                    raise KeyError("Subset not found in bottom-up MBE: %s of %s" % (sub, t))
-                d -= delta[j]
-        delta[i] = d
     by_order: Dict[int, float] = {}
-    for i, t in enumerate(terms):
-        by_order[len(t)] = by_order.get(len(t), 0.0) + delta[i]
+    for k, idx, subs in _mbe_plan(terms):
+        d = e[idx] - (delta[subs].sum(axis=1) if subs.shape[1] else 0.0)
+        delta[idx] = d
+        by_order[k] = float(np.sum(d))
     return float(np.sum(delta)), by_order, delta
 
 
@@ -156,16 +183,18 @@ class MbeRun:
     errors: List[str]
 
 
-def build_fragment_groups(system: FragmentedSystem, term_list: Sequence[Tuple[int, ...]]):
-    """The fragments of `term_list` as engine batches: terms of one order whose atoms carry the same element
-    sequence form one FragmentGroup (coordinates gathered with one fancy index).  Returns (groups, positions)
-    where positions[g][k] is the index into term_list of the k-th fragment of group g."""
-    from .methods import FragmentGroup
-    coords = np.ascontiguousarray(system.coordinates.T)           # (n_atoms, 3)
+def _group_layout(system: FragmentedSystem, term_list: Sequence[Tuple[int, ...]]):
+    """Geometry-independent part of build_fragment_groups: per group (element sequence, atom index array
+    (m, n_atoms), charges, positions in term_list).  Cached on the system per term list: a driver that evaluates
+    the same expansion again (new coordinates or not) only regathers coordinates."""
+    key = (len(term_list), hash(tuple(map(tuple, term_list))))
+    cache = system.__dict__.setdefault("_layout_cache", {})
+    if key in cache:
+        return cache[key]
     by_shape: Dict[Tuple[int, ...], List[int]] = {}
     for pos, t in enumerate(term_list):
         by_shape.setdefault(tuple(len(system.monomers[m]) for m in t), []).append(pos)
-    groups, positions = [], []
+    layout = []
     for shape, plist in by_shape.items():
         plist = np.asarray(plist)
         if len(set(shape)) == 1 and all(len(m) == shape[0] for m in system.monomers):
@@ -183,8 +212,23 @@ def build_fragment_groups(system: FragmentedSystem, term_list: Sequence[Tuple[in
             charges = np.array([int(sum(ch[m] for m in term_list[p])) for p in plist], dtype=np.int32)
         for u in range(len(uniq)):
             sel = np.nonzero(inverse == u)[0]
-            groups.append(FragmentGroup(uniq[u].astype(np.int32), coords[atoms[sel]], charges[sel]))
-            positions.append(plist[sel])
+            layout.append((uniq[u].astype(np.int32), np.ascontiguousarray(atoms[sel]), charges[sel], plist[sel]))
+    if len(cache) >= 8:
+        cache.clear()
+    cache[key] = layout
+    return layout
+
+
+def build_fragment_groups(system: FragmentedSystem, term_list: Sequence[Tuple[int, ...]]):
+    """The fragments of `term_list` as engine batches: terms of one order whose atoms carry the same element
+    sequence form one FragmentGroup (coordinates gathered with one fancy index).  Returns (groups, positions)
+    where positions[g][k] is the index into term_list of the k-th fragment of group g."""
+    from .methods import FragmentGroup
+    coords = np.ascontiguousarray(system.coordinates.T)           # (n_atoms, 3)
+    groups, positions = [], []
+    for z, atoms, charges, pos in _group_layout(system, term_list):
+        groups.append(FragmentGroup(z, coords[atoms], charges))
+        positions.append(pos)
     return groups, positions
 
 
