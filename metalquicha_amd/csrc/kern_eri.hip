@@ -138,7 +138,11 @@ static void plan_sharing(const Topology& topo, const double* host_xyz, int nfrag
             if (k == 0 || keys[k].first != keys[k - 1].first) { head = k; ++nu; }
             rep[keys[k].second] = keys[head].second;
         }
-        if ((size_t)nu * 2 > (size_t)nfrag) continue;      // too few repeats to pay for the copy
+        // too few repeats do not pay: the task-list launches are latency-bound (one wave per entry and distinct
+        // geometry) and become the critical path of a small batch -- measured on one rank's share of the (H2O)64
+        // job: 8-way split (252 dimers, 4 repeats) 41.7 ms with sharing, 35.9 ms without; 4-way split (8 repeats)
+        // 56.7 against 58.4 ms
+        if ((size_t)nu * 6 > (size_t)nfrag) continue;
         plan.shared_row[sidx] = rows++;
         auto& uq = plan.uniq[sidx];
         for (int f = 0; f < nfrag; ++f) if (rep[f] == f) uq.push_back(f);

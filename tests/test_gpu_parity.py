@@ -390,10 +390,11 @@ sys.path.insert(0, sys.argv[1])
 from metalquicha_amd import methods
 from tests.helpers import fragment_bohr, water_at
 rng = np.random.default_rng(11)
-ws = [water_at(rng, [5.9 * i, 0.5 * (i % 3), -0.4 * (i % 2)]) for i in range(7)]
-# 21 dimers built from 7 monomers (every monomer geometry repeats bit for bit in 6 dimers) + 3 odd ones out
-frags = [fragment_bohr([8, 1, 1, 8, 1, 1], np.vstack([ws[i], ws[j]])) for i in range(7) for j in range(i + 1, 7)]
-frags += [fragment_bohr([8, 1, 1, 8, 1, 1], np.vstack([water_at(rng, [0, 9.0 + k, 0]), water_at(rng, [5.5, 9.0 + k, 1.0])])) for k in range(3)]
+ws = [water_at(rng, [5.9 * (i % 4), 5.9 * (i // 4), -0.4 * (i % 2)]) for i in range(13)]
+# 78 dimers built from 13 monomers (every monomer geometry repeats bit for bit in 12 dimers: the engine shares atom
+# sets that repeat at least 6 times) + 3 odd ones out
+frags = [fragment_bohr([8, 1, 1, 8, 1, 1], np.vstack([ws[i], ws[j]])) for i in range(13) for j in range(i + 1, 13)]
+frags += [fragment_bohr([8, 1, 1, 8, 1, 1], np.vstack([water_at(rng, [0, 29.0 + k, 0]), water_at(rng, [5.5, 29.0 + k, 1.0])])) for k in range(3)]
 kw = dict(basis_set=sys.argv[2], energy_tol=1e-9, density_tol=1e-7, guess="gwh", eri_mode="incore")
 res = methods.run_hip_scf_batch(methods.ScfSettings(**kw), frags)
 print(json.dumps({"e": [r.energy.scf for r in res], "it": [r.scf_iterations for r in res],
