@@ -374,8 +374,41 @@ void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, h
         (void)hipEventRecord(st.fork, s);
         for (int k = 0; k < ERI_SIDE_STREAMS; ++k) (void)hipStreamWaitEvent(st.side[k], st.fork, 0);
     }
-    int rr = 0, rd = 0;
-    auto dense_stream = [&]() { if (!spread) return s; const int k = rd++ % (ERI_SIDE_STREAMS + 1); return k == 0 ? s : st.side[k - 1]; };
+    int rr = 0;
+    // spread mode: longest-processing-time-first assignment of the class launches to the 1 + ERI_SIDE_STREAMS
+    // streams.  A small-batch launch lasts as long as its heaviest thread: primitive quartets of the first (deepest)
+    // entry x work per primitive quartet x passes.
+    std::vector<int> lane_of(cc->launches.size(), 0), issue_order;
+    if (spread) {
+        std::vector<std::pair<double, int>> cost(cc->launches.size());
+        for (size_t k = 0; k < cc->launches.size(); ++k) {
+            const EriLaunch& L = cc->launches[k];
+            const auto& cl = topo.classes[L.cls];
+            double c = 0.0;
+            if (L.dense_n > 0) {
+                const int* e = cc->host.data() + L.dense_off;
+                double prims = 1.0;
+                for (int q = 0; q < 4; ++q) prims *= topo.shells[e[q] & 0xffff].nprim;
+                const int nc = ncart(cl.la) * ncart(cl.lb) * ncart(cl.lc) * ncart(cl.ld);
+                const int passes = eri_uses_passes(cl.la, cl.lb, cl.lc, cl.ld)
+                                       ? (nsph(cl.lc) * nsph(cl.ld) + eri_pass_chunk(cl.la, cl.lb, cl.lc, cl.ld) - 1) / eri_pass_chunk(cl.la, cl.lb, cl.lc, cl.ld)
+                                       : 1;
+                c = prims * (nc + 8.0 * nherm(cl.la + cl.lb + cl.lc + cl.ld)) * passes * (L.twin ? 1.5 : 1.0);
+            }
+            cost[k] = {c, (int)k};
+        }
+        std::sort(cost.begin(), cost.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+        for (auto& ck : cost) issue_order.push_back(ck.second);
+        double load[ERI_SIDE_STREAMS + 1] = {};
+        for (auto& ck : cost) {
+            int best = 0;
+            for (int q = 1; q <= ERI_SIDE_STREAMS; ++q) if (load[q] < load[best]) best = q;
+            load[best] += ck.first;
+            lane_of[ck.second] = best;
+        }
+    }
+    int li = 0;
+    auto dense_stream = [&]() { if (!spread) return s; const int k = lane_of[li]; return k == 0 ? s : st.side[k - 1]; };
 #define ERI_CASE(a, b, c, d_)                                                                                         \
     if (cl.la == a && cl.lb == b && cl.lc == c && cl.ld == d_) {                                                      \
         launch_eri_class<a, b, c, d_>(bv, d + L.dense_off, L.dense_n, nullptr, 0, Q, thresh, dense_stream());         \
@@ -386,7 +419,13 @@ void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, h
         launch_eri_twin_class<a, b, c, d_>(bv, d + L.dense_off, L.dense_n, nullptr, 0, Q, thresh, dense_stream());    \
         launch_eri_twin_class<a, b, c, d_>(bv, d + L.sh_off, L.sh_n, d + L.task_off, L.ntasks, Q, thresh, st.side[rr++ % ERI_SIDE_STREAMS]); \
     }
-    for (const EriLaunch& L : cc->launches) {
+    // in spread mode the launches are issued heaviest first (stream order = issue order)
+    std::vector<int> order(cc->launches.size());
+    for (size_t k = 0; k < order.size(); ++k) order[k] = (int)k;
+    if (spread) order = issue_order;
+    for (size_t oi = 0; oi < order.size(); ++oi) {
+        li = order[oi];
+        const EriLaunch& L = cc->launches[li];
         const auto& cl = topo.classes[L.cls];
         if (L.twin) {
             TWIN_CASE(0, 0, 0, 0) TWIN_CASE(1, 0, 0, 0) TWIN_CASE(1, 0, 1, 0) TWIN_CASE(1, 1, 0, 0)
