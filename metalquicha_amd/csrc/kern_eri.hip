@@ -366,9 +366,13 @@ void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, h
     // ---- launches: dense lists on the caller's stream; the task-list launches of shared entries (few, long
     // threads: one wave per entry and distinct geometry) on a side stream so that they fill gaps instead of
     // serialising; both join before the copy kernel
-    // Small batches (a few dozen monomers) give every class launch only a handful of long-running waves: the
-    // classes are then spread over the side streams as well, so their critical paths overlap instead of adding up.
-    const bool spread = bv.nfrag <= 256;
+    // The class launches are spread over the caller's stream and the side streams: small batches give every launch
+    // only a handful of long-running waves, and even a full batch has a tail per launch; with the launches placed
+    // longest-first their critical paths overlap instead of adding up.
+    // (measured with the longest-first assignment below: 2016 dimers 127.3 -> 124 ms, 1008: 75.3 -> 70.8, 504: 55.0 ->
+    // 49.5, so every batch is spread; MQC_HIP_ERI_SPREAD_MAX=n keeps batches above n fragments on one stream)
+    static const int spread_max = [] { const char* e = std::getenv("MQC_HIP_ERI_SPREAD_MAX"); return e ? std::atoi(e) : (1 << 30); }();
+    const bool spread = bv.nfrag <= spread_max;
     const bool forked = cc->shared || spread;
     if (forked) {
         (void)hipEventRecord(st.fork, s);
