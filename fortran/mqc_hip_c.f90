@@ -75,6 +75,15 @@ module mqc_hip_c
       type(c_ptr) :: density
       integer(c_int32_t) :: has_error
       character(kind=c_char) :: message(256)
+      ! ABI 2
+      real(c_double) :: dipole(3)              !! electron-Bohr, origin = centre of nuclear charge
+      integer(c_int32_t) :: has_dipole
+      type(c_ptr) :: gradient                  !! optional out, double [3*n_atoms] atom-major == gradient(3,n_atoms)
+      integer(c_int32_t) :: has_gradient
+      type(c_ptr) :: orbital_energies_beta
+      integer(c_int32_t) :: n_alpha
+      integer(c_int32_t) :: n_beta
+      real(c_double) :: s_squared
    end type
 
    public :: mqc_hip_backend_available, mqc_hip_context_get, mqc_hip_finalize, mqc_hip_last_error, &

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MQC_HIP_ABI_VERSION 1
+#define MQC_HIP_ABI_VERSION 2
 
 /* status codes (0 = ok).  VALIDATION mirrors ERROR_VALIDATION, GENERIC mirrors ERROR_GENERIC
  * (src/utils/mqc_error.f90:22-44). */
@@ -125,10 +125,20 @@ typedef struct {
     double homo;                     /* orbital energies, Hartree */
     double lumo;
     int32_t has_orbitals;
-    double *orbital_energies;        /* optional out [n_mo capacity >= n_ao] or NULL */
-    double *density;                 /* optional out [n_ao*n_ao] row-major or NULL */
+    double *orbital_energies;        /* optional out [n_mo capacity >= n_ao] or NULL (alpha spin when unrestricted) */
+    double *density;                 /* optional out [n_ao*n_ao] row-major or NULL (total density) */
     int32_t has_error;
     char message[256];
+    /* ABI 2 */
+    double dipole[3];                /* result%dipole, electron-Bohr, origin = centre of nuclear charge
+                                        (system_compute_dipole, mqc_cuest_integrals.f90:1443-1521) */
+    int32_t has_dipole;
+    double *gradient;                /* optional out [3*n_atoms] atom-major, Hartree/Bohr: result%gradient(3,n_atoms);
+                                        filled when opts->want_gradient and the pointer is not NULL */
+    int32_t has_gradient;
+    double *orbital_energies_beta;   /* optional out [n_ao] or NULL; written by unrestricted runs */
+    int32_t n_alpha, n_beta;         /* occupied orbitals per spin (n_occ = n_alpha) */
+    double s_squared;                /* <S^2> of the unrestricted determinant, 0 for restricted */
 } mqc_hip_scf_result_t;
 
 /* ---- lifecycle -------------------------------------------------------------------- */
@@ -190,6 +200,11 @@ typedef struct {
     /* the same three J/K figures restricted to launches that streamed >= 1 GiB (the dominant kernel of a large batch) */
     int64_t fock_big_launches;
     double fock_big_seconds, fock_big_bytes;
+    /* ABI 2 */
+    double xc_flops;              /* 8 P n^2 per GGA launch (4 P n^2 LDA), summed: SURVEY.md section 8d's algorithmic count */
+    double scf_step_seconds;      /* HIP-event time of the per-iteration SCF-step kernel */
+    int64_t eri_survivors;        /* shell quartets the integral stage actually formed (Schwarz survivors, shared blocks once) */
+    double df_flops, df_bytes;    /* DF J/K: 4 n^2 A (1 + o) flop and 8 n^2 A bytes per fragment-iteration, summed */
 } mqc_hip_stats_t;
 int mqc_hip_get_stats(mqc_hip_context *ctx, mqc_hip_stats_t *stats);
 int mqc_hip_device_name(mqc_hip_context *ctx, char *buf, int32_t len);

@@ -54,7 +54,9 @@ class ScfResult(C.Structure):
                 ("e_xc", C.c_double), ("scf_status", C.c_int32), ("iterations", C.c_int32),
                 ("n_ao", C.c_int32), ("n_mo", C.c_int32), ("n_occ", C.c_int32), ("homo", C.c_double),
                 ("lumo", C.c_double), ("has_orbitals", C.c_int32), ("orbital_energies", c_double_p),
-                ("density", c_double_p), ("has_error", C.c_int32), ("message", C.c_char * 256)]
+                ("density", c_double_p), ("has_error", C.c_int32), ("message", C.c_char * 256),
+                ("dipole", C.c_double * 3), ("has_dipole", C.c_int32), ("gradient", c_double_p), ("has_gradient", C.c_int32),
+                ("orbital_energies_beta", c_double_p), ("n_alpha", C.c_int32), ("n_beta", C.c_int32), ("s_squared", C.c_double)]
 
 
 class Stats(C.Structure):
@@ -64,7 +66,9 @@ class Stats(C.Structure):
                 ("scf_iterations_total", C.c_int64), ("fock_kernel_seconds", C.c_double),
                 ("fock_bytes", C.c_double), ("eri_kernel_seconds", C.c_double),
                 ("xc_kernel_seconds", C.c_double), ("xc_points", C.c_double),
-                ("fock_big_launches", C.c_int64), ("fock_big_seconds", C.c_double), ("fock_big_bytes", C.c_double)]
+                ("fock_big_launches", C.c_int64), ("fock_big_seconds", C.c_double), ("fock_big_bytes", C.c_double),
+                ("xc_flops", C.c_double), ("scf_step_seconds", C.c_double), ("eri_survivors", C.c_int64),
+                ("df_flops", C.c_double), ("df_bytes", C.c_double)]
 
 
 DECLARED_SYMBOLS = [

@@ -134,7 +134,7 @@ static size_t per_fragment_main_doubles(int n, int natoms)
     return 9 * nn      // S H X F D C J K Vprev
            + 6 * nn    // W
            + 2 * DIIS_MAX * nn   // DIIS histories
-           + DIIS_MAX * DIIS_MAX + n + 8 + 3 * (size_t)natoms + 8;   // diis_b, eps, scal, xyz, ints (padded)
+           + DIIS_MAX * DIIS_MAX + n + 8 + 3 * (size_t)natoms + 8 + 4;   // diis_b, eps, scal, xyz, ints (padded), dipole
 }
 
 // One pipeline slot: a stream with its own pools and events.  While the SCF loop of chunk k runs on
@@ -146,6 +146,7 @@ struct Slot {
     DevicePool *main, *eri, *misc, *gridw, *df;
     hipEvent_t e0, e1, e2, e3, q0, q1;
     int* h_counter;
+    hipEvent_t s0 = nullptr, s1 = nullptr;
 };
 
 // carve one chunk's arrays out of the slot's pools
@@ -153,7 +154,7 @@ static int carve_batch(mqc_hip_context* ctx, Slot& sl, const Topology& topo, con
 {
     const int n = topo.nao;
     const size_t nn = (size_t)n * n, nf = (size_t)nfrag;
-    const size_t main_bytes = sizeof(double) * nf * per_fragment_main_doubles(n, topo.natoms) + 4096;
+    const size_t main_bytes = sizeof(double) * nf * per_fragment_main_doubles(n, topo.natoms) + 8192;
     char* base = (char*)sl.main->ensure(main_bytes);
     if (!base) return fail(MQC_HIP_ERR_DEVICE, "out of device memory (SCF matrices)");
     auto take = [&base](size_t b) { char* p = base; base += (b + 255) & ~size_t(255); return p; };
@@ -171,10 +172,12 @@ static int carve_batch(mqc_hip_context* ctx, Slot& sl, const Topology& topo, con
     bv.diis_b = (double*)take(sizeof(double) * nf * DIIS_MAX * DIIS_MAX);
     bv.eps = (double*)take(sizeof(double) * nf * n);
     bv.scal = (double*)take(sizeof(double) * nf * 8);
+    bv.dip = (double*)take(sizeof(double) * nf * 4);
     bv.diis_state = (int*)take(sizeof(int) * nf * 2);
     bv.istate = (int*)take(sizeof(int) * nf * 4);
     bv.counters = (int*)sl.misc->ensure(256);
     if (!bv.counters) return fail(MQC_HIP_ERR_DEVICE, "out of device memory (counters)");
+    bv.eri_count = (unsigned long long*)(bv.counters + 16);
     bv.eri = nullptr;
     if (with_eri) {
         const size_t np = (size_t)topo.npair;
@@ -277,9 +280,9 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         std::vector<double> txyz, tw, sb(topo.natoms);
         std::vector<int> pt_atom, pt_tmpl;
         for (int a = 0; a < topo.natoms; ++a) {
-            const int z = topo.Z[a];
-            sb[a] = std::sqrt(bragg_radius_bohr((topo.zeff[a] == 0.0) ? 0 : z)) + 1e-200;
-            // ghost atoms still own grid points in the reference (atomic_numbers are passed unchanged)
+            // a ghost centre enters the grid builder with Z = 0 (numbers = nint(mol%charges), mqc_libcint_xc.F90:181-183):
+            // period-1 sizes, xi(0) = 1, Bragg radius(0) = 2 Angstrom -- it still owns grid points
+            const int z = (topo.zeff[a] == 0.0) ? 0 : topo.Z[a];
             sb[a] = std::sqrt(bragg_radius_bohr(z)) + 1e-200;
             if (!tmpl_of_z.count(z)) {
                 std::vector<double> x, w; std::string e;
@@ -343,9 +346,9 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
     HIP_CHECK_RET(hipHostMalloc((void**)&h_counter, 256));
     Slot slots[2] = {
         {0, ctx->stream, &ctx->pool_main, &ctx->pool_eri, &ctx->pool_misc, &ctx->pool_gridw, &ctx->pool_df,
-         ctx->ev0, ctx->ev1, ctx->ev2, ctx->ev3, ctx->evq0, ctx->evq1, h_counter},
+         ctx->ev0, ctx->ev1, ctx->ev2, ctx->ev3, ctx->evq0, ctx->evq1, h_counter, ctx->evs[0][0], ctx->evs[0][1]},
         {1, ctx->stream2, &ctx->pool_main2, &ctx->pool_eri2, &ctx->pool_misc2, &ctx->pool_gridw2, &ctx->pool_df2,
-         ctx->evb0, ctx->evb1, ctx->evb2, ctx->evb3, ctx->evq2, ctx->evq3, h_counter + 32}};
+         ctx->evb0, ctx->evb1, ctx->evb2, ctx->evb3, ctx->evq2, ctx->evq3, h_counter + 32, ctx->evs[1][0], ctx->evs[1][1]}};
 
     struct Job { int start = 0, nf = 0; BatchView bv{}; std::vector<double> hx; };
     std::vector<Job> jobs;
@@ -392,6 +395,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         for (int f = 0; f < nf; ++f) std::memcpy(&job.hx[(size_t)f * topo.natoms * 3], xyz[job.start + f], sizeof(double) * topo.natoms * 3);
         HIP_CHECK_RET(hipMemcpyAsync(bv.xyz, job.hx.data(), sizeof(double) * job.hx.size(), hipMemcpyHostToDevice, s));
         HIP_CHECK_RET(hipMemsetAsync(bv.istate, 0, sizeof(int) * (size_t)nf * 4, s));
+        HIP_CHECK_RET(hipMemsetAsync(bv.eri_count, 0, sizeof(unsigned long long), s));
         const double t1 = now_s();
         sx->stats.t_setup += t1 - t0;
 
@@ -453,11 +457,19 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
                 launch_xc(bv, true, s);
                 HIP_CHECK_RET(hipEventRecord(sl.e3, s));
             }
+            HIP_CHECK_RET(hipEventRecord(sl.s0, s));
             launch_scf_step(bv, s);
+            HIP_CHECK_RET(hipEventRecord(sl.s1, s));
             HIP_CHECK_RET(hipMemcpyAsync(sl.h_counter, bv.counters, sizeof(int), hipMemcpyDeviceToHost, s));
             HIP_CHECK_RET(hipStreamSynchronize(s));
             float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, sl.s0, sl.s1);
+            sx->stats.scf_step_seconds += ms * 1e-3;
             (void)hipEventElapsedTime(&ms, sl.e0, sl.e1);
+            if (use_df) {
+                sx->stats.df_bytes += (double)remaining * 8.0 * (double)naux * (double)n * (double)n;
+                sx->stats.df_flops += (double)remaining * 4.0 * (double)naux * (double)n * (double)n * (1.0 + (xc.exx != 0.0 ? (double)nocc : 0.0));
+            }
             const double launch_bytes = use_df ? (double)remaining * 2.0 * (double)naux * (double)np * 8.0
                                                : (double)remaining * (double)np * (double)np * 8.0;
             sx->stats.fock_kernel_seconds += ms * 1e-3;
@@ -471,6 +483,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
                 (void)hipEventElapsedTime(&mx, sl.e2, sl.e3);
                 sx->stats.xc_kernel_seconds += mx * 1e-3;
                 sx->stats.xc_points += (double)remaining * grid.npts;
+                sx->stats.xc_flops += (double)remaining * grid.npts * (xc.gga ? 8.0 : 4.0) * (double)n * (double)n;
             }
             remaining = sl.h_counter[0];
             ++guard;
@@ -479,12 +492,17 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         const double t4 = now_s();
         sx->stats.t_fock += t4 - t3;
 
-        std::vector<double> scal((size_t)nf * 8), eps((size_t)nf * n);
+        std::vector<double> scal((size_t)nf * 8), eps((size_t)nf * n), dip((size_t)nf * 4);
         std::vector<int> ist((size_t)nf * 4);
+        unsigned long long formed = 0;
+        launch_dipole(bv, topo, s);
+        HIP_CHECK_RET(hipMemcpyAsync(dip.data(), bv.dip, sizeof(double) * dip.size(), hipMemcpyDeviceToHost, s));
+        HIP_CHECK_RET(hipMemcpyAsync(&formed, bv.eri_count, sizeof(formed), hipMemcpyDeviceToHost, s));
         HIP_CHECK_RET(hipMemcpyAsync(scal.data(), bv.scal, sizeof(double) * scal.size(), hipMemcpyDeviceToHost, s));
         HIP_CHECK_RET(hipMemcpyAsync(eps.data(), bv.eps, sizeof(double) * eps.size(), hipMemcpyDeviceToHost, s));
         HIP_CHECK_RET(hipMemcpyAsync(ist.data(), bv.istate, sizeof(int) * ist.size(), hipMemcpyDeviceToHost, s));
         HIP_CHECK_RET(hipStreamSynchronize(s));
+        sx->stats.eri_survivors += (int64_t)formed;
         for (int f = 0; f < nf; ++f) {
             mqc_hip_scf_result_t* r = results[job.start + f];
             const int nmo = ist[4 * f + 2];
@@ -505,6 +523,18 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
             r->homo = eps[(size_t)f * n + nocc - 1];
             r->lumo = nocc < nmo ? eps[(size_t)f * n + nocc] : 0.0;
             r->has_orbitals = 1;
+            r->n_alpha = nocc; r->n_beta = nocc; r->s_squared = 0.0;
+            {
+                // mu = sum_A Z_A (R_A - O) - [tr(D r) - O tr(D S)], O = centre of nuclear charge, tr(D S) = N_electrons
+                // (system_compute_dipole, mqc_cuest_integrals.f90:1443-1521)
+                const double* x = xyz[job.start + f];
+                double ztot = 0.0, o[3] = {0, 0, 0}, mu[3] = {0, 0, 0};
+                for (int a = 0; a < topo.natoms; ++a) { ztot += topo.zeff[a]; for (int c = 0; c < 3; ++c) o[c] += topo.zeff[a] * x[3 * a + c]; }
+                if (ztot > 0.0) for (int c = 0; c < 3; ++c) o[c] /= ztot; else for (int c = 0; c < 3; ++c) o[c] = 0.0;
+                for (int a = 0; a < topo.natoms; ++a) for (int c = 0; c < 3; ++c) mu[c] += topo.zeff[a] * (x[3 * a + c] - o[c]);
+                for (int c = 0; c < 3; ++c) r->dipole[c] = mu[c] - (dip[4 * f + c] - o[c] * (double)topo.nelec);
+                r->has_dipole = 1;
+            }
             if (r->orbital_energies) std::memcpy(r->orbital_energies, &eps[(size_t)f * n], sizeof(double) * nmo);
             if (r->density) {
                 HIP_CHECK_RET(hipMemcpyAsync(r->density, bv.D + (size_t)f * n * n, sizeof(double) * n * n, hipMemcpyDeviceToHost, s));
@@ -553,6 +583,8 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         g.fock_bytes += l.fock_bytes; g.eri_kernel_seconds += l.eri_kernel_seconds;
         g.xc_kernel_seconds += l.xc_kernel_seconds; g.xc_points += l.xc_points;
         g.fock_big_launches += l.fock_big_launches; g.fock_big_seconds += l.fock_big_seconds; g.fock_big_bytes += l.fock_big_bytes;
+        g.xc_flops += l.xc_flops; g.scf_step_seconds += l.scf_step_seconds; g.eri_survivors += l.eri_survivors;
+        g.df_flops += l.df_flops; g.df_bytes += l.df_bytes;
     }
     return MQC_HIP_OK;
 }
@@ -609,6 +641,7 @@ int mqc_hip_context_get(int32_t local_rank, mqc_hip_context** out)
     HIP_CHECK_RET(hipStreamCreate(&ctx->stream2));
     for (int k = 0; k < 3; ++k) HIP_CHECK_RET(hipStreamCreateWithFlags(&ctx->side[1][k], hipStreamNonBlocking));
     for (int l = 0; l < 2; ++l) for (int k = 0; k < 2; ++k) HIP_CHECK_RET(hipEventCreateWithFlags(&ctx->evo[l][k], hipEventDisableTiming));
+    for (int l = 0; l < 2; ++l) for (int k = 0; k < 2; ++k) HIP_CHECK_RET(hipEventCreate(&ctx->evs[l][k]));
     eri_set_side_streams(0, ctx->side[0], 3);
     eri_set_side_streams(1, ctx->side[1], 3);
     for (hipEvent_t* e : {&ctx->evb0, &ctx->evb1, &ctx->evb2, &ctx->evb3, &ctx->evq0, &ctx->evq1, &ctx->evq2, &ctx->evq3})
@@ -651,10 +684,15 @@ int mqc_hip_finalize(void)
     (void)hipSetDevice(g_ctx->device);
     (void)hipStreamSynchronize(g_ctx->stream);
     (void)hipStreamSynchronize(g_ctx->stream2);
-    g_ctx->pool_topo2.release(); g_ctx->pool_aux2.release(); g_ctx->pool_grid2.release();
-    g_ctx->pool_main2.release(); g_ctx->pool_eri2.release(); g_ctx->pool_misc2.release(); g_ctx->pool_gridw2.release(); g_ctx->pool_df2.release();
-    g_ctx->pool_main.release(); g_ctx->pool_eri.release(); g_ctx->pool_topo.release(); g_ctx->pool_misc.release();
-    g_ctx->pool_grid.release(); g_ctx->pool_gridw.release(); g_ctx->pool_aux.release(); g_ctx->pool_df.release();
+    for (int l = 0; l < 2; ++l) for (int k = 0; k < 3; ++k) if (g_ctx->side[l][k]) (void)hipStreamSynchronize(g_ctx->side[l][k]);
+    // launcher state bound to this device (side streams, fork/join events, list caches), then every pool:
+    // the context's own and the launchers' function-static ones -- a later context_get starts from nothing
+    eri_reset_state();
+    release_all_pools();
+    for (int l = 0; l < 2; ++l) {
+        for (int k = 0; k < 3; ++k) if (g_ctx->side[l][k]) (void)hipStreamDestroy(g_ctx->side[l][k]);
+        for (int k = 0; k < 2; ++k) { if (g_ctx->evo[l][k]) (void)hipEventDestroy(g_ctx->evo[l][k]); if (g_ctx->evs[l][k]) (void)hipEventDestroy(g_ctx->evs[l][k]); }
+    }
     if (g_ctx->d_unit) (void)hipFree(g_ctx->d_unit);
     if (g_ctx->d_boys) (void)hipFree(g_ctx->d_boys);
     if (g_ctx->d_c2s) (void)hipFree(g_ctx->d_c2s);
@@ -678,6 +716,7 @@ int mqc_hip_device_name(mqc_hip_context* ctx, char* buf, int32_t len)
 int mqc_hip_get_stats(mqc_hip_context* ctx, mqc_hip_stats_t* st)
 {
     if (!ctx || !st) return fail(MQC_HIP_ERR_VALIDATION, "bad arguments");
+    std::lock_guard<std::mutex> lock(ctx->stats_mutex);
     st->t_setup = ctx->stats.t_setup; st->t_int1e = ctx->stats.t_int1e; st->t_eri = ctx->stats.t_eri;
     st->t_fock = ctx->stats.t_fock; st->t_scf_step = ctx->stats.t_scf_step; st->t_total = ctx->stats.t_total;
     st->fock_launches = ctx->stats.fock_launches; st->eri_quartets = ctx->stats.eri_quartets;
@@ -687,15 +726,17 @@ int mqc_hip_get_stats(mqc_hip_context* ctx, mqc_hip_stats_t* st)
     st->xc_kernel_seconds = ctx->stats.xc_kernel_seconds; st->xc_points = ctx->stats.xc_points;
     st->fock_big_launches = ctx->stats.fock_big_launches; st->fock_big_seconds = ctx->stats.fock_big_seconds;
     st->fock_big_bytes = ctx->stats.fock_big_bytes;
+    st->xc_flops = ctx->stats.xc_flops; st->scf_step_seconds = ctx->stats.scf_step_seconds;
+    st->eri_survivors = ctx->stats.eri_survivors; st->df_flops = ctx->stats.df_flops; st->df_bytes = ctx->stats.df_bytes;
     ctx->stats = Stats();
     return MQC_HIP_OK;
 }
 
 static void init_result(mqc_hip_scf_result_t* r)
 {
-    double* oe = r->orbital_energies; double* dn = r->density;
+    double* oe = r->orbital_energies; double* dn = r->density; double* gr = r->gradient; double* ob = r->orbital_energies_beta;
     std::memset(r, 0, sizeof(*r));
-    r->orbital_energies = oe; r->density = dn;
+    r->orbital_energies = oe; r->density = dn; r->gradient = gr; r->orbital_energies_beta = ob;
     r->scf_status = MQC_HIP_SCF_NOT_RUN;
 }
 
@@ -843,7 +884,7 @@ static int stage_setup(mqc_hip_context* ctx, const mqc_hip_molecule_t* mol, cons
     rc = upload_topology(ctx, sb.topo, sb.td);
     if (rc != MQC_HIP_OK) return rc;
     Slot sl0{0, ctx->stream, &ctx->pool_main, &ctx->pool_eri, &ctx->pool_misc, &ctx->pool_gridw, &ctx->pool_df,
-             ctx->ev0, ctx->ev1, ctx->ev2, ctx->ev3, ctx->evq0, ctx->evq1, nullptr};
+             ctx->ev0, ctx->ev1, ctx->ev2, ctx->ev3, ctx->evq0, ctx->evq1, nullptr, ctx->evs[0][0], ctx->evs[0][1]};
     rc = carve_batch(ctx, sl0, sb.topo, sb.td, 1, with_eri, sb.bv);
     if (rc != MQC_HIP_OK) return rc;
     sb.bv.nocc = std::max(1, sb.topo.nelec / 2); sb.bv.exx = 1.0; sb.bv.Vxc = nullptr; sb.bv.xc = XcSpec(); sb.bv.xc.ncomp = 0;

@@ -67,6 +67,10 @@ struct DevBuf {
 // grow-only device pool, the engine's device_pool_t (mqc_cuest_context.f90:40-53,142-156)
 class DevicePool {
 public:
+    DevicePool();
+    ~DevicePool();
+    DevicePool(const DevicePool&) = delete;
+    DevicePool& operator=(const DevicePool&) = delete;
     void* ensure(size_t bytes);
     void release();
     size_t capacity() const { return cap_; }
@@ -130,6 +134,8 @@ struct BatchView {      // plain pointers handed to kernels
     double* scal;                 // [nfrag][8]: e_elec, e_old, de, drms, e_final, E_xc, N_electrons, -
     int* istate;                  // [nfrag][4]: state, iterations, nmo, converged
     int* counters;                // [4]: n_not_done, ...
+    unsigned long long* eri_count;   // [1]: shell quartets the integral kernels formed (Schwarz survivors), or nullptr
+    double* dip;                  // [nfrag][4]: tr(D x), tr(D y), tr(D z) about the origin, -
     int slot;                     // 0/1: which pipeline slot (stream, pools, launcher scratch) this batch view lives in
     XcSpec xc;                    // ncomp == 0: no XC term
     GridDev grid;
@@ -148,6 +154,8 @@ struct Stats {
     double fock_kernel_seconds = 0, fock_bytes = 0, eri_kernel_seconds = 0, xc_kernel_seconds = 0, xc_points = 0;
     int64_t fock_big_launches = 0;
     double fock_big_seconds = 0, fock_big_bytes = 0;
+    double xc_flops = 0, scf_step_seconds = 0, df_flops = 0, df_bytes = 0;
+    int64_t eri_survivors = 0;
 };
 
 }  // namespace mqc
@@ -168,6 +176,7 @@ struct mqc_hip_context {
     hipEvent_t evo[2][2] = {};          // per lane: one-electron stage done / orthogonaliser + guess done
     hipEvent_t evb0 = nullptr, evb1 = nullptr, evb2 = nullptr, evb3 = nullptr;
     hipEvent_t evq0 = nullptr, evq1 = nullptr, evq2 = nullptr, evq3 = nullptr;   // integral-stage timing per slot
+    hipEvent_t evs[2][2] = {};          // per slot: SCF-step kernel timing
     int pipeline_chunks = 4;            // chunks a large batch is cut into
     int pipeline_min_fragments = 256;   // batches below this run as one chunk
     double* d_unit = nullptr;
@@ -181,6 +190,11 @@ struct mqc_hip_context {
 };
 
 namespace mqc {
+
+// every pool (context members and the launchers' function-static ones) is registered; mqc_hip_finalize frees them all
+void release_all_pools();
+// launcher state that holds streams/events of the context's device (kern_eri.hip); reset by mqc_hip_finalize
+void eri_reset_state();
 
 // host-side pieces (basis_norm.cpp, boys_table.cpp, batch.cpp)
 void set_error(const std::string& msg);
@@ -199,6 +213,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
 
 // kernel launchers (kern_*.hip)
 void launch_int1e(const BatchView& bv, const Topology& topo, hipStream_t s);
+void launch_dipole(const BatchView& bv, const Topology& topo, hipStream_t s);
 // host_xyz (optional, [nfrag][natoms][3] as uploaded): enables block sharing between fragments with identical atoms
 void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, hipStream_t s, const double* host_xyz = nullptr);
 // optional head start of the screened build (bounds + zero fill on side streams); launch_eri joins it

@@ -34,6 +34,20 @@ __device__ __forceinline__ ShellRef make_shell(const TopologyDev& tp, const doub
     return r;
 }
 
+// shell quartets a wave goes on to form (Schwarz survivors): one atomic per wave on the batch's counter
+// (the algorithmic unit of the integral stage, counted as direct_stats_t does, mqc_libcint_direct.f90:606-610)
+__device__ __forceinline__ void count_formed(unsigned long long* ctr, unsigned long long ballot)
+{
+    if (ctr && (threadIdx.x & 63) == 0) atomicAdd(ctr, (unsigned long long)__popcll(ballot));
+}
+__device__ __forceinline__ void count_formed_sum(unsigned long long* ctr, int mine)
+{
+    int v = mine;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (ctr && (threadIdx.x & 63) == 0) atomicAdd(ctr, (unsigned long long)v);
+}
+
 __device__ __forceinline__ size_t pair_index(int i, int j)
 {
     return i >= j ? (size_t)i * (i + 1) / 2 + j : (size_t)j * (j + 1) / 2 + i;
@@ -148,7 +162,9 @@ __global__ void __launch_bounds__(64) eri_kernel(BatchView bv, const int* __rest
         keep = live && (q[A * ns + B] * q[C * ns + D] >= thresh);
     }
     // wavefront-level early exit: one ballot decides for all 64 lanes
-    if (__ballot(keep) == 0ull) return;
+    const unsigned long long alive = __ballot(keep);
+    if (alive == 0ull) return;
+    count_formed(bv.eri_count, alive);
     if (!keep) return;   // the tensor was zero-filled, a skipped quartet stays zero
 
     const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
@@ -233,6 +249,7 @@ __global__ void __launch_bounds__(64) eri_twin_kernel(BatchView bv, const int* _
         keep = live && (qab * qcd >= thresh);
     }
     if (__ballot(keep) == 0ull) return;
+    count_formed_sum(bv.eri_count, keep ? (tA ? 2 : 1) * (tB ? 2 : 1) * (tC ? 2 : 1) * (tD ? 2 : 1) : 0);
     if (!keep) return;
     const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
     const ShellRef sa = make_shell(tp, xyz, A), sb = make_shell(tp, xyz, B), sc = make_shell(tp, xyz, C), sd = make_shell(tp, xyz, D);
@@ -326,7 +343,9 @@ __global__ void __launch_bounds__(64) eri_pass_kernel(BatchView bv, const int* _
         const double* q = Q + (size_t)f * ns * ns;
         keep = live && (q[A * ns + B] * q[C * ns + D] >= thresh);
     }
-    if (__ballot(keep) == 0ull) return;
+    const unsigned long long alive = __ballot(keep);
+    if (alive == 0ull) return;
+    count_formed(bv.eri_count, alive);
     if (!keep) return;
     const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
     const PairFly bra(make_shell(tp, xyz, A), make_shell(tp, xyz, B)), ket(make_shell(tp, xyz, C), make_shell(tp, xyz, D));
@@ -402,7 +421,9 @@ __global__ void __launch_bounds__(64) eri_digest_kernel(BatchView bv, const int*
         const double dk = 0.125 * bv.exx * fmax(fmax(dm[A * ns + C], dm[A * ns + D]), fmax(dm[B * ns + C], dm[B * ns + D]));
         keep = q[A * ns + B] * q[C * ns + D] * deg * fmax(dj, dk) >= thresh;
     }
-    if (__ballot(keep) == 0ull) return;
+    const unsigned long long alive = __ballot(keep);
+    if (alive == 0ull) return;
+    count_formed(bv.eri_count, alive);
     if (!keep) return;
 
     const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;

@@ -18,6 +18,36 @@ int fail(int code, const std::string& msg) { g_last_error = msg; return code; }
 const std::string& last_error_string() { return g_last_error; }
 
 // ---- device pool ---------------------------------------------------------------------
+namespace {
+struct PoolRegistry {
+    std::mutex m;
+    std::vector<DevicePool*> pools;
+};
+PoolRegistry& pool_registry() { static PoolRegistry* r = new PoolRegistry(); return *r; }   // never destroyed: pools may outlive statics
+}  // namespace
+
+DevicePool::DevicePool()
+{
+    auto& r = pool_registry();
+    std::lock_guard<std::mutex> lock(r.m);
+    r.pools.push_back(this);
+}
+
+DevicePool::~DevicePool()
+{
+    auto& r = pool_registry();
+    std::lock_guard<std::mutex> lock(r.m);
+    r.pools.erase(std::remove(r.pools.begin(), r.pools.end(), this), r.pools.end());
+    // device memory is released by mqc_hip_finalize (release_all_pools); at process exit the runtime reclaims it
+}
+
+void release_all_pools()
+{
+    auto& r = pool_registry();
+    std::lock_guard<std::mutex> lock(r.m);
+    for (DevicePool* p : r.pools) p->release();
+}
+
 void* DevicePool::ensure(size_t bytes)
 {
     if (bytes <= cap_ && ptr_) return ptr_;

@@ -177,6 +177,10 @@ struct EriLaunch { int cls; bool twin; size_t dense_off; int dense_n; size_t sh_
 struct EriListCache {
     uint64_t key = 0;
     bool valid = false;
+    // the full key, compared on a hash hit (a 64-bit collision must not hand another batch's share plan out)
+    std::string topo_key;
+    std::vector<double> xyz;
+    int nfrag = 0, flags = 0;
     DevicePool pool;
     std::vector<int> host;
     std::vector<EriLaunch> launches;
@@ -218,10 +222,30 @@ void eri_set_side_streams(int slot, const hipStream_t* streams, int count)
     for (int k = 0; k < ERI_SIDE_STREAMS && k < count; ++k) g_preset_side[slot & 1][k] = streams[k];
 }
 
+static EriSlotState g_eri_state_slot[2];
+
+// mqc_hip_finalize: the events and side streams belong to the device of the context that is going away
+void eri_reset_state()
+{
+    for (int sl = 0; sl < 2; ++sl) {
+        EriSlotState& st = g_eri_state_slot[sl];
+        if (st.fork) (void)hipEventDestroy(st.fork);
+        st.fork = nullptr;
+        for (int k = 0; k < ERI_SIDE_STREAMS; ++k) {
+            if (st.join[k]) (void)hipEventDestroy(st.join[k]);
+            st.join[k] = nullptr;
+            if (st.side[k] && st.side[k] != g_preset_side[sl][k]) (void)hipStreamDestroy(st.side[k]);   // preset ones: the context's
+            st.side[k] = nullptr;
+            g_preset_side[sl][k] = nullptr;
+        }
+        for (auto& c : st.cache) { c.valid = false; c.key = 0; c.host.clear(); c.launches.clear(); }
+        st.bounds_pending = false; st.Q = nullptr; st.next = 0;
+    }
+}
+
 static EriSlotState& eri_slot_state(int slot)
 {
-    static EriSlotState state_slot[2];
-    EriSlotState& st = state_slot[slot & 1];
+    EriSlotState& st = g_eri_state_slot[slot & 1];
     if (!st.fork) {
         (void)hipEventCreateWithFlags(&st.fork, hipEventDisableTiming);
         for (int k = 0; k < ERI_SIDE_STREAMS; ++k) {
@@ -296,7 +320,11 @@ void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, h
     key = hash_words(&key, 8, (uint64_t)bv.nfrag * 0x100000001B3ull + (twins ? 1 : 0) + (may_share ? 2 : 0) + topo.key.size() * 8 + topo.nao * 131071ull);
     if (may_share) key = hash_words(host_xyz, sizeof(double) * (size_t)bv.nfrag * topo.natoms * 3, key);
     EriListCache* cc = nullptr;
-    for (auto& c : st.cache) if (c.valid && c.key == key) cc = &c;
+    const int key_flags = (twins ? 1 : 0) + (may_share ? 2 : 0);
+    const size_t xyz_count = may_share ? (size_t)bv.nfrag * topo.natoms * 3 : 0;
+    for (auto& c : st.cache)
+        if (c.valid && c.key == key && c.nfrag == bv.nfrag && c.flags == key_flags && c.topo_key == topo.key && c.xyz.size() == xyz_count &&
+            (xyz_count == 0 || std::memcmp(c.xyz.data(), host_xyz, sizeof(double) * xyz_count) == 0)) cc = &c;
     if (!cc) {
         cc = &st.cache[st.next];
         st.next = (st.next + 1) % ERI_CACHE_WAYS;
@@ -359,6 +387,8 @@ void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, h
         int* dnew = (int*)cc->pool.ensure((hb.size() + 16) * sizeof(int));
         (void)hipMemcpyAsync(dnew, hb.data(), hb.size() * sizeof(int), hipMemcpyHostToDevice, s);
         cc->key = key;
+        cc->topo_key = topo.key; cc->nfrag = bv.nfrag; cc->flags = key_flags;
+        if (xyz_count) cc->xyz.assign(host_xyz, host_xyz + xyz_count); else cc->xyz.clear();
         cc->valid = true;
     }
     const int* d = (const int*)cc->pool.ensure(0);

@@ -152,6 +152,127 @@ static void launch_class(const BatchView& bv, const std::vector<int>& list, Devi
     (void)hipStreamSynchronize(s);   // the scratch list is reused by the next class
 }
 
+// ---------------------------------------------------------------------------------------
+// Electronic dipole  tr(D x), tr(D y), tr(D z)  about the coordinate origin, accumulated into bv.dip[f][0..2]
+// (system_compute_dipole, mqc_cuest_integrals.f90:1443-1521: mu = sum_A Z_A (R_A - O) - sum_uv D_uv <u|r - O|v>;
+// the shift to the centre of nuclear charge O is applied on the host with tr(D S) = N_electrons).
+// First moments from the same Hermite tables: <a|x|b> = (E_1^{ij} + P_x E_0^{ij}) sqrt(pi/p).
+template <int LA, int LB>
+__global__ void __launch_bounds__(64) dipole_kernel(BatchView bv, const int* __restrict__ pairs, int npairs)
+{
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)npairs * bv.nfrag;
+    if (tid >= total) return;
+    const int ip = (int)(tid / bv.nfrag), f = (int)(tid % bv.nfrag);
+    const int A = pairs[2 * ip], B = pairs[2 * ip + 1];
+    constexpr int NCA = ncart(LA), NCB = ncart(LB);
+    const TopologyDev& tp = bv.topo;
+    const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
+    const int atA = tp.sh_atom[A], atB = tp.sh_atom[B];
+    const double ax = xyz[3 * atA], ay = xyz[3 * atA + 1], az = xyz[3 * atA + 2];
+    const double bx = xyz[3 * atB], by = xyz[3 * atB + 1], bz = xyz[3 * atB + 2];
+    const double ab2 = (ax - bx) * (ax - bx) + (ay - by) * (ay - by) + (az - bz) * (az - bz);
+    double mx[NCA * NCB], my[NCA * NCB], mz[NCA * NCB];
+#pragma unroll
+    for (int i = 0; i < NCA * NCB; ++i) { mx[i] = 0.0; my[i] = 0.0; mz[i] = 0.0; }
+    const int npa = tp.sh_nprim[A], npb = tp.sh_nprim[B];
+    const double* ea = tp.exps + tp.sh_poff[A]; const double* ca = tp.coefs + tp.sh_poff[A];
+    const double* eb = tp.exps + tp.sh_poff[B]; const double* cb = tp.coefs + tp.sh_poff[B];
+    for (int ipa = 0; ipa < npa; ++ipa)
+        for (int jp = 0; jp < npb; ++jp) {
+            const double a = ea[ipa], b = eb[jp], p = a + b, ip_ = 1.0 / p;
+            const double kab = exp(-a * b * ip_ * ab2) * ca[ipa] * cb[jp];
+            const double px = (a * ax + b * bx) * ip_, py = (a * ay + b * by) * ip_, pz = (a * az + b * bz) * ip_;
+            E1D<LA, LB> ex, ey, ez;
+            ex.build(px - ax, px - bx, 0.5 * ip_);
+            ey.build(py - ay, py - by, 0.5 * ip_);
+            ez.build(pz - az, pz - bz, 0.5 * ip_);
+            const double s3 = kab * M_PI * ip_ * sqrt(M_PI * ip_);
+            int iab = 0;
+#pragma unroll
+            for (int i0 = LA; i0 >= 0; --i0)
+#pragma unroll
+                for (int i1 = LA - i0; i1 >= 0; --i1) {
+                    const int i2 = LA - i0 - i1;
+#pragma unroll
+                    for (int j0 = LB; j0 >= 0; --j0)
+#pragma unroll
+                        for (int j1 = LB - j0; j1 >= 0; --j1) {
+                            const int j2 = LB - j0 - j1;
+                            const double sx = ex.get(i0, j0, 0), sy = ey.get(i1, j1, 0), sz = ez.get(i2, j2, 0);
+                            const double dx = ((i0 + j0 >= 1) ? ex.get(i0, j0, 1) : 0.0) + px * sx;
+                            const double dy = ((i1 + j1 >= 1) ? ey.get(i1, j1, 1) : 0.0) + py * sy;
+                            const double dz = ((i2 + j2 >= 1) ? ez.get(i2, j2, 1) : 0.0) + pz * sz;
+                            mx[iab] += s3 * dx * sy * sz;
+                            my[iab] += s3 * sx * dy * sz;
+                            mz[iab] += s3 * sx * sy * dz;
+                            ++iab;
+                        }
+                }
+        }
+    constexpr int NSA = nsph(LA), NSB = nsph(LB);
+    const int n = bv.n;
+    const double* D = bv.D + (size_t)f * n * n;
+    const int oa = tp.sh_aoff[A], ob = tp.sh_aoff[B];
+    double tx = 0.0, ty = 0.0, tz = 0.0;
+#pragma unroll
+    for (int i = 0; i < NSA; ++i)
+#pragma unroll
+        for (int j = 0; j < NSB; ++j) {
+            double vx = 0.0, vy = 0.0, vz = 0.0;
+#pragma unroll
+            for (int ia = 0; ia < NCA; ++ia) {
+                double wa = 1.0;
+                if constexpr (LA >= 2) wa = c2s_coef<LA>(bv.c2s, i, ia); else wa = (i == ia) ? 1.0 : 0.0;
+                if (wa == 0.0) continue;
+#pragma unroll
+                for (int ib = 0; ib < NCB; ++ib) {
+                    double wb = 1.0;
+                    if constexpr (LB >= 2) wb = c2s_coef<LB>(bv.c2s, j, ib); else wb = (j == ib) ? 1.0 : 0.0;
+                    const double w = wa * wb;
+                    vx += w * mx[ia * NCB + ib]; vy += w * my[ia * NCB + ib]; vz += w * mz[ia * NCB + ib];
+                }
+            }
+            const double d = D[(size_t)(oa + i) * n + ob + j];
+            tx += d * vx; ty += d * vy; tz += d * vz;
+        }
+    const double w = (A == B) ? 1.0 : 2.0;      // the pair list holds A >= B once
+    double* dip = bv.dip + (size_t)f * 4;
+    atomicAdd(&dip[0], w * tx); atomicAdd(&dip[1], w * ty); atomicAdd(&dip[2], w * tz);
+}
+
+template <int LA, int LB>
+static void launch_dipole_class(const BatchView& bv, const std::vector<int>& list, int* d, hipStream_t s)
+{
+    if (list.empty()) return;
+    const int npairs = (int)list.size() / 2;
+    (void)hipMemcpyAsync(d, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice, s);
+    const long total = (long)npairs * bv.nfrag;
+    hipLaunchKernelGGL((dipole_kernel<LA, LB>), dim3((int)((total + 63) / 64)), dim3(64), 0, s, bv, d, npairs);
+}
+
+void launch_dipole(const BatchView& bv, const Topology& topo, hipStream_t s)
+{
+    static DevicePool scratch_slot[2];
+    static std::vector<int> bucket_slot[2][LMAX_AO + 1][LMAX_AO + 1];      // kept alive for the async uploads
+    auto& bucket = bucket_slot[bv.slot & 1];
+    for (auto& row : bucket) for (auto& b : row) b.clear();
+    for (size_t k = 0; k + 1 < topo.pairs.size(); k += 2) {
+        int A = topo.pairs[k], B = topo.pairs[k + 1];
+        int la = topo.shells[A].l, lb = topo.shells[B].l;
+        if (la < lb) { std::swap(A, B); std::swap(la, lb); }
+        bucket[la][lb].push_back(A);
+        bucket[la][lb].push_back(B);
+    }
+    int* d = (int*)scratch_slot[bv.slot & 1].ensure((topo.pairs.size() + 16) * sizeof(int));
+    (void)hipMemsetAsync(bv.dip, 0, sizeof(double) * 4 * (size_t)bv.nfrag, s);
+    size_t off = 0;
+#define DIP_CASE(a, b) launch_dipole_class<a, b>(bv, bucket[a][b], d + off, s); off += bucket[a][b].size();
+    DIP_CASE(0, 0) DIP_CASE(1, 0) DIP_CASE(1, 1) DIP_CASE(2, 0) DIP_CASE(2, 1) DIP_CASE(2, 2)
+    DIP_CASE(3, 0) DIP_CASE(3, 1) DIP_CASE(3, 2) DIP_CASE(3, 3)
+#undef DIP_CASE
+}
+
 void launch_int1e(const BatchView& bv, const Topology& topo, hipStream_t s)
 {
     static DevicePool scratch_slot[2];

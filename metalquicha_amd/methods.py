@@ -119,6 +119,11 @@ class CalculationResult:
     e_nuclear: float = 0.0
     e_electronic: float = 0.0
     orbital_energies: Optional[np.ndarray] = None
+    dipole: Optional[np.ndarray] = None     # (3,) electron-Bohr, origin = centre of nuclear charge
+    has_dipole: bool = False
+    gradient: Optional[np.ndarray] = None   # (3, n_atoms) Hartree/Bohr, like result%gradient
+    has_gradient: bool = False
+    s_squared: float = 0.0
 
 
 _GUESS = {"auto": capi.GUESS_AUTO, "gwh": capi.GUESS_GWH, "core": capi.GUESS_CORE}
@@ -216,6 +221,10 @@ def _fill(result: CalculationResult, r: capi.ScfResult, eps: Optional[np.ndarray
     result.has_orbitals = bool(r.has_orbitals)
     if eps is not None:
         result.orbital_energies = eps[: int(r.n_mo)].copy()
+    if r.has_dipole:
+        result.dipole = np.array([r.dipole[0], r.dipole[1], r.dipole[2]])
+        result.has_dipole = True
+    result.s_squared = float(r.s_squared)
     return result
 
 
@@ -273,6 +282,8 @@ def _struct_dtype(struct) -> np.dtype:
             fmt = "<i8"
         elif issubclass(ctype, C.Array) and ctype._type_ is C.c_char:
             fmt = "S%d" % size
+        elif issubclass(ctype, C.Array) and ctype._type_ is C.c_double:
+            fmt = ("<f8", (ctype._length_,))
         else:
             fmt = "<u8"          # pointers
         names.append(name); formats.append(fmt); offsets.append(getattr(struct, name).offset)
@@ -400,6 +411,10 @@ def _fill_record(result: CalculationResult, r) -> CalculationResult:
     result.homo = float(r["homo"])
     result.lumo = float(r["lumo"])
     result.has_orbitals = bool(r["has_orbitals"])
+    if r["has_dipole"]:
+        result.dipole = np.array(r["dipole"], dtype=float)
+        result.has_dipole = True
+    result.s_squared = float(r["s_squared"])
     return result
 
 

@@ -1,0 +1,149 @@
+"""GPU parity tests of the CALLER side of the hot path: fragment lists through
+mbe.run_mbe -> one engine batch call -> compute_mbe, against the reference's MBE(2) golden and against
+per-fragment oracle energies; plus BASELINE.json configs[1] (benzene) and a ghost-atom fragment.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from metalquicha_amd import mbe, methods
+from metalquicha_amd.basis import ANGSTROM_TO_BOHR, SYMBOL_TO_Z
+from oracle import scf_oracle as so
+from oracle import xc_oracle
+from tests.helpers import fragment_bohr, oracle_mol, water_at
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_CASES = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "manifest_subset.json")))["cases"]
+AUX = "mqc-even-tempered-jkfit"
+
+
+def test_mbe2_water_dimer_reference_golden():
+    """validation_tests_cpu.json 'MBE(2) RHF gradient (H2O)2 cc-pvdz (CPU)': MBE(2) total -152.056781852646
+    (tolerance 1e-9 in the reference suite), through run_mbe + compute_mbe + compute_mbe_coefficients."""
+    case = [c for c in _CASES if c.get("mbe_level") == 2][0]
+    system = mbe.system_from_xyz(case["symbols"], np.array(case["xyz_angstrom"]), case["fragments"])
+    st = methods.ScfSettings(basis_set=case["basis"], energy_tol=1e-10, density_tol=1e-7, guess="gwh", max_iter=case["maxiter"])
+    run = mbe.run_mbe(system, st, level=case["mbe_level"])
+    assert not run.errors, run.errors
+    assert sorted(len(t) for t in run.terms) == [1, 1, 2]
+    total, by_order, _ = mbe.compute_mbe(run.terms, run.energies)
+    assert abs(total - case["expected_energy"]) < 1e-9
+    coef = mbe.compute_mbe_coefficients(run.terms)
+    assert abs(float(np.dot(coef, run.energies)) - case["expected_energy"]) < 1e-9
+    # the two-body correction is the interaction energy of the dimer: small and negative here
+    assert -0.02 < by_order[2] < 0.0
+
+
+_CLUSTER_CHILD = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from metalquicha_amd import mbe, methods
+system = mbe.water_cluster(2)
+terms = mbe.generate_mbe_term_list(system, 2)
+st = methods.ScfSettings(basis_set="cc-pvdz", guess="gwh", energy_tol=1e-8, density_tol=1e-6, schwarz_tol=float(sys.argv[2]))
+out = {}
+for world in (1, 2):
+    e = np.zeros(len(terms)); it = np.zeros(len(terms))
+    for rank in range(world):
+        run = mbe.run_mbe(system, st, level=2, rank=rank, world=world, terms=terms)
+        assert not run.errors, run.errors
+        e += run.energies; it += run.iterations
+    out["w%d" % world] = {"e": e.tolist(), "it": it.tolist()}
+print(json.dumps(out))
+"""
+
+
+def _cluster_child(env_extra, schwarz):
+    env = dict(os.environ, **env_extra)
+    out = subprocess.run([sys.executable, "-c", _CLUSTER_CHILD, ROOT, repr(schwarz)], env=env, check=True, capture_output=True,
+                         text=True, timeout=900).stdout.strip().splitlines()[-1]
+    return json.loads(out)
+
+
+def test_mbe2_bench_shaped_cluster_matches_per_fragment_oracle():
+    """(H2O)8 (the bench generator at side 2), MBE-2 RHF/cc-pVDZ with the bench settings: 8 monomers + 28 dimers in ONE
+    batch call (two topology groups on two lanes, compactness re-ordering of the results, shared intra-monomer
+    blocks, Schwarz 1e-12).  Every fragment energy within 1e-8 Eh of the oracle's, same iteration counts; the
+    assembled MBE-2 total within 1e-8; block sharing off / round-robin over two ranks give the same numbers."""
+    system = mbe.water_cluster(2)
+    terms = mbe.generate_mbe_term_list(system, 2)
+    assert len(terms) == 36
+    got = _cluster_child({}, 1e-12)
+    e = np.array(got["w1"]["e"]); it = np.array(got["w1"]["it"])
+    eo = np.zeros(len(terms)); ito = np.zeros(len(terms))
+    for k, t in enumerate(terms):
+        frag = mbe.build_fragment(system, t)
+        o = so.run_rhf(oracle_mol("cc-pvdz", frag), int(frag.nelec), 100, 1e-8, 1e-6)
+        eo[k] = o.energy; ito[k] = o.iterations
+    assert np.max(np.abs(e - eo)) < 1e-8, np.max(np.abs(e - eo))
+    assert np.array_equal(it, ito)
+    tot, _, _ = mbe.compute_mbe(terms, e)
+    tot_o, _, _ = mbe.compute_mbe(terms, eo)
+    assert abs(tot - tot_o) < 1e-8
+    # round-robin partition over two ranks, energies summed as the all-reduce would: identical fragments, identical numbers
+    assert np.max(np.abs(np.array(got["w2"]["e"]) - e)) < 1e-10
+    assert np.array_equal(np.array(got["w2"]["it"]), it)
+    plain = _cluster_child({"MQC_HIP_NO_BLOCK_SHARING": "1", "MQC_HIP_NO_TWIN_BLOCKS": "1", "MQC_HIP_CONCURRENT_GROUPS": "0"}, 0.0)
+    assert np.max(np.abs(np.array(plain["w1"]["e"]) - e)) < 1e-9
+    assert np.array_equal(np.array(plain["w1"]["it"]), it)
+
+
+def _benzene():
+    rcc, rch = 1.397, 1.084          # D6h, in the xy-plane
+    sym, xyz = [], []
+    for k in range(6):
+        a = np.pi / 3 * k
+        sym.append("C"); xyz.append([rcc * np.cos(a), rcc * np.sin(a), 0.0])
+    for k in range(6):
+        a = np.pi / 3 * k
+        sym.append("H"); xyz.append([(rcc + rch) * np.cos(a), (rcc + rch) * np.sin(a), 0.0])
+    return methods.PhysicalFragment.from_angstrom(sym, xyz)
+
+
+def test_benzene_b3lyp_ccpvdz_df_matches_oracle():
+    """BASELINE.json configs[1]: single benzene B3LYP/cc-pVDZ, density-fitted J/K, grid level 3, GWH guess,
+    e_tol 1e-10 / d_tol 1e-8 (n_ao = 114, 21 occupied): energy within 1e-8 Eh of the oracle, same iteration count."""
+    frag = _benzene()
+    st = methods.ScfSettings(basis_set="cc-pvdz", functional="b3lyp", density_fitting=True, aux_basis_set=AUX,
+                             energy_tol=1e-10, density_tol=1e-8, guess="gwh")
+    r = methods.run_hip_scf(st, frag)
+    assert not r.has_error, r.error_message
+    assert r.scf_status == methods.SCF_CONVERGED
+    mol = oracle_mol("cc-pvdz", frag); aux = oracle_mol(AUX, frag)
+    assert mol.nao == 114
+    o = so.run_rhf(mol, 42, 100, 1e-10, 1e-8, aux=aux, xc=xc_oracle.XCOracle(mol, "b3lyp", 3))
+    assert abs(r.energy.scf - o.energy) < 1e-8, (r.energy.scf, o.energy)
+    assert r.scf_iterations == o.iterations
+    assert -232.4 < r.energy.scf < -232.1          # B3LYP/cc-pVDZ benzene, literature -232.26
+
+
+@pytest.mark.parametrize("functional", ["", "b3lyp"], ids=["rhf", "b3lyp"])
+def test_ghost_atom_fragment_matches_oracle(functional):
+    """A counterpoise-style fragment: water A with the basis functions (and grid points) of a ghosted water B --
+    ghost atoms carry basis functions, no nuclear charge and no electrons (mqc_libcint_integrals.F90:481-488,
+    mqc_physical_fragment.f90:73-83)."""
+    rng = np.random.default_rng(42)
+    xyz = np.vstack([water_at(rng, [0, 0, 0]), water_at(rng, [5.4, 0.3, -0.2])])
+    ghost = np.array([0, 0, 0, 1, 1, 1], dtype=bool)
+    frag = fragment_bohr([8, 1, 1, 8, 1, 1], xyz, ghost=ghost)
+    assert frag.nelec == 10
+    st = methods.ScfSettings(basis_set="cc-pvdz", functional=functional, energy_tol=1e-10, density_tol=1e-8, guess="gwh")
+    r = methods.run_hip_scf(st, frag)
+    assert not r.has_error, r.error_message
+    mol = oracle_mol("cc-pvdz", frag)
+    assert mol.nao == 48 and float(np.sum(mol.z)) == 10.0
+    xc = xc_oracle.XCOracle(mol, functional, 3) if functional else None
+    o = so.run_rhf(mol, 10, 100, 1e-10, 1e-8, xc=xc)
+    assert abs(r.energy.scf - o.energy) < 1e-8, (r.energy.scf, o.energy)
+    assert r.scf_iterations == o.iterations
+    # the ghost basis lowers the monomer energy (basis-set superposition), by less than a few mEh
+    real = fragment_bohr([8, 1, 1], xyz[:3])
+    r0 = methods.run_hip_scf(st, real)
+    assert 0.0 < r0.energy.scf - r.energy.scf < 5e-3
