@@ -55,7 +55,7 @@ enum { MQC_HIP_SCF_NOT_RUN = 0, MQC_HIP_SCF_CONVERGED = 1, MQC_HIP_SCF_NOT_CONVE
 
 /* initial guess (cuest_scf_settings_t%guess, src/methods/mqc_cuest_iface.f90:104-121).
  * AUTO resolves to GWH, as the cuEST backend does. */
-enum { MQC_HIP_GUESS_AUTO = 0, MQC_HIP_GUESS_CORE = 1, MQC_HIP_GUESS_GWH = 2 };
+enum { MQC_HIP_GUESS_AUTO = 0, MQC_HIP_GUESS_CORE = 1, MQC_HIP_GUESS_GWH = 2, MQC_HIP_GUESS_SAD = 3 };
 
 /* two-electron path.  AUTO = in-core packed ERIs in HBM when they fit the per-fragment
  * budget, else the direct build (the reference's choice at mqc_libcint_bridge.f90:819-892,

@@ -38,7 +38,13 @@
 
 #define LMAX 4              /* g functions; matches the reference's c2s table (l <= 4) */
 #define NCART(l) (((l) + 1) * ((l) + 2) / 2)
-#define NSPH(l) (2 * (l) + 1)
+/* Cartesian mode (orc_set_cartesian): shells above p keep their NCART Cartesian components, libcint's
+ * x^(l-i) y^(i-j) z^j order with the radial normalisation only -- what the reference's CPU path runs for a
+ * basis whose d shells are marked gto_cartesian (6-31G*, mqc_libcint_integrals.F90:132-148).  Converged SCF
+ * energies do not depend on how the individual components are normalised. */
+static int g_cartesian = 0;
+void orc_set_cartesian(int flag) { g_cartesian = flag; }
+#define NSPH(l) ((g_cartesian && (l) >= 2) ? NCART(l) : 2 * (l) + 1)
 #define MAXCART NCART(LMAX)
 #define LSUM_MAX (4 * LMAX)
 #define NHERM_MAX(L) (((L) + 1) * ((L) + 2) * ((L) + 3) / 6)
@@ -168,7 +174,7 @@ static double binom(int n, int k)
 static double fact(int n) { double r = 1.0; for (int i = 2; i <= n; ++i) r *= i; return r; }
 
 /* c2s[l] is NSPH x NCART, libcint order: m = -l..l, except l=1 which is x,y,z. */
-static double C2S[LMAX + 1][NSPH(LMAX)][MAXCART];
+static double C2S[LMAX + 1][2 * LMAX + 1][MAXCART];
 static int c2s_ready = 0;
 
 static void build_c2s(void)
@@ -227,6 +233,7 @@ static void c2s_index(int l, int pre, int post, const double *in, double *out)
 {
     if (l < 0) { memcpy(out, in, sizeof(double) * pre * post); return; }
     int nc = NCART(l), ns = NSPH(l);
+    if (g_cartesian && l >= 2) { memcpy(out, in, sizeof(double) * pre * nc * post); return; }
     for (int a = 0; a < pre; ++a)
         for (int s = 0; s < ns; ++s)
             for (int b = 0; b < post; ++b) {
@@ -612,7 +619,7 @@ void orc_eval_ao(int nshell, const int *sh_l, const int *sh_nprim, const int *sh
             for (int s = 0; s < ns; ++s) {
                 double v = 0.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;
                 for (int k = 0; k < nc; ++k) {
-                    double cs = C2S[l][s][k];
+                    double cs = (g_cartesian && l >= 2) ? (s == k ? 1.0 : 0.0) : C2S[l][s][k];
                     v += cs * vc[k]; g0 += cs * gc[0][k]; g1 += cs * gc[1][k]; g2 += cs * gc[2][k];
                 }
                 ao[g * nao + sh_aoff[A] + s] = v;

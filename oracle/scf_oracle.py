@@ -107,12 +107,14 @@ class OracleMol:
     exps: np.ndarray
     coefs: np.ndarray        # normalised
     nao: int
+    cart: bool = False       # Cartesian components above p (a basis with gto_cartesian d shells, e.g. 6-31G*)
 
     @property
     def nshell(self):
         return len(self.sh_l)
 
     def _basis_args(self, with_aoff=True, with_nao=True):
+        lib().orc_set_cartesian(ctypes.c_int(1 if self.cart else 0))      # every integral call goes through here
         args = [ctypes.c_int(self.nshell), _ip(self.sh_l), _ip(self.sh_nprim), _ip(self.sh_poff)]
         if with_aoff:
             args.append(_ip(self.sh_aoff))
@@ -122,8 +124,13 @@ class OracleMol:
         return args
 
 
+def nfun(l, cart=False):
+    l = np.asarray(l)
+    return np.where(cart & (l >= 2), (l + 1) * (l + 2) // 2, 2 * l + 1)
+
+
 def make_mol(atomic_numbers, xyz_bohr, nshell_per_atom, shell_l, shell_nprim, exps, coefs_raw,
-             ghost=None) -> OracleMol:
+             ghost=None, cart=False) -> OracleMol:
     z = np.array(atomic_numbers, dtype=np.float64)
     if ghost is not None:
         z = np.where(np.asarray(ghost, dtype=bool), 0.0, z)
@@ -133,12 +140,12 @@ def make_mol(atomic_numbers, xyz_bohr, nshell_per_atom, shell_l, shell_nprim, ex
     poff = np.zeros(len(sh_l), dtype=np.int32)
     poff[1:] = np.cumsum(sh_np)[:-1]
     aoff = np.zeros(len(sh_l), dtype=np.int32)
-    aoff[1:] = np.cumsum(2 * sh_l + 1)[:-1]
+    aoff[1:] = np.cumsum(nfun(sh_l, cart))[:-1]
     atoms = np.repeat(np.arange(len(nshell_per_atom)), np.asarray(nshell_per_atom, dtype=np.int64))
     sh_xyz = np.ascontiguousarray(xyz[atoms])
     ex = np.ascontiguousarray(exps, dtype=np.float64)
     co = np.ascontiguousarray(normalise_basis(sh_l, sh_np, ex, np.asarray(coefs_raw, dtype=np.float64)))
-    return OracleMol(z, xyz, sh_l, sh_np, poff, aoff, sh_xyz, ex, co, int(np.sum(2 * sh_l + 1)))
+    return OracleMol(z, xyz, sh_l, sh_np, poff, aoff, sh_xyz, ex, co, int(np.sum(nfun(sh_l, cart))), bool(cart))
 
 
 def nuclear_repulsion(mol: OracleMol) -> float:
