@@ -135,13 +135,16 @@ class FlatBasis:
         return np.repeat(np.arange(len(self.nshell_per_atom)), self.nshell_per_atom).astype(np.int32)
 
 
-def build_flat_basis(name: str, atomic_numbers: Sequence[int]) -> FlatBasis:
-    """`load_basis` + flattening for one fragment (ghost atoms keep their functions)."""
+def build_flat_basis(name: str, atomic_numbers: Sequence[int], allow_cartesian: bool = False) -> FlatBasis:
+    """`load_basis` + flattening for one fragment (ghost atoms keep their functions).  `allow_cartesian` is for
+    the test oracle only (the CPU reference routes Cartesian sets, the GPU boundary refuses them)."""
     path = find_basis_file(name)
     per_atom, ls, nps, ex, co = [], [], [], [], []
+    any_cart = False
     for z in atomic_numbers:
         eb = read_element(path, int(z))
-        if eb.cartesian:
+        any_cart = any_cart or eb.cartesian
+        if eb.cartesian and not allow_cartesian:
             # mqc_cuest_driver.f90:331-341 -- the GPU path refuses Cartesian sets
             raise BasisError("basis %s is Cartesian (gto_cartesian above p); the HIP backend "
                              "supports spherical sets only" % name)
@@ -149,7 +152,7 @@ def build_flat_basis(name: str, atomic_numbers: Sequence[int]) -> FlatBasis:
         for s in eb.shells:
             ls.append(s.l); nps.append(s.nprim); ex.append(s.exps); co.append(s.coefs)
     return FlatBasis(
-        spherical=True,
+        spherical=not any_cart,
         nshell_per_atom=np.array(per_atom, dtype=np.int64),
         shell_l=np.array(ls, dtype=np.int32),
         shell_nprim=np.array(nps, dtype=np.int32),

@@ -17,6 +17,9 @@
 // every pass streams contiguous rows), metric / Linv [naux][naux].
 #include "engine.hpp"
 #include "md_integrals.hpp"
+#include <cstdlib>
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 namespace mqc {
 
@@ -297,6 +300,194 @@ __global__ void __launch_bounds__(DF_NT) df_k_kernel(BatchView bv, int only_acti
 }
 
 // ------------------------------------------------------------------------------------------
+// J and K in ONE pass over the fitted tensor, contractions on the FP64 matrix cores (round 2).
+//
+// build_fock_df (mqc_libcint_rhf.f90:1576-1646): c_R = sum B_R D, J = sum_R B_R c_R, W_R = B_R C_occ,
+// K = 2 sum_R W_R W_R^T.  SURVEY 8d: J needs 8 n^2 A bytes "if J and K share a pass" -- they do here: a workgroup
+// walks auxiliary rows R of one fragment; row R (npair doubles, contiguous) is loaded ONCE from HBM into registers
+// (the next row is in flight while the current one is consumed), parked in LDS, and used for
+//   * c_R            (each wave reduces the row against the packed density in LDS),
+//   * J += B_R c_R   (lane-private accumulators over the packed pairs the thread loaded),
+//   * W_R = B_R C    as 16 x 16 MFMA jobs (A-fragments gathered from the packed row, B-fragments = C_occ in LDS),
+//   * K += W_R W_R^T as MFMA jobs on the lower-triangle tiles, accumulators resident in the waves' registers
+// across all rows of the workgroup; one atomic flush at the end.  J is finished by the second sweep c -> J inside
+// the same loop because c_R is complete once its row has been read: no second pass over B.
+constexpr int DJ_NW = 4;
+
+__device__ __forceinline__ int dj_pidx(int a, int b) { return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; }
+
+template <int JMAX, int NLD, bool WITH_K, bool DPG>
+__global__ void __launch_bounds__(64 * DJ_NW) df_jk_mfma_kernel(BatchView bv, int only_active)
+{
+    extern __shared__ double lds[];
+    const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (only_active && bv.istate[4 * f] == ST_DONE) return;
+    const int lo = lane & 15, hi = lane >> 4;
+    const int n = bv.n, na = bv.naux, o = bv.nocc;
+    const int np = bv.npair;
+    const int NT16 = (n + 15) >> 4, NP = NT16 << 4, OT = (o + 15) >> 4, OP = OT << 4, WS = OP + 1;
+    const double* __restrict__ Bf = bv.df_b + (size_t)f * na * (size_t)np;
+    const double* __restrict__ D = bv.D + (size_t)f * n * n;
+    const double* __restrict__ C = bv.C + (size_t)f * n * n;
+    // packed density, off-diagonal doubled: in LDS, or (DPG: large fragments) in the fragment's SCF workspace W, which
+    // nothing else uses while the J/K stage runs -- every workgroup of the fragment writes the same values
+    double* Dp = DPG ? bv.W + (size_t)f * 6 * n * n : lds;
+    double* row = lds + (DPG ? 0 : np);               // [np]  the current row of B
+    double* Co = row + np;                            // [NP][OP] occupied orbitals, zero padded
+    double* W = Co + (WITH_K ? (size_t)NP * OP : 0);  // [NP][WS]
+
+    for (int idx = tid; idx < np; idx += 64 * DJ_NW) {
+        int k, l;
+        df_unpack(idx, k, l);
+        const double d = D[k * n + l];
+        Dp[idx] = k == l ? d : 2.0 * d;
+    }
+    if (WITH_K) {
+        for (int idx = tid; idx < NP * OP; idx += 64 * DJ_NW) {
+            const int r = idx / OP, i = idx - r * OP;
+            Co[idx] = (r < n && i < o) ? C[r * n + i] : 0.0;
+        }
+        for (int idx = tid; idx < NP * WS; idx += 64 * DJ_NW) W[idx] = 0.0;
+    }
+    double jacc[NLD], nxt[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) jacc[k] = 0.0;
+    v4f64 kacc[JMAX];
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) kacc[j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    const int ntile = NT16 * (NT16 + 1) / 2;
+
+    int R = blockIdx.x;
+    if (R < na) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) { const int idx = tid + 64 * DJ_NW * k; nxt[k] = idx < np ? Bf[(size_t)R * np + idx] : 0.0; }
+    }
+    __syncthreads();
+    for (; R < na; R += gridDim.x) {
+        double cur[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) { cur[k] = nxt[k]; const int idx = tid + 64 * DJ_NW * k; if (idx < np) row[idx] = cur[k]; }
+        const int Rn = R + gridDim.x;
+        if (Rn < na) {
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) { const int idx = tid + 64 * DJ_NW * k; nxt[k] = idx < np ? Bf[(size_t)Rn * np + idx] : 0.0; }
+        }
+        __syncthreads();
+        // c_R: every wave forms the full dot product (no cross-wave exchange), then J += B_R c_R on the thread's pairs
+        double c = 0.0;
+        for (int idx = lane; idx < np; idx += 64) c += row[idx] * Dp[idx];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) jacc[k] += cur[k] * c;
+        if (WITH_K) {
+            // W_R = B_R C_occ: jobs (row tile, orbital tile)
+            for (int job = wave; job < NT16 * OT; job += DJ_NW) {
+                const int mt = job / OT, ot = job - mt * OT;
+                const int mu = 16 * mt + lo;
+                v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+                for (int ks = 0; ks < (NP >> 2); ++ks) {
+                    const int la = 4 * ks + hi;
+                    const double a = (mu < n && la < n) ? row[dj_pidx(mu, la)] : 0.0;
+                    const double b = Co[la * OP + 16 * ot + lo];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) W[(16 * mt + hi + 4 * r) * WS + 16 * ot + lo] = acc[r];
+            }
+            __syncthreads();
+            // K += W W^T on the lower-triangle tiles, dealt round-robin
+#pragma unroll
+            for (int j = 0; j < JMAX; ++j) {
+                const int t = wave + DJ_NW * j;
+                if (t < ntile) {
+                    int mt = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+                    while ((mt + 1) * (mt + 2) / 2 <= t) ++mt;
+                    while (mt * (mt + 1) / 2 > t) --mt;
+                    const int nt = t - mt * (mt + 1) / 2;
+                    const double* __restrict__ ar = W + (size_t)(16 * mt + lo) * WS + hi;
+                    const double* __restrict__ br = W + (size_t)(16 * nt + lo) * WS + hi;
+                    for (int ks = 0; ks < (OP >> 2); ++ks) kacc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[4 * ks], br[4 * ks], kacc[j], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // flush J (packed pairs of this thread) and K (this wave's tiles)
+    double* J = bv.J + (size_t)f * n * n;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int idx = tid + 64 * DJ_NW * k;
+        if (idx < np && jacc[k] != 0.0) {
+            int a, b;
+            df_unpack(idx, a, b);
+            atomicAdd(&J[a * n + b], jacc[k]);
+            if (a != b) atomicAdd(&J[b * n + a], jacc[k]);
+        }
+    }
+    if (WITH_K) {
+        double* K = bv.K + (size_t)f * n * n;
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) {
+            const int t = wave + DJ_NW * j;
+            if (t < ntile) {
+                int mt = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+                while ((mt + 1) * (mt + 2) / 2 <= t) ++mt;
+                while (mt * (mt + 1) / 2 > t) --mt;
+                const int nt = t - mt * (mt + 1) / 2;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int mu = 16 * mt + hi + 4 * r, nu = 16 * nt + lo;
+                    const double v = 2.0 * kacc[j][r];
+                    if (mu < n && nu < n && v != 0.0) {
+                        if (mt != nt) { atomicAdd(&K[mu * n + nu], v); atomicAdd(&K[nu * n + mu], v); }
+                        else atomicAdd(&K[mu * n + nu], v);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int JMAX, int NLD, bool WITH_K, bool DPG>
+static void df_jk_mfma_launch(const BatchView& bv, int oa, hipStream_t s)
+{
+    const int np16 = ((bv.n + 15) / 16) * 16, op = ((bv.nocc + 15) / 16) * 16;
+    const size_t lds = sizeof(double) * ((DPG ? 1 : 2) * (size_t)bv.npair + (WITH_K ? (size_t)np16 * op + (size_t)np16 * (op + 1) : 0) + 8);
+    auto kern = df_jk_mfma_kernel<JMAX, NLD, WITH_K, DPG>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int gx = (3072 + bv.nfrag - 1) / bv.nfrag;
+    if (gx > bv.naux) gx = bv.naux;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(kern, dim3(gx, bv.nfrag), dim3(64 * DJ_NW), lds, s, bv, oa);
+}
+
+// false: no instantiation covers this size (the round-1 kernels take it)
+static bool df_jk_mfma_dispatch(const BatchView& bv, int oa, hipStream_t s)
+{
+    const int nt = (bv.n + 15) / 16, ntile = nt * (nt + 1) / 2, jobs = (ntile + DJ_NW - 1) / DJ_NW;
+    const int nld = (bv.npair + 64 * DJ_NW - 1) / (64 * DJ_NW);
+    const bool k = bv.exx != 0.0;
+    const int np16 = nt * 16, op = ((bv.nocc + 15) / 16) * 16;
+    const size_t body = (k ? (size_t)np16 * op + (size_t)np16 * (op + 1) : 0) + 8;
+    const bool dpg = sizeof(double) * (2 * (size_t)bv.npair + body) > 64 * 1024;      // keep >= 2 workgroups per CU
+    if (sizeof(double) * ((size_t)bv.npair + body) > 150 * 1024) return false;
+#define DJ(JM, NL)                                                                                        \
+    do {                                                                                                  \
+        if (k) { if (dpg) df_jk_mfma_launch<JM, NL, true, true>(bv, oa, s); else df_jk_mfma_launch<JM, NL, true, false>(bv, oa, s); } \
+        else { if (dpg) df_jk_mfma_launch<1, NL, false, true>(bv, oa, s); else df_jk_mfma_launch<1, NL, false, false>(bv, oa, s); }   \
+        return true;                                                                                      \
+    } while (0)
+    if (jobs <= 1 && nld <= 2) DJ(1, 2);            // n <= 16..31
+    if (jobs <= 2 && nld <= 5) DJ(2, 5);            // n <= 48 (npair 1176)
+    if (jobs <= 3 && nld <= 9) DJ(3, 9);            // n <= 64
+    if (jobs <= 6 && nld <= 19) DJ(6, 19);          // n <= 96
+    if (jobs <= 9 && nld <= 33) DJ(9, 33);          // n <= 128
+#undef DJ
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------
 template <int LA, int LB, int LC>
 static void df3c_launch(const BatchView& bv, const std::vector<int>& t, int* d, hipStream_t s)
 {
@@ -363,6 +554,12 @@ void launch_df_jk(const BatchView& bv, bool only_active, hipStream_t s)
 {
     const int n = bv.n, oa = only_active ? 1 : 0;
     (void)hipMemsetAsync(bv.K, 0, sizeof(double) * (size_t)bv.nfrag * n * n, s);
+    // MQC_HIP_DF_V1=1: the round-1 kernels (J as one workgroup per fragment with two passes over B, K on the vector units)
+    static const bool v1 = [] { const char* e = std::getenv("MQC_HIP_DF_V1"); return e && e[0] == '1'; }();
+    if (!v1) {
+        (void)hipMemsetAsync(bv.J, 0, sizeof(double) * (size_t)bv.nfrag * n * n, s);
+        if (df_jk_mfma_dispatch(bv, oa, s)) return;
+    }
     const size_t ldsj = sizeof(double) * ((size_t)bv.npair + bv.naux + 8);
     (void)hipFuncSetAttribute((const void*)df_j_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsj);
     hipLaunchKernelGGL(df_j_kernel, dim3(bv.nfrag), dim3(DF_NT), ldsj, s, bv, oa);

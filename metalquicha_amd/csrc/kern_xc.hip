@@ -17,6 +17,7 @@
 // A += a chi^T accumulates in REGISTERS across all tiles of the workgroup and is flushed once.
 #include "engine.hpp"
 #include "md_integrals.hpp"
+#include <cstdlib>
 
 namespace mqc {
 
@@ -605,6 +606,209 @@ static void xc_mfma_launch(const BatchView& bv, int oa, hipStream_t s)
     hipLaunchKernelGGL(kern, dim3(gx, bv.nfrag), dim3(64 * XM_NW), lds, s, bv, oa);
 }
 
+// ------------------------------------------------------------------ tiled workgroup kernel, any n (round 2)
+// The wave-private kernel above keeps the whole density matrix and all n x n accumulator tiles in ONE wave's
+// registers: 400 registers, one wave per SIMD, every LDS / scalar / transcendental latency exposed, the functional
+// evaluated by 64 lanes for 16 points, and nothing above n = 48.  Here a WORKGROUP of XV_NW waves owns a tile of PT
+// points: the AO slab [function][point] is shared in LDS, and the two GEMM-shaped contractions are cut into
+// 16 x 16 MFMA jobs dealt round-robin to the waves --
+//     X = D chi      jobs (row tile, point tile): D as A-fragments straight from global memory (one fragment's D is
+//                    n^2 * 8 B and stays in L1/L2), chi as B-fragments from LDS; the job's partial rho / grad rho
+//                    are reduced over its 16 rows in registers and added into LDS with ds_add_f64;
+//     A += a chi^T   jobs (row tile, column tile): a wave keeps ITS tiles' accumulators (ceil(NT16^2 / XV_NW) of them)
+//                    in registers across all tiles of the workgroup and flushes them once.
+// A wave then needs < 128 registers at n = 48 (3 workgroups = 12 waves per CU), the functional runs once per point
+// (lane = point on wave 0 while the other workgroups of the CU compute), and n up to 144 uses the matrix cores
+// (benzene/cc-pVDZ n = 114, def2-TZVP water dimer n = 86).  Same arithmetic as mqc_libcint_xc.F90:796-927.
+constexpr int XV_NW = 4;
+
+template <bool GGA, int PT, int JMAX, int OCC>
+__global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, int only_active)
+{
+    extern __shared__ double lds[];
+    const int f = blockIdx.y;
+    if (only_active && bv.istate[4 * f] == ST_DONE) return;
+    constexpr int RS = PT + 1, PT16 = PT / 16;
+    const int n = bv.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lo = lane & 15, hi = lane >> 4;
+    const int NT16 = (n + 15) >> 4, NP = NT16 << 4, KS = NP >> 2;
+    const TopologyDev& tp = bv.topo;
+    const GridDev& gd = bv.grid;
+    double* chi = lds;                                        // [NP][RS]
+    double* gx = chi + (size_t)NP * RS;                       // GGA: grad chi, x then overwritten by a;  LDA: a
+    double* gy = gx + (size_t)NP * RS;
+    double* gz = gy + (GGA ? (size_t)NP * RS : 0);
+    double* red = gz + (GGA ? (size_t)NP * RS : 0);           // [PT][4] rho, grad rho partial sums
+    double* coef = red + 4 * PT;                              // [PT][4] w v_rho / 2, 2 w v_sigma grad rho
+    const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
+    const double* __restrict__ D = bv.D + (size_t)f * n * n;
+    const double* __restrict__ wts = gd.weights + (size_t)f * gd.npts;
+
+    // rows n..NP-1 stay zero for the whole kernel; the sums start at zero
+    for (int idx = tid; idx < (GGA ? 4 : 2) * NP * RS + 8 * PT; idx += 64 * XV_NW) lds[idx] = 0.0;
+    v4f64 vacc[JMAX];
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) vacc[j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    double e_acc = 0.0, n_acc = 0.0;
+    __syncthreads();
+
+    const int ntiles = (gd.npts + PT - 1) / PT;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int g0 = tile * PT;
+        // 1. AO values (and gradients) of the tile: (radial group, point) items, point fastest
+        for (int idx = tid; idx < tp.ngroup * PT; idx += 64 * XV_NW) {
+            const int rg = idx / PT, p = idx - rg * PT;
+            const int g = g0 + p;
+            if (g < gd.npts) {
+                const int oa = gd.pt_atom[g], it = gd.pt_tmpl[g];
+                eval_group<GGA>(tp, xyz, rg, xyz[3 * oa] + gd.tmpl_xyz[3 * it], xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1],
+                                xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2], chi, gx, gy, gz, RS, p);
+            } else {
+                zero_group<GGA>(tp, rg, chi, gx, gy, gz, RS, p);
+            }
+        }
+        __syncthreads();
+        // 2. X = D chi, job = (row tile mt, point tile pt); rho and grad rho from the accumulator rows
+        for (int job = wave; job < NT16 * PT16; job += XV_NW) {
+            const int mt = job / PT16, pt = job - mt * PT16;
+            v4f64 xacc = (v4f64){0.0, 0.0, 0.0, 0.0};
+            const int mu_a = 16 * mt + lo;
+            const double* __restrict__ drow = D + (size_t)mu_a * n;
+            const bool row_ok = mu_a < n;
+            for (int ks = 0; ks < KS; ++ks) {
+                const int nu = 4 * ks + hi;
+                const double a = (row_ok && nu < n) ? drow[nu] : 0.0;
+                const double b = chi[nu * RS + 16 * pt + lo];
+                xacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, xacc, 0, 0, 0);
+            }
+            double rho = 0.0, rx = 0.0, ry = 0.0, rz = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = (16 * mt + hi + 4 * r) * RS + 16 * pt + lo;
+                const double x = xacc[r];
+                rho += x * chi[o];
+                if (GGA) { rx += x * gx[o]; ry += x * gy[o]; rz += x * gz[o]; }
+            }
+            rho += __shfl_xor(rho, 16, 64); rho += __shfl_xor(rho, 32, 64);
+            if (GGA) {
+                rx += __shfl_xor(rx, 16, 64); rx += __shfl_xor(rx, 32, 64);
+                ry += __shfl_xor(ry, 16, 64); ry += __shfl_xor(ry, 32, 64);
+                rz += __shfl_xor(rz, 16, 64); rz += __shfl_xor(rz, 32, 64);
+            }
+            if (hi == 0) {
+                double* rp = red + 4 * (16 * pt + lo);
+                atomicAdd(&rp[0], rho);
+                if (GGA) { atomicAdd(&rp[1], rx); atomicAdd(&rp[2], ry); atomicAdd(&rp[3], rz); }
+            }
+        }
+        __syncthreads();
+        // 3. the functional, one lane per point
+        if (tid < PT) {
+            const int p = tid;
+            double* rp = red + 4 * p;
+            const double rho = rp[0], rx = 2.0 * rp[1], ry = 2.0 * rp[2], rz = 2.0 * rp[3];
+            rp[0] = 0.0; rp[1] = 0.0; rp[2] = 0.0; rp[3] = 0.0;
+            const double sigma = GGA ? rx * rx + ry * ry + rz * rz : 0.0;
+            double fx, vr, vs;
+            eval_functional(bv.xc, rho, sigma, fx, vr, vs);
+            const double w = (g0 + p < gd.npts) ? wts[g0 + p] : 0.0;
+            e_acc += w * fx;
+            n_acc += w * rho;
+            double* cp = coef + 4 * p;
+            cp[0] = 0.5 * w * vr;
+            const double t2 = 2.0 * w * vs;
+            cp[1] = t2 * rx; cp[2] = t2 * ry; cp[3] = t2 * rz;
+        }
+        __syncthreads();
+        // 4. a[mu][p] = w v_rho / 2 chi + 2 w v_sigma grad rho . grad chi, written over gx
+        for (int idx = tid; idx < n * PT; idx += 64 * XV_NW) {
+            const int mu = idx / PT, p = idx - mu * PT;
+            const int o = mu * RS + p;
+            const double* cp = coef + 4 * p;
+            double a = cp[0] * chi[o];
+            if (GGA) a += cp[1] * gx[o] + cp[2] * gy[o] + cp[3] * gz[o];
+            gx[o] = a;
+        }
+        __syncthreads();
+        // 5. A += a chi^T: this wave's tiles t = wave, wave + XV_NW, ...
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) {
+            const int t = wave + XV_NW * j;
+            if (t < NT16 * NT16) {
+                const int mt = t / NT16, nt = t - mt * NT16;
+                const double* __restrict__ ar = gx + (size_t)(16 * mt + lo) * RS + hi;
+                const double* __restrict__ br = chi + (size_t)(16 * nt + lo) * RS + hi;
+#pragma unroll
+                for (int ks = 0; ks < PT / 4; ++ks) vacc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[4 * ks], br[4 * ks], vacc[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // flush: lane holds A[mu = 16 mt + hi + 4 r][nu = 16 nt + lo]
+    double* Vx = bv.Vxc + (size_t)f * n * n;
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        const int t = wave + XV_NW * j;
+        if (t < NT16 * NT16) {
+            const int mt = t / NT16, nt = t - mt * NT16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mu = 16 * mt + hi + 4 * r, nu = 16 * nt + lo;
+                const double v = vacc[j][r];
+                if (mu < n && nu < n && v != 0.0) atomicAdd(&Vx[mu * n + nu], v);
+            }
+        }
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { e_acc += __shfl_down(e_acc, off, 64); n_acc += __shfl_down(n_acc, off, 64); }
+        if (lane == 0) {
+            atomicAdd(&bv.scal[(size_t)f * 8 + 5], e_acc);
+            atomicAdd(&bv.scal[(size_t)f * 8 + 6], n_acc);
+        }
+    }
+}
+
+template <bool GGA, int PT, int JMAX, int OCC>
+static void xc_tile_launch(const BatchView& bv, int oa, hipStream_t s)
+{
+    const int np = ((bv.n + 15) / 16) * 16;
+    const size_t lds = sizeof(double) * ((size_t)(GGA ? 4 : 2) * np * (PT + 1) + 8 * PT);
+    auto kern = xc_tile_kernel<GGA, PT, JMAX, OCC>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int ntiles = (bv.grid.npts + PT - 1) / PT;
+    int gx = (6144 + bv.nfrag - 1) / bv.nfrag;       // ~3 workgroups per CU x 8 in flight over the batch; many tiles each
+    if (gx > ntiles) gx = ntiles;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(kern, dim3(gx, bv.nfrag), dim3(64 * XV_NW), lds, s, bv, oa);
+}
+
+template <bool GGA>
+static bool xc_tile_dispatch(const BatchView& bv, int oa, hipStream_t s)
+{
+    // waves per SIMD the register allocation aims at for the 32-point kernels: 2 (224 registers, no scratch) or
+    // 3 (168 registers, ~160 B of scratch in the functional); MQC_HIP_XC_OCC picks, measured default below
+    static const int occ = [] { const char* e = std::getenv("MQC_HIP_XC_OCC"); return e ? std::atoi(e) : 2; }();
+    const int nt = (bv.n + 15) / 16, jobs = (nt * nt + XV_NW - 1) / XV_NW;
+    if (nt <= 4) {                       // n <= 64: 32-point tiles
+        if (occ >= 3) {
+            if (jobs <= 1) xc_tile_launch<GGA, 32, 1, 3>(bv, oa, s);
+            else if (jobs <= 3) xc_tile_launch<GGA, 32, 3, 3>(bv, oa, s);
+            else xc_tile_launch<GGA, 32, 4, 3>(bv, oa, s);
+        } else {
+            if (jobs <= 1) xc_tile_launch<GGA, 32, 1, 2>(bv, oa, s);
+            else if (jobs <= 3) xc_tile_launch<GGA, 32, 3, 2>(bv, oa, s);
+            else xc_tile_launch<GGA, 32, 4, 2>(bv, oa, s);
+        }
+        return true;
+    }
+    if (jobs <= 9) xc_tile_launch<GGA, 16, 9, 1>(bv, oa, s);             // n <= 96
+    else if (jobs <= 16) xc_tile_launch<GGA, 16, 16, 1>(bv, oa, s);      // n <= 128
+    else if (jobs <= 21) xc_tile_launch<GGA, 16, 21, 1>(bv, oa, s);      // n <= 144
+    else return false;
+    return true;
+}
+
 __global__ void xc_reset_kernel(BatchView bv)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -631,6 +835,9 @@ void launch_xc(const BatchView& bv, bool only_active, hipStream_t s)
     (void)hipMemsetAsync(bv.Vxc, 0, sizeof(double) * (size_t)bv.nfrag * n * n, s);
     hipLaunchKernelGGL(xc_reset_kernel, dim3((bv.nfrag + 255) / 256), dim3(256), 0, s, bv);
     const bool gga = bv.xc.gga != 0;
+    // MQC_HIP_XC_V1=1: the round-1 kernels (wave-private MFMA kernel for n <= 48, VALU kernel above), kept for A/B runs
+    static const bool v1 = [] { const char* e = std::getenv("MQC_HIP_XC_V1"); return e && e[0] == '1'; }();
+    if (!v1 && (gga ? xc_tile_dispatch<true>(bv, oa, s) : xc_tile_dispatch<false>(bv, oa, s))) return;
     if (n <= 48) {
         // fragment sizes of an MBE run: both GEMMs on the FP64 matrix cores
         if (n <= 32) { if (gga) xc_mfma_launch<true, 2>(bv, oa, s); else xc_mfma_launch<false, 2>(bv, oa, s); }

@@ -15,9 +15,9 @@ def fragment_bohr(Z, xyz_bohr, **kw) -> PhysicalFragment:
 
 
 def oracle_mol(basis: str, frag: PhysicalFragment):
-    fb = build_flat_basis(basis, frag.element_numbers)
+    fb = build_flat_basis(basis, frag.element_numbers, allow_cartesian=True)
     return so.make_mol(frag.element_numbers, frag.coordinates.T, fb.nshell_per_atom, fb.shell_l, fb.shell_nprim,
-                       fb.exps, fb.coefs, ghost=frag.ghost)
+                       fb.exps, fb.coefs, ghost=frag.ghost, cart=not fb.spherical)
 
 
 def random_rotation(rng):

@@ -118,8 +118,11 @@ from metalquicha_amd.basis import SYMBOL_TO_Z
 from oracle import grid_oracle, xc_oracle
 
 _CASES = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "manifest_subset.json")))["cases"]
-_RHF = [c for c in _CASES if c["method"] == "hf" and "mbe_level" not in c and "gradient" not in c["name"]]
-_KS = [c for c in _CASES if c["method"] == "dft" and c["functional"] in xc_oracle.FUNCTIONALS and "grid 3" in c["name"]]
+_RHF = [c for c in _CASES if c["method"] == "hf" and "mbe_level" not in c and c["driver"] == "Energy"
+        and not c["unrestricted"] and not c["density_fitting"]]
+_DF = [c for c in _CASES if c["method"] == "hf" and c["density_fitting"] and c["driver"] == "Energy" and not c["unrestricted"]]
+_KS = [c for c in _CASES if c["method"] == "dft" and c["functional"] in xc_oracle.FUNCTIONALS and "grid 3" in c["name"]
+       and not c["unrestricted"] and not c["density_fitting"]]
 
 
 def _mol(c):
@@ -130,9 +133,26 @@ def _mol(c):
 
 @pytest.mark.parametrize("case", _RHF, ids=[c["name"] for c in _RHF])
 def test_manifest_rhf(case):
-    """PySCF-referenced RHF energies (tolerance 1e-9): pins STO-3G and cc-pVDZ for H, C, N, O."""
+    """PySCF-referenced RHF energies (tolerance 1e-9): pins STO-3G, cc-pVDZ, 6-31G, 6-31G* / 6-31G** (Cartesian d),
+    def2-SVP and def2-TZVP (f shells) for H, C, N, O as typed into metalquicha_amd/basis_data."""
     frag, mol = _mol(case)
     r = so.run_rhf(mol, int(frag.nelec), case["maxiter"], 1e-10, 1e-7)
+    assert r.converged
+    assert abs(r.energy - case["expected_energy"]) < 1e-9
+
+
+@pytest.mark.parametrize("case", _DF, ids=[c["name"] for c in _DF])
+def test_manifest_density_fitted_rhf(case):
+    """The reference's density-fitted RHF goldens whose auxiliary basis this repository can supply: H2O 6-31G*/6-31G*
+    -76.188111755038 and CH4 6-31G**/6-31G** -40.381603512964 (validation_tests_cpu.json, df-hf/).  This is what pins
+    the oracle's DF leg -- three-centre (mu nu|P) and two-centre (P|Q) integrals, the J^{-1/2} fit with its 1e-10
+    eigenvalue cut (mqc_libcint_integrals.F90:913-1038), DF-J and DF-K (mqc_libcint_rhf.f90:1576-1646) -- to numbers
+    the reference produced; the HIP DF path is then compared with this oracle."""
+    frag, mol = _mol(case)
+    z = [SYMBOL_TO_Z[s.lower()] for s in case["symbols"]]
+    aux = oracle_mol(case["aux_basis"], fragment_bohr(z, np.array(case["xyz_angstrom"]) * ANGSTROM_TO_BOHR))
+    assert mol.cart and aux.cart          # Pople star sets: Cartesian d on both sides (they must share the angular form)
+    r = so.run_rhf(mol, int(frag.nelec), case["maxiter"], 1e-10, 1e-7, aux=aux)
     assert r.converged
     assert abs(r.energy - case["expected_energy"]) < 1e-9
 
