@@ -210,6 +210,11 @@ static int validate_options(const mqc_hip_scf_options_t& o, const Topology& topo
     if (o.max_iter < 1) { msg = "max_iter must be positive"; return MQC_HIP_ERR_VALIDATION; }
     if (o.use_diis && (o.diis_size < 0 || o.diis_size > DIIS_MAX)) { msg = "diis_size must be within 0..8"; return MQC_HIP_ERR_VALIDATION; }
     if (!o.density_fitting && o.eri_mode == MQC_HIP_ERI_INCORE && !incore_supported(topo.nao)) { msg = "fragment too large for the in-core exact-ERI path (n_ao <= 116); use eri_mode auto/direct or density fitting"; return MQC_HIP_ERR_UNSUPPORTED; }
+    if (topo.lmax > CLASS_LMAX) {
+        const bool direct = !o.density_fitting && (o.eri_mode == MQC_HIP_ERI_DIRECT || (o.eri_mode == MQC_HIP_ERI_AUTO && !incore_supported(topo.nao)));
+        if (direct) { msg = "orbital f shells: the direct (integral-recomputing) Fock build covers s, p, d shells; this fragment is too large for the in-core path (n_ao <= 116)"; return MQC_HIP_ERR_UNSUPPORTED; }
+        if (o.density_fitting) { msg = "orbital f shells with density fitting are not available in this build of the HIP backend (three-centre kernels cover s, p, d orbital shells)"; return MQC_HIP_ERR_UNSUPPORTED; }
+    }
     if (topo.nao > 140) { msg = "fragment too large for the LDS eigen-solver (n_ao <= 140)"; return MQC_HIP_ERR_UNSUPPORTED; }
     return MQC_HIP_OK;
 }
@@ -318,7 +323,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
 
     const int n = topo.nao;
     const size_t np = (size_t)topo.npair;
-    const size_t two_e = use_df ? (2 * (size_t)naux * np + 2 * (size_t)naux * naux) : (use_direct ? 2 * (size_t)n * n : np * np);
+    const size_t two_e = use_df ? (2 * (size_t)naux * np + 3 * (size_t)naux * naux) : (use_direct ? 2 * (size_t)n * n : np * np);
     const size_t per_frag = sizeof(double) * (per_fragment_main_doubles(n, topo.natoms) + two_e + (xc.ncomp > 0 ? (size_t)n * n + grid.npts : 0));
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
@@ -377,9 +382,10 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         bv.naux = naux; bv.aux = tdx; bv.unit = ctx->d_unit;
         if (use_df) {
             const size_t a3 = (size_t)nf * naux * np, mm = (size_t)nf * naux * naux;
-            double* base = (double*)sl.df->ensure(sizeof(double) * (2 * a3 + 2 * mm) + 1024);
+            double* base = (double*)sl.df->ensure(sizeof(double) * (2 * a3 + 3 * mm) + 1024);
             if (!base) return fail(MQC_HIP_ERR_DEVICE, "out of device memory (fitted tensor)");
             bv.df_a3 = base; bv.df_b = base + a3; bv.df_metric = base + 2 * a3; bv.df_linv = base + 2 * a3 + mm;
+            bv.df_work = base + 2 * a3 + 2 * mm;
             HIP_CHECK_RET(hipMemsetAsync(bv.scal, 0, sizeof(double) * (size_t)nf * 8, s));
         }
         bv.nocc = nocc; bv.exx = xc.exx; bv.e_tol = opts.energy_tol; bv.d_tol = opts.density_tol;
@@ -541,9 +547,8 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
                 HIP_CHECK_RET(hipStreamSynchronize(s));
             }
             r->has_error = 0; r->message[0] = '\0';
-            if (use_df && scal[8 * f + 7] != 0.0)
-                fill_error(r, "density fitting: the auxiliary metric (P|Q) is near-singular (pivot below 1e-10); "
-                              "the reference would drop those modes, this backend refuses instead");
+            if (use_df && scal[8 * f + 7] == 1.0)
+                fill_error(r, "density fitting: the auxiliary metric (P|Q) could not be factorised or diagonalised");
             else if (!std::isfinite(r->e_total)) fill_error(r, "SCF produced a non-finite energy");
             else if (!conv && !opts.allow_crap_scf)
                 fill_error(r, "SCF did not converge in " + std::to_string(r->iterations) + " iterations");

@@ -20,7 +20,8 @@
 
 namespace mqc {
 
-constexpr int KERNEL_LMAX = 2;      // highest AO angular momentum the compiled kernel classes cover
+constexpr int KERNEL_LMAX = 3;      // highest AO angular momentum: s, p, d by per-class register kernels, f by the general LDS kernel
+constexpr int CLASS_LMAX = 2;       // highest l the per-class ERI / digest / 3-centre kernels are instantiated for
 constexpr int AUX_LMAX = 3;         // highest angular momentum of an auxiliary (fitting) shell
 constexpr int DIIS_MAX = 8;         // subspace size the device ring buffers are laid out for
 
@@ -146,6 +147,7 @@ struct BatchView {      // plain pointers handed to kernels
     const double* unit;           // {0.0, 1.0}: exponent and coefficient of the unit shell
     double *df_a3, *df_b;         // [nfrag][naux][npair]: (P|mu nu) and the fitted tensor
     double *df_metric, *df_linv;  // [nfrag][naux][naux]
+    double* df_work;              // [nfrag][naux][naux] scratch of the fit (saved diagonal; V^T of the eigen path)
 };
 
 struct Stats {
@@ -218,6 +220,10 @@ void launch_dipole(const BatchView& bv, const Topology& topo, hipStream_t s);
 void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, hipStream_t s, const double* host_xyz = nullptr);
 // optional head start of the screened build (bounds + zero fill on side streams); launch_eri joins it
 void launch_eri_bounds(const BatchView& bv, const Topology& topo, double schwarz_tol, hipStream_t s);
+// wave-cooperative kernel for classes with an f (or g) shell (kern_eri_general.hip); false: class too large for LDS
+bool launch_eri_general(const BatchView& bv, int la, int lb, int lc, int ld, const int* d_list, int nq, const int* d_tasks, int ntasks,
+                        const double* Q, double thresh, hipStream_t s);
+bool launch_schwarz_general(const BatchView& bv, int la, int lb, const int* d_pairs, int npairs, double* Qout, hipStream_t s);
 void eri_set_side_streams(int slot, const hipStream_t* streams, int count);
 void launch_jk_incore(const BatchView& bv, bool only_active, hipStream_t s);
 void launch_direct_setup(const BatchView& bv, const Topology& topo, hipStream_t s);

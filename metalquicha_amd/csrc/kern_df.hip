@@ -117,15 +117,29 @@ __global__ void __launch_bounds__(64) df2c_kernel(BatchView bv, const int* __res
         }
 }
 
-// In-place Cholesky M = L L^T (lower) and Linv = L^{-1}, one workgroup per fragment, global memory.
+// In-place Cholesky M = L L^T (lower) and Linv = L^{-1}, one workgroup per fragment, matrices in global memory (L2).
+// Step k: column k goes to LDS (scaled), then the trailing update runs row-wise -- a wave per row, lanes along the
+// row -- so every access to the matrix is a contiguous row segment (the round-1 version walked (i, j) by integer
+// division with a strided column read per element: 0.8 GB of L2 transactions per fragment, 38 ms for 2016 dimers).
+//
+// Which fit is it?  The reference forms J^{-1/2} = U s^{-1/2} U^T over the eigenvalues ABOVE 1e-10
+// (metric_inverse_sqrt, mqc_libcint_integrals.F90:992-1038).  J and K depend on the fitted tensor through B^T B only,
+// and B^T B = A3^T J^{-1} A3 for ANY square root -- so when no eigenvalue is cut, the Cholesky fit gives the
+// reference's J and K exactly.  No eigenvalue is cut when lambda_min > 1e-10, and lambda_min = 1/||J^{-1}||_2 >=
+// 1/||L^{-1}||_F^2: the kernel checks that bound (and the pivots) and flags the fragment otherwise (scal[7] = 1);
+// flagged fragments take the eigen-decomposition path below, which applies the cut as the reference does.
 __global__ void __launch_bounds__(DF_NT) df_cholesky_kernel(BatchView bv)
 {
+    extern __shared__ double colbuf[];       // [na] column k, then reduction scratch
     const int f = blockIdx.x, tid = threadIdx.x, na = bv.naux;
+    const int lane = tid & 63, wave = tid >> 6;
     double* M = bv.df_metric + (size_t)f * na * na;
     double* Li = bv.df_linv + (size_t)f * na * na;
-    __shared__ double s_d;
+    double* save = bv.df_work + (size_t)f * na * na;     // the diagonal survives here (first na entries)
+    __shared__ double s_d, s_red[DF_NT / 64];
     __shared__ int s_bad;
     if (tid == 0) s_bad = 0;
+    for (int i = tid; i < na; i += DF_NT) save[i] = M[(size_t)i * na + i];
     __syncthreads();
     for (int k = 0; k < na; ++k) {
         if (tid == 0) {
@@ -134,57 +148,172 @@ __global__ void __launch_bounds__(DF_NT) df_cholesky_kernel(BatchView bv)
             s_d = sqrt(akk > DF_PIVOT_FLOOR ? akk : 1.0);
         }
         __syncthreads();
-        const double d = s_d;
-        for (int i = k + tid; i < na; i += DF_NT) M[(size_t)i * na + k] = (i == k) ? d : M[(size_t)i * na + k] / d;
+        const double d = s_d, rd = 1.0 / d;
+        for (int i = k + tid; i < na; i += DF_NT) {
+            const double v = (i == k) ? d : M[(size_t)i * na + k] * rd;
+            M[(size_t)i * na + k] = v;
+            colbuf[i] = v;
+        }
         __syncthreads();
-        // trailing update of the lower triangle: rows i > k, columns k < j <= i
-        const int m = na - k - 1;
-        for (long idx = tid; idx < (long)m * m; idx += DF_NT) {
-            const int ii = (int)(idx / m), jj = (int)(idx % m);
-            if (jj > ii) continue;
-            const int i = k + 1 + ii, j = k + 1 + jj;
-            M[(size_t)i * na + j] -= M[(size_t)i * na + k] * M[(size_t)j * na + k];
+        for (int i = k + 1 + wave; i < na; i += DF_NT / 64) {
+            const double ci = colbuf[i];
+            double* __restrict__ row = M + (size_t)i * na;
+            for (int j = k + 1 + lane; j <= i; j += 64) row[j] -= ci * colbuf[j];
         }
         __syncthreads();
     }
-    // Linv by forward substitution, one column per thread: L X = I
-    for (int c = tid; c < na; c += DF_NT) {
+    // Linv by forward substitution, one column per thread: L X = I  (row r of L through LDS)
+    double fro = 0.0;
+    for (int c0 = 0; c0 < na; c0 += DF_NT) {
+        const int c = c0 + tid;
         for (int r = 0; r < na; ++r) {
-            double s = (r == c) ? 1.0 : 0.0;
-            if (r < c) { Li[(size_t)r * na + c] = 0.0; continue; }
-            for (int t = c; t < r; ++t) s -= M[(size_t)r * na + t] * Li[(size_t)t * na + c];
-            Li[(size_t)r * na + c] = s / M[(size_t)r * na + r];
-        }
-    }
-    if (tid == 0 && s_bad) bv.scal[(size_t)f * 8 + 7] = 1.0;   // near-singular metric: reported by the host
-}
-
-// Bfit[R][col] = sum_{S <= R} Linv[R][S] A3[S][col]; thread = one packed pair column, 8 rows at a time
-__global__ void __launch_bounds__(DF_NT) df_fit_kernel(BatchView bv)
-{
-    const int f = blockIdx.y, na = bv.naux;
-    const size_t np = (size_t)bv.npair;
-    const long col = (long)blockIdx.x * DF_NT + threadIdx.x;
-    if (col >= (long)np) return;
-    const double* __restrict__ A3 = bv.df_a3 + (size_t)f * na * np;
-    double* __restrict__ Bf = bv.df_b + (size_t)f * na * np;
-    const double* __restrict__ Li = bv.df_linv + (size_t)f * na * na;
-    constexpr int RB = 8;
-    for (int r0 = 0; r0 < na; r0 += RB) {
-        double acc[RB];
-#pragma unroll
-        for (int r = 0; r < RB; ++r) acc[r] = 0.0;
-        const int rmax = min(r0 + RB, na);
-        for (int s = 0; s < rmax; ++s) {
-            const double a = A3[(size_t)s * np + col];
-#pragma unroll
-            for (int r = 0; r < RB; ++r) {
-                const int R = r0 + r;
-                if (R < na && s <= R) acc[r] += Li[(size_t)R * na + s] * a;
+            __syncthreads();
+            for (int t = tid; t <= r; t += DF_NT) colbuf[t] = M[(size_t)r * na + t];
+            __syncthreads();
+            if (c < na) {
+                double v = 0.0;
+                if (r >= c) {
+                    double s = (r == c) ? 1.0 : 0.0;
+                    for (int t = c; t < r; ++t) s -= colbuf[t] * Li[(size_t)t * na + c];
+                    v = s / colbuf[r];
+                    fro += v * v;
+                }
+                Li[(size_t)r * na + c] = v;
             }
         }
+    }
 #pragma unroll
-        for (int r = 0; r < RB; ++r) if (r0 + r < na) Bf[(size_t)(r0 + r) * np + col] = acc[r];
+    for (int off = 32; off > 0; off >>= 1) fro += __shfl_xor(fro, off, 64);
+    if (lane == 0) s_red[wave] = fro;
+    __syncthreads();
+    if (tid == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < DF_NT / 64; ++w) tot += s_red[w];
+        // lambda_min >= 1 / ||L^-1||_F^2 must clear the reference's cut with a margin for the rounding of the factor
+        const bool safe = !s_bad && tot > 0.0 && (1.0 / tot) > 2.0 * DF_PIVOT_FLOOR;
+        bv.scal[(size_t)f * 8 + 7] = safe ? 0.0 : 1.0;
+        s_bad = safe ? 0 : 1;
+    }
+    __syncthreads();
+    if (s_bad) {
+        // hand the eigen path a pristine metric: the strict upper triangle was never touched, the diagonal was saved
+        for (int i = wave; i < na; i += DF_NT / 64)
+            for (int j = lane; j < i; j += 64) M[(size_t)i * na + j] = M[(size_t)j * na + i];
+        __syncthreads();
+        for (int i = tid; i < na; i += DF_NT) M[(size_t)i * na + i] = save[i];
+    }
+}
+
+// Eigen path for flagged fragments: the reference's J^{-1/2} = U s^{-1/2} U^T over eigenvalues > 1e-10.
+// One-sided (Hestenes) Jacobi on the ROWS of B = V^T M: plane rotations make the rows orthogonal; then row p of V^T is
+// eigenvector p and lambda_p = b_p . v_p.  Rows are contiguous, a wave owns a pair of rows, the pairs of one round of
+// the round-robin ordering are disjoint.  Rare (a well-conditioned auxiliary basis never comes here), so the kernel
+// is written for robustness, not speed.
+__global__ void __launch_bounds__(DF_NT) df_metric_eig_kernel(BatchView bv)
+{
+    const int f = blockIdx.x, tid = threadIdx.x, na = bv.naux;
+    if (bv.scal[(size_t)f * 8 + 7] == 0.0) return;
+    const int lane = tid & 63, wave = tid >> 6;
+    double* Bm = bv.df_metric + (size_t)f * na * na;      // becomes V^T M
+    double* Vt = bv.df_work + (size_t)f * na * na;        // V^T
+    double* T = bv.df_linv + (size_t)f * na * na;         // result: J^{-1/2}
+    __shared__ double s_off[DF_NT / 64];
+    __shared__ int s_done;
+    for (int idx = tid; idx < na * na; idx += DF_NT) Vt[idx] = (idx / na == idx % na) ? 1.0 : 0.0;
+    __syncthreads();
+    const int m = (na + 1) & ~1;                          // players of the tournament (one bye when na is odd)
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        double worst = 0.0;
+        for (int round = 0; round < m - 1; ++round) {
+            for (int k = wave; k < m / 2; k += DF_NT / 64) {
+                int p, q;
+                if (k == 0) { p = m - 1; q = round; }
+                else { p = (round + k) % (m - 1); q = (round - k + (m - 1)) % (m - 1); }
+                if (p >= na || q >= na) continue;
+                double* bp = Bm + (size_t)p * na; double* bq = Bm + (size_t)q * na;
+                double al = 0.0, be = 0.0, ga = 0.0;
+                for (int j = lane; j < na; j += 64) { const double x = bp[j], y = bq[j]; al += x * x; be += y * y; ga += x * y; }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) { al += __shfl_xor(al, off, 64); be += __shfl_xor(be, off, 64); ga += __shfl_xor(ga, off, 64); }
+                const double lim = sqrt(al * be);
+                if (!(fabs(ga) > 1.0e-15 * lim) || lim == 0.0) continue;
+                worst = fmax(worst, fabs(ga) / lim);
+                const double zeta = (be - al) / (2.0 * ga);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                double* vp = Vt + (size_t)p * na; double* vq = Vt + (size_t)q * na;
+                for (int j = lane; j < na; j += 64) {
+                    const double x = bp[j], y = bq[j];
+                    bp[j] = c * x - sn * y; bq[j] = sn * x + c * y;
+                    const double u = vp[j], w = vq[j];
+                    vp[j] = c * u - sn * w; vq[j] = sn * u + c * w;
+                }
+            }
+            __syncthreads();
+        }
+        if (lane == 0) s_off[wave] = worst;
+        __syncthreads();
+        if (tid == 0) {
+            double w = 0.0;
+            for (int k = 0; k < DF_NT / 64; ++k) w = fmax(w, s_off[k]);
+            s_done = w < 1.0e-14;
+        }
+        __syncthreads();
+        if (s_done) break;
+    }
+    // T = sum over kept p of v_p v_p^T / sqrt(lambda_p), lambda_p = b_p . v_p; the first row of B keeps 1/sqrt(lambda) (0 = cut)
+    double* isl = Bm;      // reuse: inverse square roots go to a scratch row after the eigenvalues are known
+    __syncthreads();
+    double lam_keep = 0.0;
+    (void)lam_keep;
+    // eigenvalues first (rows of B are still needed), then overwrite row storage
+    for (int p = wave; p < na; p += DF_NT / 64) {
+        double s = 0.0;
+        for (int j = lane; j < na; j += 64) s += Bm[(size_t)p * na + j] * Vt[(size_t)p * na + j];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) T[p] = (s > DF_PIVOT_FLOOR) ? 1.0 / sqrt(s) : 0.0;      // parked in T's first row for a moment
+    }
+    __syncthreads();
+    for (int p = tid; p < na; p += DF_NT) isl[p] = T[p];
+    __syncthreads();
+    for (int idx = tid; idx < na * na; idx += DF_NT) {
+        const int i = idx / na, j = idx - i * na;
+        double s = 0.0;
+        for (int p = 0; p < na; ++p) s += isl[p] * Vt[(size_t)p * na + i] * Vt[(size_t)p * na + j];
+        T[idx] = s;
+    }
+    if (tid == 0) bv.scal[(size_t)f * 8 + 7] = 2.0;       // fitted with the full symmetric J^{-1/2}
+}
+
+// Bfit = Linv x A3 on the FP64 matrix cores: job = (16 auxiliary rows, 16 packed-pair columns); the lower-triangular
+// factor stops the k loop at the diagonal block, the symmetric J^{-1/2} of the eigen path (flag 2) runs it in full.
+__global__ void __launch_bounds__(DF_NT) df_fit_mfma_kernel(BatchView bv)
+{
+    const int f = blockIdx.y, na = bv.naux;
+    const int np = bv.npair;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lo = lane & 15, hi = lane >> 4;
+    const int nrt = (na + 15) >> 4, nct = (np + 15) >> 4;
+    const bool full = bv.scal[(size_t)f * 8 + 7] == 2.0;
+    const double* __restrict__ A3 = bv.df_a3 + (size_t)f * na * (size_t)np;
+    double* __restrict__ Bf = bv.df_b + (size_t)f * na * (size_t)np;
+    const double* __restrict__ Li = bv.df_linv + (size_t)f * na * na;
+    for (int job = blockIdx.x * (DF_NT / 64) + wave; job < nrt * nct; job += gridDim.x * (DF_NT / 64)) {
+        const int rt = job / nct, ct = job - rt * nct;
+        const int R = 16 * rt + lo, col = 16 * ct + lo;
+        const int kend = full ? na : min(na, 16 * (rt + 1));
+        v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+        for (int s0 = 0; s0 < kend; s0 += 4) {
+            const int sidx = s0 + hi;
+            const double a = (R < na && sidx < kend && (full || sidx <= R)) ? Li[(size_t)R * na + sidx] : 0.0;
+            const double b = (sidx < kend && col < np) ? A3[(size_t)sidx * np + col] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * rt + hi + 4 * r;
+            if (row < na && col < np) Bf[(size_t)row * np + col] = acc[r];
+        }
     }
 }
 
@@ -544,8 +673,14 @@ void launch_df_build(const BatchView& bv, const Topology& topo, const Topology& 
 #define DF2(p, q) df2c_launch<p, q>(bv, t2[p][q], d + off, s); off += t2[p][q].size();
     DF2(0, 0) DF2(1, 0) DF2(1, 1) DF2(2, 0) DF2(2, 1) DF2(2, 2) DF2(3, 0) DF2(3, 1) DF2(3, 2) DF2(3, 3)
 #undef DF2
-    hipLaunchKernelGGL(df_cholesky_kernel, dim3(bv.nfrag), dim3(DF_NT), 0, s, bv);
-    hipLaunchKernelGGL(df_fit_kernel, dim3((bv.npair + DF_NT - 1) / DF_NT, bv.nfrag), dim3(DF_NT), 0, s, bv);
+    hipLaunchKernelGGL(df_cholesky_kernel, dim3(bv.nfrag), dim3(DF_NT), sizeof(double) * (size_t)(bv.naux + 8), s, bv);
+    hipLaunchKernelGGL(df_metric_eig_kernel, dim3(bv.nfrag), dim3(DF_NT), 0, s, bv);      // flagged fragments only
+    {
+        const int jobs = ((bv.naux + 15) / 16) * ((bv.npair + 15) / 16);
+        int gx = (jobs + DF_NT / 64 - 1) / (DF_NT / 64);
+        if (gx > 1024) gx = 1024;
+        hipLaunchKernelGGL(df_fit_mfma_kernel, dim3(gx, bv.nfrag), dim3(DF_NT), 0, s, bv);
+    }
 }
 
 size_t df_k_lds_bytes(int n, int o, bool blds) { return sizeof(double) * ((blds ? (size_t)n * (n + 1) : 0) + (size_t)n * o + (size_t)n * (o + 1) + 8); }

@@ -289,6 +289,15 @@ void launch_eri_bounds(const BatchView& bv, const Topology& topo, double schwarz
     SCHWARZ_CASE(2, 2) SCHWARZ_CASE(0, 0) SCHWARZ_CASE(2, 1) SCHWARZ_CASE(1, 1)
     SCHWARZ_CASE(1, 0) SCHWARZ_CASE(2, 0)
 #undef SCHWARZ_CASE
+    for (int a = CLASS_LMAX + 1; a <= KERNEL_LMAX; ++a)
+        for (int b = 0; b <= a; ++b) {
+            auto& bk = st.bucket[a][b];
+            if (bk.empty()) continue;
+            hipStream_t ss = st.side[rr++ % ERI_SIDE_STREAMS];
+            (void)hipMemcpyAsync(d_pairs + off, bk.data(), bk.size() * sizeof(int), hipMemcpyHostToDevice, ss);
+            launch_schwarz_general(bv, a, b, d_pairs + off, (int)bk.size() / 2, Q, ss);
+            off += bk.size();
+        }
     if (bv.eri) (void)hipMemsetAsync(bv.eri, 0, sizeof(double) * np * np * bv.nfrag, st.side[ERI_SIDE_STREAMS - 1]);
     for (int k = 0; k < ERI_SIDE_STREAMS; ++k) (void)hipEventRecord(st.join[k], st.side[k]);
     st.bounds_pending = true;
@@ -443,8 +452,14 @@ void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, h
     }
     int li = 0;
     auto dense_stream = [&]() { if (!spread) return s; const int k = lane_of[li]; return k == 0 ? s : st.side[k - 1]; };
+    // MQC_HIP_ERI_GENERAL=k: classes whose total angular momentum is >= k AND that would take the pass kernels go
+    // through the wave-cooperative LDS kernel instead (no scratch, one wave per quartet and fragment); default: off
+    static const int gen_from = [] { const char* e = std::getenv("MQC_HIP_ERI_GENERAL"); return e ? std::atoi(e) : 99; }();
+    auto to_general = [&](const Topology::ClassList& c) {
+        return c.la > CLASS_LMAX || (eri_uses_passes(c.la, c.lb, c.lc, c.ld) && c.la + c.lb + c.lc + c.ld >= gen_from);
+    };
 #define ERI_CASE(a, b, c, d_)                                                                                         \
-    if (cl.la == a && cl.lb == b && cl.lc == c && cl.ld == d_) {                                                      \
+    if (!general && cl.la == a && cl.lb == b && cl.lc == c && cl.ld == d_) {                                          \
         launch_eri_class<a, b, c, d_>(bv, d + L.dense_off, L.dense_n, nullptr, 0, Q, thresh, dense_stream());         \
         launch_eri_class<a, b, c, d_>(bv, d + L.sh_off, L.sh_n, d + L.task_off, L.ntasks, Q, thresh, st.side[rr++ % ERI_SIDE_STREAMS]); \
     }
@@ -461,6 +476,7 @@ void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, h
         li = order[oi];
         const EriLaunch& L = cc->launches[li];
         const auto& cl = topo.classes[L.cls];
+        const bool general = to_general(cl);
         if (L.twin) {
             TWIN_CASE(0, 0, 0, 0) TWIN_CASE(1, 0, 0, 0) TWIN_CASE(1, 0, 1, 0) TWIN_CASE(1, 1, 0, 0)
             TWIN_CASE(1, 1, 1, 0) TWIN_CASE(2, 0, 0, 0) TWIN_CASE(2, 0, 1, 0) TWIN_CASE(2, 1, 0, 0)
@@ -473,6 +489,11 @@ void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, h
         ERI_CASE(2, 1, 0, 0) ERI_CASE(2, 1, 1, 0) ERI_CASE(2, 1, 1, 1) ERI_CASE(2, 1, 2, 0) ERI_CASE(2, 1, 2, 1)
         ERI_CASE(2, 2, 0, 0) ERI_CASE(2, 2, 1, 0) ERI_CASE(2, 2, 1, 1) ERI_CASE(2, 2, 2, 0) ERI_CASE(2, 2, 2, 1)
         ERI_CASE(2, 2, 2, 2)
+        if (general) {
+            // a class with an f shell (or a d-heavy class routed here): the wave-cooperative LDS kernel
+            launch_eri_general(bv, cl.la, cl.lb, cl.lc, cl.ld, d + L.dense_off, L.dense_n, nullptr, 0, Q, thresh, dense_stream());
+            launch_eri_general(bv, cl.la, cl.lb, cl.lc, cl.ld, d + L.sh_off, L.sh_n, d + L.task_off, L.ntasks, Q, thresh, st.side[rr++ % ERI_SIDE_STREAMS]);
+        }
     }
 #undef ERI_CASE
 #undef TWIN_CASE

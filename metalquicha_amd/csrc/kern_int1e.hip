@@ -292,6 +292,10 @@ void launch_int1e(const BatchView& bv, const Topology& topo, hipStream_t s)
     launch_class<2, 0>(bv, bucket[2][0], scratch, s);
     launch_class<2, 1>(bv, bucket[2][1], scratch, s);
     launch_class<2, 2>(bv, bucket[2][2], scratch, s);
+    launch_class<3, 0>(bv, bucket[3][0], scratch, s);
+    launch_class<3, 1>(bv, bucket[3][1], scratch, s);
+    launch_class<3, 2>(bv, bucket[3][2], scratch, s);
+    launch_class<3, 3>(bv, bucket[3][3], scratch, s);
 }
 
 }  // namespace mqc

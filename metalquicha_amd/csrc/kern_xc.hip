@@ -229,7 +229,7 @@ constexpr int XC_NT = 256;
 template <bool GGA>
 __device__ __forceinline__ void emit_shell(int l, int ao, double dx, double dy, double dz, double rad, double drad,
                                            double* __restrict__ chi, double* __restrict__ gx, double* __restrict__ gy,
-                                           double* __restrict__ gz, int ptp, int p)
+                                           double* __restrict__ gz, int ptp, int p, const double* __restrict__ c2s)
 {
     if (l == 0) {
         chi[ao * ptp + p] = rad;
@@ -240,6 +240,34 @@ __device__ __forceinline__ void emit_shell(int l, int ao, double dx, double dy, 
             gx[ao * ptp + p] = rad + dx * dx * drad; gy[ao * ptp + p] = dx * dy * drad; gz[ao * ptp + p] = dx * dz * drad;
             gx[(ao + 1) * ptp + p] = dy * dx * drad; gy[(ao + 1) * ptp + p] = rad + dy * dy * drad; gz[(ao + 1) * ptp + p] = dy * dz * drad;
             gx[(ao + 2) * ptp + p] = dz * dx * drad; gy[(ao + 2) * ptp + p] = dz * dy * drad; gz[(ao + 2) * ptp + p] = rad + dz * dz * drad;
+        }
+    } else if (l >= 3) {
+        // l = 3, 4: Cartesian monomials x^a y^b z^c in libcint order, transformed with the packed c2s table
+        const int nc = ncart(l), nsp = nsph(l);
+        auto ipow = [](double x, int k) { double r = 1.0; for (int i = 0; i < k; ++i) r *= x; return r; };   // k <= 4, no arrays (no scratch)
+        const double* tab = c2s + c2s_table_offset(l);
+        for (int m = 0; m < nsp; ++m) {
+            double v = 0.0, ax = 0.0, ay = 0.0, az = 0.0;
+            int k = 0;
+            for (int a = l; a >= 0; --a)
+                for (int b = l - a; b >= 0; --b, ++k) {
+                    const int c = l - a - b;
+                    const double w = tab[m * nc + k];
+                    if (w == 0.0) continue;
+                    const double xa = ipow(dx, a), yb = ipow(dy, b), zc = ipow(dz, c);
+                    v += w * xa * yb * zc;
+                    if (GGA) {
+                        if (a) ax += w * a * ipow(dx, a - 1) * yb * zc;
+                        if (b) ay += w * b * xa * ipow(dy, b - 1) * zc;
+                        if (c) az += w * c * xa * yb * ipow(dz, c - 1);
+                    }
+                }
+            chi[(ao + m) * ptp + p] = v * rad;
+            if (GGA) {
+                gx[(ao + m) * ptp + p] = ax * rad + v * dx * drad;
+                gy[(ao + m) * ptp + p] = ay * rad + v * dy * drad;
+                gz[(ao + m) * ptp + p] = az * rad + v * dz * drad;
+            }
         }
     } else {
         // l = 2: Cartesian xx,xy,xz,yy,yz,zz -> libcint's xy,yz,z2,xz,x2-y2
@@ -270,7 +298,7 @@ __device__ __forceinline__ void emit_shell(int l, int ao, double dx, double dy, 
 template <bool GGA>
 __device__ __forceinline__ void eval_group(const TopologyDev& tp, const double* __restrict__ xyz, int g, double px, double py, double pz,
                                            double* __restrict__ chi, double* __restrict__ gx, double* __restrict__ gy,
-                                           double* __restrict__ gz, int ptp, int p)
+                                           double* __restrict__ gz, int ptp, int p, const double* __restrict__ c2s)
 {
     const int sh0 = tp.grp_first[g], nc = tp.grp_count[g], np = tp.grp_nprim[g];
     const int l = tp.sh_l[sh0], at = tp.sh_atom[sh0];
@@ -296,7 +324,7 @@ __device__ __forceinline__ void eval_group(const TopologyDev& tp, const double* 
     }
 #pragma unroll
     for (int k = 0; k < XC_GROUP_MAX; ++k)
-        if (k < nc) emit_shell<GGA>(l, tp.sh_aoff[sh0 + k], dx, dy, dz, rad[k], drad[k], chi, gx, gy, gz, ptp, p);
+        if (k < nc) emit_shell<GGA>(l, tp.sh_aoff[sh0 + k], dx, dy, dz, rad[k], drad[k], chi, gx, gy, gz, ptp, p, c2s);
 }
 
 // zero rows of a group for a point beyond the grid
@@ -357,7 +385,7 @@ __global__ void __launch_bounds__(XC_NT) xc_kernel(BatchView bv, int only_active
             if (g < gd.npts) {
                 const int oa = gd.pt_atom[g], it = gd.pt_tmpl[g];
                 eval_group<GGA>(tp, xyz, rg, xyz[3 * oa] + gd.tmpl_xyz[3 * it], xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1],
-                                xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2], chi, gx, gy, gz, PTP, p);
+                                xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2], chi, gx, gy, gz, PTP, p, bv.c2s);
             } else {
                 zero_group<GGA>(tp, rg, chi, gx, gy, gz, PTP, p);
             }
@@ -494,7 +522,7 @@ __global__ void __launch_bounds__(64 * XM_NW) xc_mfma_kernel(BatchView bv, int o
             if (g < gd.npts) {
                 const int oa = gd.pt_atom[g], it = gd.pt_tmpl[g];
                 eval_group<GGA>(tp, xyz, rg, xyz[3 * oa] + gd.tmpl_xyz[3 * it], xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1],
-                                xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2], chi, gx, gy, gz, XM_RS, p);
+                                xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2], chi, gx, gy, gz, XM_RS, p, bv.c2s);
             } else {
                 zero_group<GGA>(tp, rg, chi, gx, gy, gz, XM_RS, p);
             }
@@ -625,10 +653,14 @@ constexpr int XV_NW = 4;
 template <bool GGA, int PT, int JMAX, int OCC>
 __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, int only_active)
 {
+    // A SUPER-TILE is 256 points = one per thread.  Pass 1 walks its sub-tiles of PT points (AO slab, X = D chi,
+    // rho / grad rho into LDS), then ALL 256 threads evaluate the functional, one point each -- at full lane and
+    // wave utilisation instead of PT lanes of one wave while three waves wait (that serial section was half of a
+    // tile's critical path) -- and pass 2 walks the sub-tiles again (AO slab rebuilt, a = ..., A += a chi^T).
     extern __shared__ double lds[];
     const int f = blockIdx.y;
     if (only_active && bv.istate[4 * f] == ST_DONE) return;
-    constexpr int RS = PT + 1, PT16 = PT / 16;
+    constexpr int RS = PT + 1, PT16 = PT / 16, SUPER = 64 * XV_NW, NSUB = SUPER / PT;
     const int n = bv.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lo = lane & 15, hi = lane >> 4;
     const int NT16 = (n + 15) >> 4, NP = NT16 << 4, KS = NP >> 2;
@@ -638,72 +670,81 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
     double* gx = chi + (size_t)NP * RS;                       // GGA: grad chi, x then overwritten by a;  LDA: a
     double* gy = gx + (size_t)NP * RS;
     double* gz = gy + (GGA ? (size_t)NP * RS : 0);
-    double* red = gz + (GGA ? (size_t)NP * RS : 0);           // [PT][4] rho, grad rho partial sums
-    double* coef = red + 4 * PT;                              // [PT][4] w v_rho / 2, 2 w v_sigma grad rho
+    double* red = gz + (GGA ? (size_t)NP * RS : 0);           // [SUPER][4] rho, grad rho sums of the super-tile
+    double* coef = red + 4 * SUPER;                           // [SUPER][4] w v_rho / 2, 2 w v_sigma grad rho
     const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
     const double* __restrict__ D = bv.D + (size_t)f * n * n;
     const double* __restrict__ wts = gd.weights + (size_t)f * gd.npts;
 
     // rows n..NP-1 stay zero for the whole kernel; the sums start at zero
-    for (int idx = tid; idx < (GGA ? 4 : 2) * NP * RS + 8 * PT; idx += 64 * XV_NW) lds[idx] = 0.0;
+    for (int idx = tid; idx < (GGA ? 4 : 2) * NP * RS + 8 * SUPER; idx += SUPER) lds[idx] = 0.0;
     v4f64 vacc[JMAX];
 #pragma unroll
     for (int j = 0; j < JMAX; ++j) vacc[j] = (v4f64){0.0, 0.0, 0.0, 0.0};
     double e_acc = 0.0, n_acc = 0.0;
     __syncthreads();
 
-    const int ntiles = (gd.npts + PT - 1) / PT;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int g0 = tile * PT;
-        // 1. AO values (and gradients) of the tile: (radial group, point) items, point fastest
-        for (int idx = tid; idx < tp.ngroup * PT; idx += 64 * XV_NW) {
+    auto ao_slab = [&](int g0) {
+        // AO values (and gradients) of PT points: (radial group, point) items, point fastest
+        for (int idx = tid; idx < tp.ngroup * PT; idx += SUPER) {
             const int rg = idx / PT, p = idx - rg * PT;
             const int g = g0 + p;
             if (g < gd.npts) {
                 const int oa = gd.pt_atom[g], it = gd.pt_tmpl[g];
                 eval_group<GGA>(tp, xyz, rg, xyz[3 * oa] + gd.tmpl_xyz[3 * it], xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1],
-                                xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2], chi, gx, gy, gz, RS, p);
+                                xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2], chi, gx, gy, gz, RS, p, bv.c2s);
             } else {
                 zero_group<GGA>(tp, rg, chi, gx, gy, gz, RS, p);
             }
         }
-        __syncthreads();
-        // 2. X = D chi, job = (row tile mt, point tile pt); rho and grad rho from the accumulator rows
-        for (int job = wave; job < NT16 * PT16; job += XV_NW) {
-            const int mt = job / PT16, pt = job - mt * PT16;
-            v4f64 xacc = (v4f64){0.0, 0.0, 0.0, 0.0};
-            const int mu_a = 16 * mt + lo;
-            const double* __restrict__ drow = D + (size_t)mu_a * n;
-            const bool row_ok = mu_a < n;
-            for (int ks = 0; ks < KS; ++ks) {
-                const int nu = 4 * ks + hi;
-                const double a = (row_ok && nu < n) ? drow[nu] : 0.0;
-                const double b = chi[nu * RS + 16 * pt + lo];
-                xacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, xacc, 0, 0, 0);
-            }
-            double rho = 0.0, rx = 0.0, ry = 0.0, rz = 0.0;
+    };
+
+    const int nsuper = (gd.npts + SUPER - 1) / SUPER;
+    for (int st = blockIdx.x; st < nsuper; st += gridDim.x) {
+        const int s0 = st * SUPER;
+        // ---- pass 1: densities of the 256 points
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const int g0 = s0 + sub * PT;
+            if (g0 >= gd.npts) break;
+            ao_slab(g0);
+            __syncthreads();
+            // X = D chi, job = (row tile mt, point tile pt); rho and grad rho from the accumulator rows
+            for (int job = wave; job < NT16 * PT16; job += XV_NW) {
+                const int mt = job / PT16, pt = job - mt * PT16;
+                v4f64 xacc = (v4f64){0.0, 0.0, 0.0, 0.0};
+                const int mu_a = 16 * mt + lo;
+                const double* __restrict__ drow = D + (size_t)mu_a * n;
+                const bool row_ok = mu_a < n;
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int nu = 4 * ks + hi;
+                    const double a = (row_ok && nu < n) ? drow[nu] : 0.0;
+                    const double b = chi[nu * RS + 16 * pt + lo];
+                    xacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, xacc, 0, 0, 0);
+                }
+                double rho = 0.0, rx = 0.0, ry = 0.0, rz = 0.0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = (16 * mt + hi + 4 * r) * RS + 16 * pt + lo;
-                const double x = xacc[r];
-                rho += x * chi[o];
-                if (GGA) { rx += x * gx[o]; ry += x * gy[o]; rz += x * gz[o]; }
+                for (int r = 0; r < 4; ++r) {
+                    const int o = (16 * mt + hi + 4 * r) * RS + 16 * pt + lo;
+                    const double x = xacc[r];
+                    rho += x * chi[o];
+                    if (GGA) { rx += x * gx[o]; ry += x * gy[o]; rz += x * gz[o]; }
+                }
+                rho += __shfl_xor(rho, 16, 64); rho += __shfl_xor(rho, 32, 64);
+                if (GGA) {
+                    rx += __shfl_xor(rx, 16, 64); rx += __shfl_xor(rx, 32, 64);
+                    ry += __shfl_xor(ry, 16, 64); ry += __shfl_xor(ry, 32, 64);
+                    rz += __shfl_xor(rz, 16, 64); rz += __shfl_xor(rz, 32, 64);
+                }
+                if (hi == 0) {
+                    double* rp = red + 4 * (sub * PT + 16 * pt + lo);
+                    atomicAdd(&rp[0], rho);
+                    if (GGA) { atomicAdd(&rp[1], rx); atomicAdd(&rp[2], ry); atomicAdd(&rp[3], rz); }
+                }
             }
-            rho += __shfl_xor(rho, 16, 64); rho += __shfl_xor(rho, 32, 64);
-            if (GGA) {
-                rx += __shfl_xor(rx, 16, 64); rx += __shfl_xor(rx, 32, 64);
-                ry += __shfl_xor(ry, 16, 64); ry += __shfl_xor(ry, 32, 64);
-                rz += __shfl_xor(rz, 16, 64); rz += __shfl_xor(rz, 32, 64);
-            }
-            if (hi == 0) {
-                double* rp = red + 4 * (16 * pt + lo);
-                atomicAdd(&rp[0], rho);
-                if (GGA) { atomicAdd(&rp[1], rx); atomicAdd(&rp[2], ry); atomicAdd(&rp[3], rz); }
-            }
+            __syncthreads();
         }
-        __syncthreads();
-        // 3. the functional, one lane per point
-        if (tid < PT) {
+        // ---- the functional: thread = point
+        {
             const int p = tid;
             double* rp = red + 4 * p;
             const double rho = rp[0], rx = 2.0 * rp[1], ry = 2.0 * rp[2], rz = 2.0 * rp[3];
@@ -711,7 +752,7 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
             const double sigma = GGA ? rx * rx + ry * ry + rz * rz : 0.0;
             double fx, vr, vs;
             eval_functional(bv.xc, rho, sigma, fx, vr, vs);
-            const double w = (g0 + p < gd.npts) ? wts[g0 + p] : 0.0;
+            const double w = (s0 + p < gd.npts) ? wts[s0 + p] : 0.0;
             e_acc += w * fx;
             n_acc += w * rho;
             double* cp = coef + 4 * p;
@@ -719,27 +760,34 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
             const double t2 = 2.0 * w * vs;
             cp[1] = t2 * rx; cp[2] = t2 * ry; cp[3] = t2 * rz;
         }
-        __syncthreads();
-        // 4. a[mu][p] = w v_rho / 2 chi + 2 w v_sigma grad rho . grad chi, written over gx
-        for (int idx = tid; idx < n * PT; idx += 64 * XV_NW) {
-            const int mu = idx / PT, p = idx - mu * PT;
-            const int o = mu * RS + p;
-            const double* cp = coef + 4 * p;
-            double a = cp[0] * chi[o];
-            if (GGA) a += cp[1] * gx[o] + cp[2] * gy[o] + cp[3] * gz[o];
-            gx[o] = a;
-        }
-        __syncthreads();
-        // 5. A += a chi^T: this wave's tiles t = wave, wave + XV_NW, ...
+        // ---- pass 2: a and the accumulation
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const int g0 = s0 + sub * PT;
+            if (g0 >= gd.npts) break;
+            __syncthreads();          // coef written / the previous sub-tile's MFMA reads are done
+            ao_slab(g0);
+            __syncthreads();
+            // a[mu][p] = w v_rho / 2 chi + 2 w v_sigma grad rho . grad chi, written over gx
+            for (int idx = tid; idx < n * PT; idx += SUPER) {
+                const int mu = idx / PT, p = idx - mu * PT;
+                const int o = mu * RS + p;
+                const double* cp = coef + 4 * (sub * PT + p);
+                double a = cp[0] * chi[o];
+                if (GGA) a += cp[1] * gx[o] + cp[2] * gy[o] + cp[3] * gz[o];
+                gx[o] = a;
+            }
+            __syncthreads();
+            // A += a chi^T: this wave's tiles t = wave, wave + XV_NW, ...
 #pragma unroll
-        for (int j = 0; j < JMAX; ++j) {
-            const int t = wave + XV_NW * j;
-            if (t < NT16 * NT16) {
-                const int mt = t / NT16, nt = t - mt * NT16;
-                const double* __restrict__ ar = gx + (size_t)(16 * mt + lo) * RS + hi;
-                const double* __restrict__ br = chi + (size_t)(16 * nt + lo) * RS + hi;
+            for (int j = 0; j < JMAX; ++j) {
+                const int t = wave + XV_NW * j;
+                if (t < NT16 * NT16) {
+                    const int mt = t / NT16, nt = t - mt * NT16;
+                    const double* __restrict__ ar = gx + (size_t)(16 * mt + lo) * RS + hi;
+                    const double* __restrict__ br = chi + (size_t)(16 * nt + lo) * RS + hi;
 #pragma unroll
-                for (int ks = 0; ks < PT / 4; ++ks) vacc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[4 * ks], br[4 * ks], vacc[j], 0, 0, 0);
+                    for (int ks = 0; ks < PT / 4; ++ks) vacc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[4 * ks], br[4 * ks], vacc[j], 0, 0, 0);
+                }
             }
         }
         __syncthreads();
@@ -759,13 +807,12 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
             }
         }
     }
-    if (wave == 0) {
+    // E_xc and N_e: every thread holds partial sums
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { e_acc += __shfl_down(e_acc, off, 64); n_acc += __shfl_down(n_acc, off, 64); }
-        if (lane == 0) {
-            atomicAdd(&bv.scal[(size_t)f * 8 + 5], e_acc);
-            atomicAdd(&bv.scal[(size_t)f * 8 + 6], n_acc);
-        }
+    for (int off = 32; off > 0; off >>= 1) { e_acc += __shfl_down(e_acc, off, 64); n_acc += __shfl_down(n_acc, off, 64); }
+    if (lane == 0) {
+        atomicAdd(&bv.scal[(size_t)f * 8 + 5], e_acc);
+        atomicAdd(&bv.scal[(size_t)f * 8 + 6], n_acc);
     }
 }
 
@@ -773,10 +820,10 @@ template <bool GGA, int PT, int JMAX, int OCC>
 static void xc_tile_launch(const BatchView& bv, int oa, hipStream_t s)
 {
     const int np = ((bv.n + 15) / 16) * 16;
-    const size_t lds = sizeof(double) * ((size_t)(GGA ? 4 : 2) * np * (PT + 1) + 8 * PT);
+    const size_t lds = sizeof(double) * ((size_t)(GGA ? 4 : 2) * np * (PT + 1) + 8 * 64 * XV_NW);
     auto kern = xc_tile_kernel<GGA, PT, JMAX, OCC>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int ntiles = (bv.grid.npts + PT - 1) / PT;
+    const int ntiles = (bv.grid.npts + 64 * XV_NW - 1) / (64 * XV_NW);      // super-tiles of 256 points
     int gx = (6144 + bv.nfrag - 1) / bv.nfrag;       // ~3 workgroups per CU x 8 in flight over the batch; many tiles each
     if (gx > ntiles) gx = ntiles;
     if (gx < 1) gx = 1;

@@ -1,14 +1,15 @@
 """Stage-level entry points of the C ABI (mqc_hip_int1e, _eri_packed, _jk_incore, _syev,
 _diis_coefficients) as numpy-in / numpy-out functions.  They run the same kernels the SCF
-driver launches and exist so that each row of the hot-path table can be parity-tested alone."""
+driver launches and exist so that each row of the hot-path table can be parity-tested alone.
+Test infrastructure: a ctypes helper for tests/, not part of the product package."""
 from __future__ import annotations
 
 import ctypes as C
 
 import numpy as np
 
-from . import capi
-from .methods import PhysicalFragment, _Marshalled, _flat_basis
+from metalquicha_amd import capi
+from metalquicha_amd.methods import PhysicalFragment, _Marshalled, _flat_basis
 
 
 def _marshal(basis_set: str, fragment: PhysicalFragment):

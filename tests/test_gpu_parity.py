@@ -7,7 +7,8 @@ Tolerances: the reference's own direct-vs-in-core bound is 1e-11 elementwise
 import numpy as np
 import pytest
 
-from metalquicha_amd import methods, stages
+from metalquicha_amd import methods
+from tests import stages
 from oracle import scf_oracle as so
 from tests.helpers import fragment_bohr, oracle_mol, water_at, synthetic_density
 
@@ -147,6 +148,45 @@ def test_water_dimer_ccpvdz_matches_oracle():
     o = so.run_rhf(oracle_mol("cc-pvdz", frag), 20, 100, 1e-10, 1e-8)
     assert abs(r.energy.scf - o.energy) < 1e-8
     assert r.scf_iterations == o.iterations
+
+
+# ---- f shells: the wave-cooperative general kernel (def2-TZVP, BASELINE.json configs[3]) --------------------------
+def test_def2_tzvp_stage_integrals_match_oracle():
+    """def2-TZVP water (n = 43, one f shell on O): S, T, V and the packed ERI tensor against the oracle -- every class
+    with an f shell goes through kern_eri_general.hip, the s/p/d classes through the register kernels."""
+    frag = fragment_bohr(*WATER)
+    mol = oracle_mol("def2-tzvp", frag)
+    assert mol.nao == 43 and int(np.max(mol.sh_l)) == 3
+    S, T, V = stages.int1e("def2-tzvp", frag)
+    So, To, Vo = so.int1e(mol)
+    assert np.max(np.abs(S - So)) < 1e-12
+    assert np.max(np.abs(T - To)) < 1e-10
+    assert np.max(np.abs(V - Vo)) < 1e-10
+    M = stages.eri_packed("def2-tzvp", frag)
+    ref = stages.pack_eri(so.eri4(mol))
+    assert not np.any(np.isnan(M))                 # the stage entry poisons the tensor first: every element was written
+    assert np.max(np.abs(M - ref)) < 1e-11
+    assert np.max(np.abs(M - M.T)) == 0.0
+    scr = stages.eri_packed("def2-tzvp", frag, schwarz_tol=1e-12)
+    assert np.max(np.abs(scr - ref)) < 1e-11
+
+
+def test_def2_tzvp_water_dimer_batch_matches_oracle():
+    """A configs[3]-shaped batch: def2-TZVP monomers (n = 43) and a dimer (n = 86) in one call, RHF and B3LYP
+    (XC grid kernel with f functions), against the oracle."""
+    rng = np.random.default_rng(86)
+    ws = [water_at(rng, c) for c in ([0, 0, 0], [5.5, 0.3, -0.2])]
+    frags = [fragment_bohr([8, 1, 1], ws[0]), fragment_bohr([8, 1, 1], ws[1]), fragment_bohr([8, 1, 1, 8, 1, 1], np.vstack(ws))]
+    for fn in ("", "b3lyp"):
+        st = methods.ScfSettings(basis_set="def2-tzvp", functional=fn, energy_tol=1e-9, density_tol=1e-7, guess="gwh")
+        res = methods.run_hip_scf_batch(st, frags)
+        for f, r in zip(frags[1:], res[1:]):
+            assert not r.has_error, r.error_message
+            mol = oracle_mol("def2-tzvp", f)
+            xc = xc_oracle.XCOracle(mol, fn, 3) if fn else None
+            o = so.run_rhf(mol, int(f.nelec), 100, 1e-9, 1e-7, xc=xc)
+            assert abs(r.energy.scf - o.energy) < 1e-8, (fn, r.energy.scf, o.energy)
+            assert r.scf_iterations == o.iterations
 
 
 def test_refusals_match_reference_behaviour():
@@ -349,6 +389,35 @@ def test_df_rhf_with_the_orbital_basis_as_auxiliary_basis_matches_pinned_oracle(
     exact = methods.run_hip_scf(methods.ScfSettings(basis_set="6-31g", energy_tol=1e-10, density_tol=1e-8, guess="gwh"), frag)
     assert abs(exact.energy.scf - (-75.984779843967)) < 1e-9            # manifest row RHF H2O 6-31g
     assert abs(r.energy.scf - exact.energy.scf) > 1e-3                   # a fit in a basis this small is far off
+
+
+def test_df_near_singular_metric_takes_the_reference_eigen_cut(tmp_path, monkeypatch):
+    """An auxiliary basis with a (numerically) duplicated shell: the metric (P|Q) has an eigenvalue far below the
+    reference's 1e-10 cut (metric_inverse_sqrt, mqc_libcint_integrals.F90:992-1038).  The engine's Cholesky fit flags
+    the fragment (pivot / ||L^-1||_F bound), the Jacobi eigen path builds J^{-1/2} over the kept eigenvalues, and the
+    energy equals the oracle's (numpy eigh with the same cut) -- and the energy without the duplicate."""
+    import json, os
+    from metalquicha_amd import basis as basis_mod
+    src = json.load(open(basis_mod.find_basis_file(AUX)))
+    dup = json.loads(json.dumps(src))
+    sh = json.loads(json.dumps(dup["elements"]["8"]["electron_shells"][0]))
+    sh["exponents"] = ["%.16E" % (float(e) * (1.0 + 1.0e-9)) for e in sh["exponents"]]
+    dup["elements"]["8"]["electron_shells"].append(sh)
+    with open(tmp_path / "mqc-dup-jkfit.json", "w") as f:
+        json.dump(dup, f)
+    monkeypatch.setenv("MQC_BASIS_PATH", str(tmp_path))
+    frag = fragment_bohr(*WATER)
+    kw = dict(basis_set="cc-pvdz", density_fitting=True, energy_tol=1e-10, density_tol=1e-8, guess="gwh")
+    r = methods.run_hip_scf(methods.ScfSettings(aux_basis_set="mqc-dup-jkfit", **kw), frag)
+    assert not r.has_error, r.error_message
+    mol = oracle_mol("cc-pvdz", frag)
+    aux = oracle_mol("mqc-dup-jkfit", frag)
+    w = np.linalg.eigvalsh(so.eri2c(aux))
+    assert w[0] < 1e-10 < w[1] * 1e3            # exactly the duplicated direction is (numerically) null
+    o = so.run_rhf(mol, 10, 100, 1e-10, 1e-8, aux=aux)
+    assert abs(r.energy.scf - o.energy) < 1e-8, (r.energy.scf, o.energy)
+    clean = methods.run_hip_scf(methods.ScfSettings(aux_basis_set=AUX, **kw), frag)
+    assert abs(r.energy.scf - clean.energy.scf) < 1e-7      # the duplicate adds nothing to the fit
 
 
 def test_cartesian_basis_is_refused_like_the_cuest_driver_does():

@@ -148,7 +148,7 @@ def test_device_twin_block_equals_segmented_blocks(hostcheck, cls):
 def test_topology_twin_cut_covers_every_quartet_once(hostcheck, zs, basis, expect_twins):
     """cc-pVDZ C/N/O: the 1s/2s functions are twins (same 9 primitives).  Twin entries expanded over their
     members plus the uncovered rest must be exactly the canonical quartet set of each class, nothing twice."""
-    from metalquicha_amd import stages
+    from tests import stages
     from tests.helpers import fragment_bohr
     rng = np.random.default_rng(3)
     frag = fragment_bohr(zs, rng.uniform(-3, 3, size=(len(zs), 3)))
