@@ -18,6 +18,7 @@
 
 namespace mqc {
 const std::string& last_error_string();
+void eri_plan_lists(const BatchView& bv, const Topology& topo, hipStream_t s, const double* host_xyz);   // kern_eri.hip
 
 static int stage_check(const char* stage)
 {
@@ -128,10 +129,11 @@ static int upload_topology(mqc_hip_context* ctx, const Topology& topo, TopologyD
     return MQC_HIP_OK;
 }
 
-static size_t per_fragment_main_doubles(int n, int natoms)
+static size_t per_fragment_main_doubles(int n, int natoms, bool uhf = false)
 {
     const size_t nn = (size_t)n * n;
-    return 9 * nn      // S H X F D C J K Vprev
+    return (uhf ? 6 * nn + 2 * DIIS_MAX * nn + n : 0)   // beta spin: D C F J K Vprev, DIIS histories, eps
+           + 9 * nn    // S H X F D C J K Vprev
            + 6 * nn    // W
            + 2 * DIIS_MAX * nn   // DIIS histories
            + DIIS_MAX * DIIS_MAX + n + 8 + 3 * (size_t)natoms + 8 + 4;   // diis_b, eps, scal, xyz, ints (padded), dipole
@@ -150,11 +152,12 @@ struct Slot {
 };
 
 // carve one chunk's arrays out of the slot's pools
-static int carve_batch(mqc_hip_context* ctx, Slot& sl, const Topology& topo, const TopologyDev& td, int nfrag, bool with_eri, BatchView& bv)
+static int carve_batch(mqc_hip_context* ctx, Slot& sl, const Topology& topo, const TopologyDev& td, int nfrag, bool with_eri, BatchView& bv,
+                       bool uhf = false)
 {
     const int n = topo.nao;
     const size_t nn = (size_t)n * n, nf = (size_t)nfrag;
-    const size_t main_bytes = sizeof(double) * nf * per_fragment_main_doubles(n, topo.natoms) + 8192;
+    const size_t main_bytes = sizeof(double) * nf * per_fragment_main_doubles(n, topo.natoms, uhf) + 16384;
     char* base = (char*)sl.main->ensure(main_bytes);
     if (!base) return fail(MQC_HIP_ERR_DEVICE, "out of device memory (SCF matrices)");
     auto take = [&base](size_t b) { char* p = base; base += (b + 255) & ~size_t(255); return p; };
@@ -173,6 +176,16 @@ static int carve_batch(mqc_hip_context* ctx, Slot& sl, const Topology& topo, con
     bv.eps = (double*)take(sizeof(double) * nf * n);
     bv.scal = (double*)take(sizeof(double) * nf * 8);
     bv.dip = (double*)take(sizeof(double) * nf * 4);
+    bv.uhf = uhf ? 1 : 0; bv.nalpha = 0; bv.nbeta = 0;
+    bv.Db = bv.Cb = bv.Fb = bv.Jb = bv.Kb = bv.Vprevb = bv.epsb = bv.diis_fb = bv.diis_eb = nullptr;
+    if (uhf) {
+        bv.Db = (double*)take(sizeof(double) * nf * nn); bv.Cb = (double*)take(sizeof(double) * nf * nn);
+        bv.Fb = (double*)take(sizeof(double) * nf * nn); bv.Jb = (double*)take(sizeof(double) * nf * nn);
+        bv.Kb = (double*)take(sizeof(double) * nf * nn); bv.Vprevb = (double*)take(sizeof(double) * nf * nn);
+        bv.diis_fb = (double*)take(sizeof(double) * nf * DIIS_MAX * nn);
+        bv.diis_eb = (double*)take(sizeof(double) * nf * DIIS_MAX * nn);
+        bv.epsb = (double*)take(sizeof(double) * nf * n);
+    }
     bv.diis_state = (int*)take(sizeof(int) * nf * 2);
     bv.istate = (int*)take(sizeof(int) * nf * 4);
     bv.counters = (int*)sl.misc->ensure(256);
@@ -202,11 +215,21 @@ static int validate_options(const mqc_hip_scf_options_t& o, const Topology& topo
         if (tmp.ncomp > 0 && topo.natoms > 64) { msg = "XC grid: fragments above 64 atoms are not supported yet"; return MQC_HIP_ERR_UNSUPPORTED; }
     }
     if (o.want_gradient) { msg = "analytic gradients are not available in this build of the HIP backend"; return MQC_HIP_ERR_UNSUPPORTED; }
-    if (o.unrestricted || topo.multiplicity != 1 || (topo.nelec % 2) != 0) {
-        msg = "the HIP backend runs restricted closed-shell SCF only (multiplicity 1, even electron count)";
-        return MQC_HIP_ERR_UNSUPPORTED;
-    }
-    if (topo.nelec < 2) { msg = "RHF: no electrons to place"; return MQC_HIP_ERR_VALIDATION; }
+    // restricted iff multiplicity 1, even electron count and not forced (mqc_cuest_driver.f90:127)
+    const bool uhf = o.unrestricted || topo.multiplicity != 1 || (topo.nelec % 2) != 0;
+    if (uhf) {
+        // the occupation checks of run_libcint_uhf (mqc_libcint_rhf.f90:768-793)
+        if (topo.multiplicity < 1) { msg = "UHF: multiplicity must be at least 1"; return MQC_HIP_ERR_VALIDATION; }
+        if ((topo.nelec + topo.multiplicity - 1) % 2 != 0) { msg = "UHF: an electron count and multiplicity that cannot be paired -- their parities disagree"; return MQC_HIP_ERR_VALIDATION; }
+        const int na = (topo.nelec + topo.multiplicity - 1) / 2, nb = topo.nelec - na;
+        if (nb < 0 || na < 0) { msg = "UHF: multiplicity asks for more unpaired electrons than the system has"; return MQC_HIP_ERR_VALIDATION; }
+        if (na < 1) { msg = "UHF: no electrons to place"; return MQC_HIP_ERR_VALIDATION; }
+        XcSpec tmp; std::string e;
+        parse_functional(o.functional, tmp, e);
+        if (tmp.ncomp > 0) { msg = "unrestricted Kohn-Sham (spin-polarised functionals) is not available in this build of the HIP backend; unrestricted Hartree-Fock is"; return MQC_HIP_ERR_UNSUPPORTED; }
+        if (o.density_fitting) { msg = "UHF with density fitting is not available (the CPU reference refuses it too, mqc_libcint_bridge.f90:605-612)"; return MQC_HIP_ERR_UNSUPPORTED; }
+        if (o.eri_mode == MQC_HIP_ERI_DIRECT || !incore_supported(topo.nao)) { msg = "UHF runs on the in-core exact-ERI path (n_ao <= 116)"; return MQC_HIP_ERR_UNSUPPORTED; }
+    } else if (topo.nelec < 2) { msg = "RHF: no electrons to place"; return MQC_HIP_ERR_VALIDATION; }
     if (o.max_iter < 1) { msg = "max_iter must be positive"; return MQC_HIP_ERR_VALIDATION; }
     if (o.use_diis && (o.diis_size < 0 || o.diis_size > DIIS_MAX)) { msg = "diis_size must be within 0..8"; return MQC_HIP_ERR_VALIDATION; }
     if (!o.density_fitting && o.eri_mode == MQC_HIP_ERI_INCORE && !incore_supported(topo.nao)) { msg = "fragment too large for the in-core exact-ERI path (n_ao <= 116); use eri_mode auto/direct or density fitting"; return MQC_HIP_ERR_UNSUPPORTED; }
@@ -324,7 +347,8 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
     const int n = topo.nao;
     const size_t np = (size_t)topo.npair;
     const size_t two_e = use_df ? (2 * (size_t)naux * np + 3 * (size_t)naux * naux) : (use_direct ? 2 * (size_t)n * n : np * np);
-    const size_t per_frag = sizeof(double) * (per_fragment_main_doubles(n, topo.natoms) + two_e + (xc.ncomp > 0 ? (size_t)n * n + grid.npts : 0));
+    const bool uhf_mem = opts.unrestricted || topo.multiplicity != 1 || (topo.nelec % 2) != 0;
+    const size_t per_frag = sizeof(double) * (per_fragment_main_doubles(n, topo.natoms, uhf_mem) + two_e + (xc.ncomp > 0 ? (size_t)n * n + grid.npts : 0));
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     free_b += ctx->pool_main.capacity() + ctx->pool_eri.capacity() + ctx->pool_df.capacity() + ctx->pool_gridw.capacity()
@@ -346,7 +370,10 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
     if (chunk > ntot) chunk = ntot;
     if (chunk > 60000) chunk = 60000;    // grid.y limit of the J/K kernel
 
-    const int nocc = topo.nelec / 2;
+    const bool uhf = opts.unrestricted || topo.multiplicity != 1 || (topo.nelec % 2) != 0;
+    const int nalpha = uhf ? (topo.nelec + topo.multiplicity - 1) / 2 : topo.nelec / 2;
+    const int nbeta = uhf ? topo.nelec - nalpha : topo.nelec / 2;
+    const int nocc = uhf ? nalpha : topo.nelec / 2;
     int* h_counter = nullptr;
     HIP_CHECK_RET(hipHostMalloc((void**)&h_counter, 256));
     Slot slots[2] = {
@@ -377,8 +404,9 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         hipStream_t s = sl.s;
         const double t0 = now_s();
         BatchView& bv = job.bv;
-        int rc = carve_batch(ctx, sl, topo, td, nf, !use_df && !use_direct, bv);
+        int rc = carve_batch(ctx, sl, topo, td, nf, !use_df && !use_direct, bv, uhf);
         if (rc != MQC_HIP_OK) return rc;
+        bv.nalpha = nalpha; bv.nbeta = nbeta;
         bv.naux = naux; bv.aux = tdx; bv.unit = ctx->d_unit;
         if (use_df) {
             const size_t a3 = (size_t)nf * naux * np, mm = (size_t)nf * naux * naux;
@@ -407,6 +435,9 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
 
         if (!use_df && !use_direct) launch_eri_bounds(bv, topo, stol, s);     // screened build: bounds run next to the 1e stage
         launch_int1e(bv, topo, s);
+        // block-sharing plan and class lists of the integral stage: host work that depends on the geometry only, done
+        // here while the bounds and one-electron kernels run
+        if (!use_df && !use_direct) eri_plan_lists(bv, topo, s, job.hx.data());
         if ((rc = stage_check("int1e")) != MQC_HIP_OK) return rc;
         // The orthogonaliser and the starting guess need S and H only and are latency-bound (one workgroup per
         // fragment, Jacobi sweeps): they run on a side stream next to the compute-bound two-electron stage
@@ -455,7 +486,15 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
             HIP_CHECK_RET(hipEventRecord(sl.e0, s));
             if (use_df) launch_df_jk(bv, true, s);
             else if (use_direct) launch_jk_direct(bv, topo, direct_tol, true, s);
-            else launch_jk_incore(bv, true, s);
+            else {
+                launch_jk_incore(bv, true, s);
+                if (uhf) {
+                    // the same stream over the tensor with the beta density: J[D_b], K[D_b]
+                    BatchView vb = bv;
+                    vb.D = bv.Db; vb.J = bv.Jb; vb.K = bv.Kb;
+                    launch_jk_incore(vb, true, s);
+                }
+            }
             HIP_CHECK_RET(hipEventRecord(sl.e1, s));
             if (guard == 0 && (rc = stage_check("J/K build")) != MQC_HIP_OK) return rc;
             if (xc.ncomp > 0) {
@@ -477,7 +516,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
                 sx->stats.df_flops += (double)remaining * 4.0 * (double)naux * (double)n * (double)n * (1.0 + (xc.exx != 0.0 ? (double)nocc : 0.0));
             }
             const double launch_bytes = use_df ? (double)remaining * 2.0 * (double)naux * (double)np * 8.0
-                                               : (double)remaining * (double)np * (double)np * 8.0;
+                                               : (double)remaining * (double)np * (double)np * 8.0 * (uhf ? 2.0 : 1.0);
             sx->stats.fock_kernel_seconds += ms * 1e-3;
             sx->stats.fock_bytes += launch_bytes;
             sx->stats.fock_launches += 1;
@@ -502,6 +541,14 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         std::vector<int> ist((size_t)nf * 4);
         unsigned long long formed = 0;
         launch_dipole(bv, topo, s);
+        std::vector<double> epsb;
+        if (uhf) {
+            BatchView vb = bv;
+            vb.D = bv.Db;
+            launch_dipole(vb, topo, s, true);      // total density = D_a + D_b
+            epsb.resize((size_t)nf * n);
+            HIP_CHECK_RET(hipMemcpyAsync(epsb.data(), bv.epsb, sizeof(double) * epsb.size(), hipMemcpyDeviceToHost, s));
+        }
         HIP_CHECK_RET(hipMemcpyAsync(dip.data(), bv.dip, sizeof(double) * dip.size(), hipMemcpyDeviceToHost, s));
         HIP_CHECK_RET(hipMemcpyAsync(&formed, bv.eri_count, sizeof(formed), hipMemcpyDeviceToHost, s));
         HIP_CHECK_RET(hipMemcpyAsync(scal.data(), bv.scal, sizeof(double) * scal.size(), hipMemcpyDeviceToHost, s));
@@ -515,7 +562,8 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
             r->n_ao = n; r->n_mo = nmo; r->n_occ = nocc;
             if (nocc > nmo) {
                 // nmo check: more occupied orbitals than the basis supports after dropping near-null modes
-                fill_error(r, "RHF: more occupied orbitals than the basis supports after near-null modes were dropped");
+                fill_error(r, uhf ? "UHF: more alpha electrons than the basis supports after near-null modes were dropped"
+                                  : "RHF: more occupied orbitals than the basis supports after near-null modes were dropped");
                 r->scf_status = MQC_HIP_SCF_NOT_RUN;
                 continue;
             }
@@ -529,7 +577,33 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
             r->homo = eps[(size_t)f * n + nocc - 1];
             r->lumo = nocc < nmo ? eps[(size_t)f * n + nocc] : 0.0;
             r->has_orbitals = 1;
-            r->n_alpha = nocc; r->n_beta = nocc; r->s_squared = 0.0;
+            r->n_alpha = nalpha; r->n_beta = nbeta; r->s_squared = 0.0;
+            if (uhf) {
+                // <S^2> = S_z (S_z + 1) + n_beta - sum_ij |<a_i|S|b_j>|^2  (spin_contamination, mqc_libcint_rhf.f90)
+                const size_t nnh = (size_t)n * n;
+                std::vector<double> Ca(nnh), Cb(nnh), Sm(nnh);
+                HIP_CHECK_RET(hipMemcpyAsync(Ca.data(), bv.C + (size_t)f * nnh, sizeof(double) * nnh, hipMemcpyDeviceToHost, s));
+                HIP_CHECK_RET(hipMemcpyAsync(Cb.data(), bv.Cb + (size_t)f * nnh, sizeof(double) * nnh, hipMemcpyDeviceToHost, s));
+                HIP_CHECK_RET(hipMemcpyAsync(Sm.data(), bv.S + (size_t)f * nnh, sizeof(double) * nnh, hipMemcpyDeviceToHost, s));
+                HIP_CHECK_RET(hipStreamSynchronize(s));
+                double ov2 = 0.0;
+                std::vector<double> SCb((size_t)n * std::max(nbeta, 1));
+                for (int mu = 0; mu < n; ++mu)
+                    for (int j = 0; j < nbeta; ++j) {
+                        double t = 0.0;
+                        for (int nu = 0; nu < n; ++nu) t += Sm[(size_t)mu * n + nu] * Cb[(size_t)nu * n + j];
+                        SCb[(size_t)mu * nbeta + j] = t;
+                    }
+                for (int i = 0; i < nalpha; ++i)
+                    for (int j = 0; j < nbeta; ++j) {
+                        double t = 0.0;
+                        for (int mu = 0; mu < n; ++mu) t += Ca[(size_t)mu * n + i] * SCb[(size_t)mu * nbeta + j];
+                        ov2 += t * t;
+                    }
+                const double sz = 0.5 * (nalpha - nbeta);
+                r->s_squared = sz * (sz + 1.0) + nbeta - ov2;
+                if (r->orbital_energies_beta) std::memcpy(r->orbital_energies_beta, &epsb[(size_t)f * n], sizeof(double) * nmo);
+            }
             {
                 // mu = sum_A Z_A (R_A - O) - [tr(D r) - O tr(D S)], O = centre of nuclear charge, tr(D S) = N_electrons
                 // (system_compute_dipole, mqc_cuest_integrals.f90:1443-1521)
@@ -545,6 +619,11 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
             if (r->density) {
                 HIP_CHECK_RET(hipMemcpyAsync(r->density, bv.D + (size_t)f * n * n, sizeof(double) * n * n, hipMemcpyDeviceToHost, s));
                 HIP_CHECK_RET(hipStreamSynchronize(s));
+                if (uhf) {
+                    std::vector<double> db((size_t)n * n);
+                    HIP_CHECK_RET(hipMemcpy(db.data(), bv.Db + (size_t)f * n * n, sizeof(double) * n * n, hipMemcpyDeviceToHost));
+                    for (size_t k = 0; k < db.size(); ++k) r->density[k] += db[k];
+                }
             }
             r->has_error = 0; r->message[0] = '\0';
             if (use_df && scal[8 * f + 7] == 1.0)

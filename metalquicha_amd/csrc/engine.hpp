@@ -148,6 +148,10 @@ struct BatchView {      // plain pointers handed to kernels
     double *df_a3, *df_b;         // [nfrag][naux][npair]: (P|mu nu) and the fitted tensor
     double *df_metric, *df_linv;  // [nfrag][naux][naux]
     double* df_work;              // [nfrag][naux][naux] scratch of the fit (saved diagonal; V^T of the eigen path)
+    // unrestricted SCF (uhf != 0): D, C, F, J, K, Vprev, eps and the DIIS histories above are the ALPHA spin's,
+    // these are the BETA spin's; densities are D_s = C_s,occ C_s,occ^T (no factor 2)
+    int uhf, nalpha, nbeta;
+    double *Db, *Cb, *Fb, *Jb, *Kb, *Vprevb, *epsb, *diis_fb, *diis_eb;
 };
 
 struct Stats {
@@ -215,7 +219,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
 
 // kernel launchers (kern_*.hip)
 void launch_int1e(const BatchView& bv, const Topology& topo, hipStream_t s);
-void launch_dipole(const BatchView& bv, const Topology& topo, hipStream_t s);
+void launch_dipole(const BatchView& bv, const Topology& topo, hipStream_t s, bool accumulate = false);
 // host_xyz (optional, [nfrag][natoms][3] as uploaded): enables block sharing between fragments with identical atoms
 void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, hipStream_t s, const double* host_xyz = nullptr);
 // optional head start of the screened build (bounds + zero fill on side streams); launch_eri joins it

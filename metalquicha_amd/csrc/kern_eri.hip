@@ -303,22 +303,12 @@ void launch_eri_bounds(const BatchView& bv, const Topology& topo, double schwarz
     st.bounds_pending = true;
 }
 
-void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, hipStream_t s, const double* host_xyz)
+// Host side of the integral stage: block-sharing plan, class / task lists, ONE upload.  Depends on the geometry only,
+// so the engine calls it right after the geometry upload (eri_plan_lists) and the planning runs on the host while the
+// Schwarz-bound and one-electron kernels run on the device; launch_eri then finds the entry in the cache.
+static EriListCache* eri_lists(const BatchView& bv, const Topology& topo, hipStream_t s, const double* host_xyz)
 {
     EriSlotState& st = eri_slot_state(bv.slot);
-    const size_t np = (size_t)bv.npair;
-    // The class lists cover every element of the pair matrix, so the unscreened build overwrites the whole
-    // tensor and needs no zero fill (22 GB for the (H2O)64 dimers); a screened build leaves skipped blocks at zero.
-    double* Q = nullptr;
-    double thresh = 0.0;
-    if (schwarz_tol > 0.0) {
-        if (!st.bounds_pending || st.bounds_tol != schwarz_tol) launch_eri_bounds(bv, topo, schwarz_tol, s);
-        for (int k = 0; k < ERI_SIDE_STREAMS; ++k) (void)hipStreamWaitEvent(s, st.join[k], 0);
-        st.bounds_pending = false;
-        Q = st.Q;
-        thresh = schwarz_tol;
-    }
-
     // twin-shell cut and block sharing combine with Schwarz screening (a twin entry is kept when any member
     // combination passes; shared entries are tested with their representative's bounds)
     const bool twins = !twin_blocks_disabled();
@@ -400,6 +390,30 @@ void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, h
         if (xyz_count) cc->xyz.assign(host_xyz, host_xyz + xyz_count); else cc->xyz.clear();
         cc->valid = true;
     }
+    return cc;
+}
+
+void eri_plan_lists(const BatchView& bv, const Topology& topo, hipStream_t s, const double* host_xyz)
+{
+    (void)eri_lists(bv, topo, s, host_xyz);
+}
+
+void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, hipStream_t s, const double* host_xyz)
+{
+    EriSlotState& st = eri_slot_state(bv.slot);
+    const size_t np = (size_t)bv.npair;
+    // The class lists cover every element of the pair matrix, so the unscreened build overwrites the whole
+    // tensor and needs no zero fill (22 GB for the (H2O)64 dimers); a screened build leaves skipped blocks at zero.
+    double* Q = nullptr;
+    double thresh = 0.0;
+    if (schwarz_tol > 0.0) {
+        if (!st.bounds_pending || st.bounds_tol != schwarz_tol) launch_eri_bounds(bv, topo, schwarz_tol, s);
+        for (int k = 0; k < ERI_SIDE_STREAMS; ++k) (void)hipStreamWaitEvent(s, st.join[k], 0);
+        st.bounds_pending = false;
+        Q = st.Q;
+        thresh = schwarz_tol;
+    }
+    EriListCache* cc = eri_lists(bv, topo, s, host_xyz);
     const int* d = (const int*)cc->pool.ensure(0);
 
     // ---- launches: dense lists on the caller's stream; the task-list launches of shared entries (few, long

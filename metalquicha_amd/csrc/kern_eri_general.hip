@@ -322,6 +322,9 @@ __global__ void __launch_bounds__(64) eri_general_kernel(BatchView bv, int la, i
         if (A == B && j > i) continue;
         if (C == D && l > k) continue;
         const size_t row = pair_index(oa + i, ob + j), col = pair_index(oc + k, od + l);
+        // a diagonal quartet (AB|AB) holds (ij|kl) and (kl|ij) in the same block, equal up to rounding and owned by
+        // different lanes: only the lower triangle writes, so that M stays exactly symmetric
+        if (A == C && B == D && row < col) continue;
         const double v = OUT[idx];
         M[row * np + col] = v;
         M[col * np + row] = v;

@@ -140,16 +140,14 @@ __global__ void __launch_bounds__(64) int1e_kernel(BatchView bv, const int* __re
 }
 
 template <int LA, int LB>
-static void launch_class(const BatchView& bv, const std::vector<int>& list, DevicePool& scratch, hipStream_t s)
+static void launch_class(const BatchView& bv, const std::vector<int>& list, int* d, hipStream_t s)
 {
     if (list.empty()) return;
     int npairs = (int)list.size() / 2;
-    int* d = (int*)scratch.ensure(list.size() * sizeof(int));
     (void)hipMemcpyAsync(d, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice, s);
     long total = (long)npairs * bv.nfrag;
     int blocks = (int)((total + 63) / 64);
     hipLaunchKernelGGL((int1e_kernel<LA, LB>), dim3(blocks), dim3(64), 0, s, bv, d, npairs);
-    (void)hipStreamSynchronize(s);   // the scratch list is reused by the next class
 }
 
 // ---------------------------------------------------------------------------------------
@@ -251,7 +249,7 @@ static void launch_dipole_class(const BatchView& bv, const std::vector<int>& lis
     hipLaunchKernelGGL((dipole_kernel<LA, LB>), dim3((int)((total + 63) / 64)), dim3(64), 0, s, bv, d, npairs);
 }
 
-void launch_dipole(const BatchView& bv, const Topology& topo, hipStream_t s)
+void launch_dipole(const BatchView& bv, const Topology& topo, hipStream_t s, bool accumulate)
 {
     static DevicePool scratch_slot[2];
     static std::vector<int> bucket_slot[2][LMAX_AO + 1][LMAX_AO + 1];      // kept alive for the async uploads
@@ -265,7 +263,7 @@ void launch_dipole(const BatchView& bv, const Topology& topo, hipStream_t s)
         bucket[la][lb].push_back(B);
     }
     int* d = (int*)scratch_slot[bv.slot & 1].ensure((topo.pairs.size() + 16) * sizeof(int));
-    (void)hipMemsetAsync(bv.dip, 0, sizeof(double) * 4 * (size_t)bv.nfrag, s);
+    if (!accumulate) (void)hipMemsetAsync(bv.dip, 0, sizeof(double) * 4 * (size_t)bv.nfrag, s);
     size_t off = 0;
 #define DIP_CASE(a, b) launch_dipole_class<a, b>(bv, bucket[a][b], d + off, s); off += bucket[a][b].size();
     DIP_CASE(0, 0) DIP_CASE(1, 0) DIP_CASE(1, 1) DIP_CASE(2, 0) DIP_CASE(2, 1) DIP_CASE(2, 2)
@@ -276,9 +274,12 @@ void launch_dipole(const BatchView& bv, const Topology& topo, hipStream_t s)
 void launch_int1e(const BatchView& bv, const Topology& topo, hipStream_t s)
 {
     static DevicePool scratch_slot[2];
-    DevicePool& scratch = scratch_slot[bv.slot & 1];
-    // bucket the (A>=B) shell pairs by (la,lb) with la >= lb
-    std::vector<int> bucket[KERNEL_LMAX + 1][KERNEL_LMAX + 1];
+    // one device list with an offset per class and host buckets that outlive the asynchronous uploads: no host
+    // synchronisation between the class launches (the batch view of the NEXT call reuses them only after the stream
+    // has been drained by the SCF loop)
+    static std::vector<int> bucket_slot[2][LMAX_AO + 1][LMAX_AO + 1];
+    auto& bucket = bucket_slot[bv.slot & 1];
+    for (auto& row : bucket) for (auto& b : row) b.clear();
     for (size_t k = 0; k + 1 < topo.pairs.size(); k += 2) {
         int A = topo.pairs[k], B = topo.pairs[k + 1];
         int la = topo.shells[A].l, lb = topo.shells[B].l;
@@ -286,16 +287,12 @@ void launch_int1e(const BatchView& bv, const Topology& topo, hipStream_t s)
         bucket[la][lb].push_back(A);
         bucket[la][lb].push_back(B);
     }
-    launch_class<0, 0>(bv, bucket[0][0], scratch, s);
-    launch_class<1, 0>(bv, bucket[1][0], scratch, s);
-    launch_class<1, 1>(bv, bucket[1][1], scratch, s);
-    launch_class<2, 0>(bv, bucket[2][0], scratch, s);
-    launch_class<2, 1>(bv, bucket[2][1], scratch, s);
-    launch_class<2, 2>(bv, bucket[2][2], scratch, s);
-    launch_class<3, 0>(bv, bucket[3][0], scratch, s);
-    launch_class<3, 1>(bv, bucket[3][1], scratch, s);
-    launch_class<3, 2>(bv, bucket[3][2], scratch, s);
-    launch_class<3, 3>(bv, bucket[3][3], scratch, s);
+    int* d = (int*)scratch_slot[bv.slot & 1].ensure((topo.pairs.size() + 16) * sizeof(int));
+    size_t off = 0;
+#define I1_CASE(a, b) launch_class<a, b>(bv, bucket[a][b], d + off, s); off += bucket[a][b].size();
+    I1_CASE(0, 0) I1_CASE(1, 0) I1_CASE(1, 1) I1_CASE(2, 0) I1_CASE(2, 1) I1_CASE(2, 2)
+    I1_CASE(3, 0) I1_CASE(3, 1) I1_CASE(3, 2) I1_CASE(3, 3)
+#undef I1_CASE
 }
 
 }  // namespace mqc

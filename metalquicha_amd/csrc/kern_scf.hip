@@ -356,14 +356,17 @@ __global__ void __launch_bounds__(NT) orthogonalizer_kernel(BatchView bv)
 // WARM: the previous iteration's eigenvectors Vp (orthogonal basis, bv.Vprev) pre-rotate F' so
 // that the Jacobi sweeps start from a nearly diagonal matrix; V then starts from Vp, so the final
 // V is the full eigenvector matrix and no extra product is needed.
+// vprev / nocc / dfac: spin channel of an unrestricted run (defaults: the closed-shell values)
 template <bool VLDS, bool WARM>
-__device__ void diagonalize_and_density(const BatchView& bv, FragPtrs& p, JacobiLds& jl, int m)
+__device__ void diagonalize_and_density(const BatchView& bv, FragPtrs& p, JacobiLds& jl, int m, double* vprev = nullptr, int nocc = -1,
+                                        double dfac = 2.0)
 {
     const int n = bv.n, tid = threadIdx.x;
     const size_t nn = (size_t)n * n;
     double* T = p.W + 2 * nn;       // F X  (n x m), then F' Vp (m x m)
     double* Vg = p.W + 3 * nn;      // global eigenvectors when they do not fit in LDS
-    double* Vp = bv.Vprev + (size_t)blockIdx.x * nn;    // m x m, ld n
+    double* Vp = (vprev ? vprev : bv.Vprev) + (size_t)blockIdx.x * nn;    // m x m, ld n
+    if (nocc < 0) nocc = bv.nocc;
     const int mp = even_up(m), lda = jl.lda;
     const int ldv = VLDS ? lda : m;
     if (!VLDS) jl.V = Vg;
@@ -406,7 +409,18 @@ __device__ void diagonalize_and_density(const BatchView& bv, FragPtrs& p, Jacobi
     wg_gemm_mfma<false, false>(n, m, m, p.X, n, jl.V, ldv, [&](int r, int i, double v) { Cg[r * n + rank[i]] = v; });
     // D = 2 C_occ C_occ^T
     double* const Dg = p.D;
-    wg_gemm_mfma<false, true>(n, n, bv.nocc, Cg, n, Cg, n, [&](int i, int j, double v) { Dg[i * n + j] = 2.0 * v; });
+    wg_gemm_mfma<false, true>(n, n, nocc, Cg, n, Cg, n, [&](int i, int j, double v) { Dg[i * n + j] = dfac * v; });
+}
+
+// the beta spin's view of a fragment: same S, H, X, W, state; its own F, D, C, J, K, eps and histories
+__device__ __forceinline__ FragPtrs frag_ptrs_beta(const BatchView& bv, int f)
+{
+    const size_t nn = (size_t)bv.n * bv.n;
+    FragPtrs p = frag_ptrs(bv, f);
+    p.F = bv.Fb + f * nn; p.D = bv.Db + f * nn; p.C = bv.Cb + f * nn; p.J = bv.Jb + f * nn; p.K = bv.Kb + f * nn;
+    p.eps = bv.epsb + (size_t)f * bv.n;
+    p.diis_f = bv.diis_fb + f * DIIS_MAX * nn; p.diis_e = bv.diis_eb + f * DIIS_MAX * nn;
+    return p;
 }
 
 // Starting Fock (core or GWH, guess_fock mqc_libcint_rhf.f90:1354-1380), then the first density.
@@ -425,7 +439,21 @@ __global__ void __launch_bounds__(NT) guess_kernel(BatchView bv, int guess_kind)
         p.F[idx] = v;
     }
     __syncthreads();
-    diagonalize_and_density<VLDS, false>(bv, p, jl, m);
+    if (bv.uhf) {
+        // symmetric guess: both spins get the orbitals of the same starting Fock, the occupations separate them
+        // (run_libcint_uhf, mqc_libcint_rhf.f90:838-866)
+        diagonalize_and_density<VLDS, false>(bv, p, jl, m, nullptr, bv.nalpha, 1.0);
+        FragPtrs pb = frag_ptrs_beta(bv, f);
+        const size_t nn = (size_t)n * n;
+        double* Vpa = bv.Vprev + (size_t)f * nn; double* Vpb = bv.Vprevb + (size_t)f * nn;
+        for (int idx = tid; idx < n * n; idx += NT) { pb.C[idx] = p.C[idx]; Vpb[idx] = Vpa[idx]; pb.F[idx] = p.F[idx]; }
+        for (int i = tid; i < n; i += NT) pb.eps[i] = p.eps[i];
+        __syncthreads();
+        double* const Dbg = pb.D; const double* Cbg = pb.C;
+        wg_gemm_mfma<false, true>(n, n, bv.nbeta, Cbg, n, Cbg, n, [&](int i, int j, double v) { Dbg[i * n + j] = v; });
+    } else {
+        diagonalize_and_density<VLDS, false>(bv, p, jl, m);
+    }
     if (tid == 0) {
         p.istate[0] = ST_ITER; p.istate[1] = 0; p.istate[3] = 0;
         p.diis_state[0] = 0; p.diis_state[1] = 0;
@@ -598,6 +626,128 @@ __global__ void __launch_bounds__(NT) scf_step_kernel(BatchView bv)
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Unrestricted step (run_libcint_uhf, mqc_libcint_rhf.f90:868-931): F_s = H + J[D_a + D_b] - exx K[D_s],
+// E = 1/2 sum_s D_s (H + F_s); the commutators of both spins laid end to end form ONE DIIS error vector, the two
+// Fock matrices one DIIS Fock vector (a single coefficient set moves both spins), extrapolation starts at
+// iteration 4 (DEFAULT_UHF_DIIS_START, :51); both spins are diagonalised; dE and the rms over BOTH density changes
+// decide convergence; the final state rebuilds the energy from the converged densities.
+constexpr int UHF_DIIS_START = 4;
+
+template <bool VLDS>
+__global__ void __launch_bounds__(NT) scf_step_uhf_kernel(BatchView bv)
+{
+    extern __shared__ double lds[];
+    const int f = blockIdx.x, n = bv.n, tid = threadIdx.x;
+    FragPtrs pa = frag_ptrs(bv, f);
+    FragPtrs pb = frag_ptrs_beta(bv, f);
+    const int state = pa.istate[0];
+    if (state == ST_DONE) return;
+    const int m = pa.istate[2];
+    const size_t nn = (size_t)n * n;
+    JacobiLds jl = carve_jacobi(lds, m, VLDS, nullptr);
+
+    double e = 0.0;
+    for (int idx = tid; idx < n * n; idx += NT) {
+        const double h = pa.H[idx];
+        const double j = pa.J[idx] + pb.J[idx];
+        const double fa = h + j - bv.exx * pa.K[idx];
+        const double fb = h + j - bv.exx * pb.K[idx];
+        e += pa.D[idx] * (h + fa) + pb.D[idx] * (h + fb);
+        pa.F[idx] = fa; pb.F[idx] = fb;
+    }
+    e = 0.5 * block_sum(e, jl.red);
+    if (state == ST_FINAL) {
+        if (tid == 0) { pa.scal[4] = e; pa.istate[0] = ST_DONE; }
+        return;
+    }
+    const int iter = pa.istate[1] + 1;
+
+    // commutators straight into the newest history slot (the slot is claimed even without DIIS: one slot of scratch)
+    const int maxv = bv.diis_size;
+    int n_stored = pa.diis_state[0], newest = pa.diis_state[1];
+    if (maxv > 0) { newest = newest % maxv + 1; if (n_stored < maxv) n_stored += 1; }
+    const int slot = maxv > 0 ? newest - 1 : 0;
+    double* W0 = pa.W; double* W1 = pa.W + nn; double* W2 = pa.W + 2 * nn;
+    for (int spin = 0; spin < 2; ++spin) {
+        FragPtrs& p = spin ? pb : pa;
+        double* Err = p.diis_e + (size_t)slot * nn;
+        wg_gemm_mfma<false, false>(n, n, n, p.F, n, p.D, n, [&](int i, int j, double v) { W0[i * n + j] = v; });
+        wg_gemm_mfma<false, false>(n, n, n, W0, n, p.S, n, [&](int i, int j, double v) { W1[i * n + j] = v; });
+        for (int idx = tid; idx < n * n; idx += NT) {
+            const int i = idx / n, j = idx - i * n;
+            W0[idx] = W1[idx] - W1[j * n + i];
+        }
+        __syncthreads();
+        wg_gemm_mfma<false, false>(n, m, n, W0, n, p.X, n, [&](int i, int j, double v) { W2[i * n + j] = v; });
+        wg_gemm_mfma<true, false>(m, m, n, p.X, n, W2, n, [&](int i, int j, double v) { Err[i * m + j] = v; });
+        if (maxv > 0) {
+            double* fh = p.diis_f + (size_t)slot * nn;
+            for (int idx = tid; idx < n * n; idx += NT) fh[idx] = p.F[idx];
+        }
+        __syncthreads();
+    }
+    if (maxv > 0) {
+        const double* ea = pa.diis_e + (size_t)slot * nn;
+        const double* eb = pb.diis_e + (size_t)slot * nn;
+        for (int age = 1; age <= n_stored; ++age) {
+            const int other = diis_slot_of_age(newest, n_stored, maxv, age) - 1;
+            const double* oa = pa.diis_e + (size_t)other * nn;
+            const double* ob = pb.diis_e + (size_t)other * nn;
+            double s = 0.0;
+            for (int idx = tid; idx < m * m; idx += NT) s += ea[idx] * oa[idx] + eb[idx] * ob[idx];
+            s = block_sum(s, jl.red);
+            if (tid == 0) { pa.diis_b[slot * maxv + other] = s; pa.diis_b[other * maxv + slot] = s; }
+        }
+        __syncthreads();
+        __shared__ double coef_u[DIIS_MAX + 2];
+        __shared__ int ok_u;
+        if (tid == 0) {
+            double cf[DIIS_MAX + 2];
+            const bool ok = (iter >= UHF_DIIS_START) && diis_solve(pa.diis_b, newest, n_stored, maxv, cf);
+            ok_u = ok ? 1 : 0;
+            if (ok) for (int i = 0; i <= n_stored; ++i) coef_u[i] = cf[i];
+            pa.diis_state[0] = n_stored; pa.diis_state[1] = newest;
+        }
+        __syncthreads();
+        if (ok_u) {
+            for (int idx = tid; idx < n * n; idx += NT) {
+                double sa = 0.0, sb = 0.0;
+                for (int i = 0; i < n_stored; ++i) {
+                    const int sl = diis_slot_of_age(newest, n_stored, maxv, i + 1) - 1;
+                    sa += coef_u[i] * pa.diis_f[(size_t)sl * nn + idx];
+                    sb += coef_u[i] * pb.diis_f[(size_t)sl * nn + idx];
+                }
+                pa.F[idx] = sa; pb.F[idx] = sb;
+            }
+        }
+        __syncthreads();
+    }
+
+    // old densities to W0 / W1, both spins diagonalised, new densities
+    for (int idx = tid; idx < n * n; idx += NT) { W0[idx] = pa.D[idx]; W1[idx] = pb.D[idx]; }
+    __syncthreads();
+    diagonalize_and_density<VLDS, true>(bv, pa, jl, m, bv.Vprev, bv.nalpha, 1.0);
+    __syncthreads();
+    diagonalize_and_density<VLDS, true>(bv, pb, jl, m, bv.Vprevb, bv.nbeta, 1.0);
+
+    double d2 = 0.0;
+    for (int idx = tid; idx < n * n; idx += NT) {
+        const double da = pa.D[idx] - W0[idx], db = pb.D[idx] - W1[idx];
+        d2 += da * da + db * db;
+    }
+    d2 = block_sum(d2, jl.red);
+    if (tid == 0) {
+        const double e_old = pa.scal[1];
+        const double de = fabs(e - e_old);
+        const double drms = sqrt(d2 / (double)(2 * n * n));
+        pa.scal[0] = e; pa.scal[1] = e; pa.scal[2] = de; pa.scal[3] = drms;
+        pa.istate[1] = iter;
+        if (iter > 1 && de < bv.e_tol && drms < bv.d_tol) { pa.istate[3] = 1; pa.istate[0] = ST_FINAL; }
+        else if (iter >= bv.max_iter) { pa.istate[3] = 0; pa.istate[0] = ST_FINAL; }
+    }
+}
+
 __global__ void count_active_kernel(BatchView bv)
 {
     int c = 0;
@@ -656,7 +806,10 @@ void launch_scf_step(const BatchView& bv, hipStream_t s)
 {
     apply_jacobi_env();
     const size_t lds = scf_lds_bytes(bv.n);
-    if (v_in_lds(bv.n)) launch_wg(scf_step_kernel<true>, bv.nfrag, lds, s, bv);
+    if (bv.uhf) {
+        if (v_in_lds(bv.n)) launch_wg(scf_step_uhf_kernel<true>, bv.nfrag, lds, s, bv);
+        else launch_wg(scf_step_uhf_kernel<false>, bv.nfrag, lds, s, bv);
+    } else if (v_in_lds(bv.n)) launch_wg(scf_step_kernel<true>, bv.nfrag, lds, s, bv);
     else launch_wg(scf_step_kernel<false>, bv.nfrag, lds, s, bv);
     hipLaunchKernelGGL(count_active_kernel, dim3(1), dim3(256), 0, s, bv);
 }

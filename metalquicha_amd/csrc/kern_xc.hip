@@ -649,6 +649,9 @@ static void xc_mfma_launch(const BatchView& bv, int oa, hipStream_t s)
 // (lane = point on wave 0 while the other workgroups of the CU compute), and n up to 144 uses the matrix cores
 // (benzene/cc-pVDZ n = 114, def2-TZVP water dimer n = 86).  Same arithmetic as mqc_libcint_xc.F90:796-927.
 constexpr int XV_NW = 4;
+// MQC_HIP_XC_PROBE (timing experiments only, results are then meaningless): bit 0 skips the AO slab evaluation, bit 1 the
+// X = D chi jobs, bit 2 the functional (constants instead), bit 3 the accumulation A += a chi^T
+__device__ int g_xc_probe = 0;
 
 template <bool GGA, int PT, int JMAX, int OCC>
 __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, int only_active)
@@ -684,7 +687,9 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
     double e_acc = 0.0, n_acc = 0.0;
     __syncthreads();
 
+    const int probe = g_xc_probe;
     auto ao_slab = [&](int g0) {
+        if (probe & 1) return;
         // AO values (and gradients) of PT points: (radial group, point) items, point fastest
         for (int idx = tid; idx < tp.ngroup * PT; idx += SUPER) {
             const int rg = idx / PT, p = idx - rg * PT;
@@ -709,7 +714,7 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
             ao_slab(g0);
             __syncthreads();
             // X = D chi, job = (row tile mt, point tile pt); rho and grad rho from the accumulator rows
-            for (int job = wave; job < NT16 * PT16; job += XV_NW) {
+            for (int job = wave; job < NT16 * PT16 && !(probe & 2); job += XV_NW) {
                 const int mt = job / PT16, pt = job - mt * PT16;
                 v4f64 xacc = (v4f64){0.0, 0.0, 0.0, 0.0};
                 const int mu_a = 16 * mt + lo;
@@ -751,7 +756,8 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
             rp[0] = 0.0; rp[1] = 0.0; rp[2] = 0.0; rp[3] = 0.0;
             const double sigma = GGA ? rx * rx + ry * ry + rz * rz : 0.0;
             double fx, vr, vs;
-            eval_functional(bv.xc, rho, sigma, fx, vr, vs);
+            if (probe & 4) { fx = -rho; vr = -1.0; vs = 0.0; }
+            else eval_functional(bv.xc, rho, sigma, fx, vr, vs);
             const double w = (s0 + p < gd.npts) ? wts[s0 + p] : 0.0;
             e_acc += w * fx;
             n_acc += w * rho;
@@ -781,7 +787,7 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
 #pragma unroll
             for (int j = 0; j < JMAX; ++j) {
                 const int t = wave + XV_NW * j;
-                if (t < NT16 * NT16) {
+                if (t < NT16 * NT16 && !(probe & 8)) {
                     const int mt = t / NT16, nt = t - mt * NT16;
                     const double* __restrict__ ar = gx + (size_t)(16 * mt + lo) * RS + hi;
                     const double* __restrict__ br = chi + (size_t)(16 * nt + lo) * RS + hi;
@@ -882,6 +888,11 @@ void launch_xc(const BatchView& bv, bool only_active, hipStream_t s)
     (void)hipMemsetAsync(bv.Vxc, 0, sizeof(double) * (size_t)bv.nfrag * n * n, s);
     hipLaunchKernelGGL(xc_reset_kernel, dim3((bv.nfrag + 255) / 256), dim3(256), 0, s, bv);
     const bool gga = bv.xc.gga != 0;
+    static const bool probed = [] {
+        if (const char* e = std::getenv("MQC_HIP_XC_PROBE")) { const int v = std::atoi(e); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_xc_probe), &v, sizeof(int)); }
+        return true;
+    }();
+    (void)probed;
     // MQC_HIP_XC_V1=1: the round-1 kernels (wave-private MFMA kernel for n <= 48, VALU kernel above), kept for A/B runs
     static const bool v1 = [] { const char* e = std::getenv("MQC_HIP_XC_V1"); return e && e[0] == '1'; }();
     if (!v1 && (gga ? xc_tile_dispatch<true>(bv, oa, s) : xc_tile_dispatch<false>(bv, oa, s))) return;

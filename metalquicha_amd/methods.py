@@ -124,6 +124,9 @@ class CalculationResult:
     gradient: Optional[np.ndarray] = None   # (3, n_atoms) Hartree/Bohr, like result%gradient
     has_gradient: bool = False
     s_squared: float = 0.0
+    orbital_energies_beta: Optional[np.ndarray] = None
+    n_alpha: int = 0
+    n_beta: int = 0
 
 
 _GUESS = {"auto": capi.GUESS_AUTO, "gwh": capi.GUESS_GWH, "core": capi.GUESS_CORE}
@@ -225,6 +228,7 @@ def _fill(result: CalculationResult, r: capi.ScfResult, eps: Optional[np.ndarray
         result.dipole = np.array([r.dipole[0], r.dipole[1], r.dipole[2]])
         result.has_dipole = True
     result.s_squared = float(r.s_squared)
+    result.n_alpha = int(r.n_alpha); result.n_beta = int(r.n_beta)
     return result
 
 
@@ -240,13 +244,18 @@ def run_hip_scf(settings: ScfSettings, fragment: PhysicalFragment, result: Optio
         aux = _flat_basis(settings.aux_basis_set, fragment) if settings.density_fitting else None
         m = _Marshalled(fragment, fb, aux)
         eps = np.zeros(fb.nao)
+        epsb = np.zeros(fb.nao)
         r = capi.ScfResult()
         r.orbital_energies = capi.dptr(eps)
+        r.orbital_energies_beta = capi.dptr(epsb)
         rc = lib.mqc_hip_scf_run(ctx, C.byref(m.mol), C.byref(m.bas), C.byref(m.aux_bas) if aux is not None else None,
                                  C.byref(opts), C.byref(r))
         if rc != capi.MQC_HIP_OK and not r.has_error:
             capi.check(rc)
-        return _fill(result, r, eps)
+        _fill(result, r, eps)
+        if result.has_energy and int(r.n_alpha) != int(r.n_beta) or settings.unrestricted:
+            result.orbital_energies_beta = epsb[: int(r.n_mo)].copy()
+        return result
     except (capi.HipBackendError, BasisError) as e:
         result.has_error = True
         result.has_energy = False

@@ -433,3 +433,101 @@ def run_rhf(mol: OracleMol, nelec: int, max_iter=100, e_tol=1e-8, d_tol=1e-6, di
     F, e_final, exc = assemble(D, C)
     enuc = nuclear_repulsion(mol)
     return ScfResult(e_final + enuc, e_final, enuc, converged, iters, eps, C, D, F, exc, hist)
+
+
+# --------------------------------------------------------------------------- unrestricted SCF
+UHF_DIIS_START = 4           # backends/libcint/mqc_libcint_rhf.f90:51 (DEFAULT_UHF_DIIS_START)
+
+
+def spin_contamination(Ca, Cb, S, n_alpha, n_beta):
+    """<S^2> of the unrestricted determinant: S_z (S_z + 1) + n_beta - sum_ij |<a_i|b_j>|^2."""
+    sz = 0.5 * (n_alpha - n_beta)
+    ov = Ca[:, :n_alpha].T @ S @ Cb[:, :n_beta]
+    return sz * (sz + 1.0) + n_beta - float(np.sum(ov ** 2))
+
+
+@dataclass
+class UhfResult:
+    energy: float
+    electronic: float
+    nuclear: float
+    converged: bool
+    iterations: int
+    eps_a: np.ndarray
+    eps_b: np.ndarray
+    Ca: np.ndarray
+    Cb: np.ndarray
+    Da: np.ndarray
+    Db: np.ndarray
+    s_squared: float
+    n_alpha: int
+    n_beta: int
+
+
+def run_uhf(mol: OracleMol, nelec: int, multiplicity: int, max_iter=100, e_tol=1e-8, d_tol=1e-6, diis_vectors=8,
+            guess="gwh", diis_start=UHF_DIIS_START, eri=None) -> UhfResult:
+    """Unrestricted Hartree-Fock with the reference CPU path's semantics (run_libcint_uhf,
+    backends/libcint/mqc_libcint_rhf.f90:682-974): F_s = H + J[D_a + D_b] - K[D_s], one DIIS over both spins
+    (Fock matrices and commutators laid end to end) from iteration `diis_start`, dE and the rms over BOTH density
+    changes, final full rebuild; symmetric core / GWH guess -- the occupations separate the spins."""
+    if multiplicity < 1 or (nelec + multiplicity - 1) % 2:
+        raise ValueError("UHF: electron count and multiplicity cannot be paired")
+    na = (nelec + multiplicity - 1) // 2
+    nb = nelec - na
+    if nb < 0 or na < 1:
+        raise ValueError("UHF: bad occupation")
+    S, T, V = int1e(mol)
+    H = T + V
+    n = mol.nao
+    if eri is None:
+        eri = eri4(mol)
+    X = build_orthogonalizer(S)
+    m = X.shape[1]
+    if na > m:
+        raise ValueError("UHF: more alpha electrons than the basis supports")
+
+    def assemble(Da, Db):
+        J = np.einsum("ijkl,kl->ij", eri, Da + Db, optimize=True)
+        Ka = np.einsum("ikjl,kl->ij", eri, Da, optimize=True)
+        Kb = np.einsum("ikjl,kl->ij", eri, Db, optimize=True)
+        Fa = H + J - Ka
+        Fb = H + J - Kb
+        e = 0.5 * float(np.sum(Da * (H + Fa)) + np.sum(Db * (H + Fb)))
+        return Fa, Fb, e
+
+    F0 = H.copy() if guess == "core" else guess_fock_gwh(S, H)
+    Ca, ea = diagonalize(F0, X)
+    Cb, eb = Ca.copy(), ea.copy()
+    Da = Ca[:, :na] @ Ca[:, :na].T
+    Db = Cb[:, :nb] @ Cb[:, :nb].T
+    diis = Diis(diis_vectors, 2 * n * n, 2 * m * m)
+    e_old = 0.0
+    converged = False
+    iters = 0
+    for it in range(1, max_iter + 1):
+        Da_old, Db_old = Da.copy(), Db.copy()
+        Fa, Fb, e_elec = assemble(Da, Db)
+        erra = commutator(Fa, Da, S, X)
+        errb = commutator(Fb, Db, S, X)
+        ff = np.concatenate([Fa.reshape(-1), Fb.reshape(-1)])
+        diis.push(ff, np.concatenate([erra.reshape(-1), errb.reshape(-1)]))
+        if it >= diis_start:
+            ex, ok = diis.extrapolate(ff)
+            if ok:
+                Fa = ex[: n * n].reshape(n, n)
+                Fb = ex[n * n:].reshape(n, n)
+        Ca, ea = diagonalize(Fa, X)
+        Cb, eb = diagonalize(Fb, X)
+        Da = Ca[:, :na] @ Ca[:, :na].T
+        Db = Cb[:, :nb] @ Cb[:, :nb].T
+        de = abs(e_elec - e_old)
+        drms = math.sqrt((float(np.sum((Da - Da_old) ** 2)) + float(np.sum((Db - Db_old) ** 2))) / (2 * n * n))
+        e_old = e_elec
+        iters = it
+        if it > 1 and de < e_tol and drms < d_tol:
+            converged = True
+            break
+    _, _, e_final = assemble(Da, Db)
+    enuc = nuclear_repulsion(mol)
+    return UhfResult(e_final + enuc, e_final, enuc, converged, iters, ea, eb, Ca, Cb, Da, Db,
+                     spin_contamination(Ca, Cb, S, na, nb), na, nb)

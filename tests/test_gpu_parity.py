@@ -4,10 +4,14 @@ Tolerances: the reference's own direct-vs-in-core bound is 1e-11 elementwise
 (test/test_mqc_libcint_direct.f90:139); total energies must agree to <= 1e-8 Eh per fragment
 (BASELINE.json north_star) and the known-answer programs assert 1e-9.
 """
+import json
+import os
+
 import numpy as np
 import pytest
 
 from metalquicha_amd import methods
+from metalquicha_amd.basis import ANGSTROM_TO_BOHR, SYMBOL_TO_Z
 from tests import stages
 from oracle import scf_oracle as so
 from tests.helpers import fragment_bohr, oracle_mol, water_at, synthetic_density
@@ -189,10 +193,55 @@ def test_def2_tzvp_water_dimer_batch_matches_oracle():
             assert r.scf_iterations == o.iterations
 
 
+# ---- unrestricted Hartree-Fock ---------------------------------------------------------------------------------
+def _uhf_cases():
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "manifest_subset.json")))["cases"]
+    return [c for c in cases if c["method"] == "hf" and c["unrestricted"] and c["driver"] == "Energy" and not c["density_fitting"]]
+
+
+@pytest.mark.parametrize("case", _uhf_cases(), ids=[c["name"] for c in _uhf_cases()])
+def test_manifest_uhf_goldens(case):
+    """validation_tests_cpu.json uhf/ rows (OH doublet in STO-3G, cc-pVDZ, def2-SVP; O2 triplet in cc-pVDZ), tolerance
+    1e-9: energy against the golden, iteration count, <S^2> and both spins' orbital energies against the oracle."""
+    z = [SYMBOL_TO_Z[s.lower()] for s in case["symbols"]]
+    frag = fragment_bohr(z, np.array(case["xyz_angstrom"]) * ANGSTROM_TO_BOHR, multiplicity=case["multiplicity"])
+    st = methods.ScfSettings(basis_set=case["basis"], energy_tol=1e-10, density_tol=1e-7, guess="gwh", max_iter=case["maxiter"])
+    r = methods.run_hip_scf(st, frag)
+    assert not r.has_error, r.error_message
+    assert r.scf_status == methods.SCF_CONVERGED
+    assert abs(r.energy.scf - case["expected_energy"]) < 1e-9
+    o = so.run_uhf(oracle_mol(case["basis"], frag), int(frag.nelec), case["multiplicity"], case["maxiter"], 1e-10, 1e-7)
+    assert abs(r.energy.scf - o.energy) < 1e-9
+    assert r.scf_iterations == o.iterations
+    assert (r.n_alpha, r.n_beta) == (o.n_alpha, o.n_beta)
+    assert abs(r.s_squared - o.s_squared) < 1e-6
+    assert np.max(np.abs(r.orbital_energies[: o.n_alpha + 1] - o.eps_a[: o.n_alpha + 1])) < 1e-6
+    assert np.max(np.abs(r.orbital_energies_beta[: o.n_beta + 1] - o.eps_b[: o.n_beta + 1])) < 1e-6
+
+
+def test_uhf_batch_and_closed_shell_limit():
+    """A batch of OH radicals at different bond lengths in one call (UHF topology group) against the oracle; a closed-shell
+    molecule run unrestricted lands on the restricted energy with <S^2> = 0."""
+    frags = [fragment_bohr([8, 1], [[0, 0, 0], [0, 0, d]], multiplicity=2) for d in (1.70, 1.83, 1.95, 2.10)]
+    st = methods.ScfSettings(basis_set="cc-pvdz", energy_tol=1e-10, density_tol=1e-8, guess="gwh")
+    res = methods.run_hip_scf_batch(st, frags)
+    for f, r in zip(frags, res):
+        assert not r.has_error, r.error_message
+        o = so.run_uhf(oracle_mol("cc-pvdz", f), 9, 2, 100, 1e-10, 1e-8)
+        assert abs(r.energy.scf - o.energy) < 1e-8, (r.energy.scf, o.energy)
+        assert r.scf_iterations == o.iterations
+    w = fragment_bohr(*WATER)
+    ru = methods.run_hip_scf(methods.ScfSettings(basis_set="cc-pvdz", energy_tol=1e-10, density_tol=1e-8, guess="gwh", unrestricted=True), w)
+    rr = methods.run_hip_scf(methods.ScfSettings(basis_set="cc-pvdz", energy_tol=1e-10, density_tol=1e-8, guess="gwh"), w)
+    assert not ru.has_error, ru.error_message
+    assert abs(ru.energy.scf - rr.energy.scf) < 1e-9
+    assert abs(ru.s_squared) < 1e-8
+
+
 def test_refusals_match_reference_behaviour():
-    st = methods.ScfSettings(basis_set="sto-3g", unrestricted=True)
+    st = methods.ScfSettings(basis_set="sto-3g", unrestricted=True, functional="pbe")
     r = methods.run_hip_scf(st, fragment_bohr(*WATER))
-    assert r.has_error and not r.has_energy
+    assert r.has_error and not r.has_energy              # unrestricted Kohn-Sham: refused, not run restricted
     st = methods.ScfSettings(basis_set="sto-3g", max_iter=2, energy_tol=1e-12, density_tol=1e-12)
     r = methods.run_hip_scf(st, fragment_bohr(*WATER))
     assert r.scf_status == methods.SCF_NOT_CONVERGED and r.has_error     # not converged is an error ...
@@ -200,7 +249,7 @@ def test_refusals_match_reference_behaviour():
     r = methods.run_hip_scf(st, fragment_bohr(*WATER))
     assert r.scf_status == methods.SCF_NOT_CONVERGED and not r.has_error and r.has_energy   # ... unless allowed
     oh = methods.run_hip_scf(methods.ScfSettings(basis_set="sto-3g"), fragment_bohr([8, 1], [[0, 0, 0], [0, 0, 1.8]]))
-    assert oh.has_error      # odd electron count
+    assert oh.has_error      # nine electrons cannot be paired into a singlet (parities disagree): a validation error
 
 
 def _jk_from_packed(M, D):
