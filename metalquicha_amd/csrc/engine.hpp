@@ -112,6 +112,7 @@ struct TopologyDev {
     int *grp_first, *grp_count, *grp_nprim, *grp_poff, *grp_coff;
     double *gexps, *gcoefs;
     int ngroup;
+    int gprim_total, gcoef_total;     // lengths of gexps / gcoefs (the tiled XC kernel keeps the tables in LDS)
 };
 constexpr int XC_GROUP_MAX = 3;      // shells per radial group
 

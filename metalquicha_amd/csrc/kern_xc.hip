@@ -295,6 +295,21 @@ __device__ __forceinline__ void emit_shell(int l, int ao, double dx, double dy, 
 
 // one (point, radial group) work item: the exponentials of the group's primitives are formed once and contracted
 // with every member shell's coefficient row (TopologyDev::grp_*), then each member gets its angular part
+// the radial-group tables a workgroup keeps in LDS (the tiled kernel): per group a packed descriptor
+// (first shell's AO offset | l << 12 | atom << 16 | shell count << 24 | primitive count << 26), exponent / coefficient
+// offsets, and the exponent and coefficient arrays themselves -- global loads in the primitive loop were a dependent
+// chain of L2 latencies per (point, group) item
+struct GroupTables {
+    const int* desc;        // [ngroup][4]: packed, poff, coff, ao offsets of shells 1..2 packed (aoff1 | aoff2 << 16)
+    const double* exps;
+    const double* coefs;
+};
+
+template <bool GGA>
+__device__ __forceinline__ void eval_group_lds(const GroupTables& gt, const double* __restrict__ xyz, int g, double px, double py, double pz,
+                                               double* __restrict__ chi, double* __restrict__ gx, double* __restrict__ gy,
+                                               double* __restrict__ gz, int ptp, int p, const double* __restrict__ c2s);
+
 template <bool GGA>
 __device__ __forceinline__ void eval_group(const TopologyDev& tp, const double* __restrict__ xyz, int g, double px, double py, double pz,
                                            double* __restrict__ chi, double* __restrict__ gx, double* __restrict__ gy,
@@ -325,6 +340,39 @@ __device__ __forceinline__ void eval_group(const TopologyDev& tp, const double* 
 #pragma unroll
     for (int k = 0; k < XC_GROUP_MAX; ++k)
         if (k < nc) emit_shell<GGA>(l, tp.sh_aoff[sh0 + k], dx, dy, dz, rad[k], drad[k], chi, gx, gy, gz, ptp, p, c2s);
+}
+
+template <bool GGA>
+__device__ __forceinline__ void eval_group_lds(const GroupTables& gt, const double* __restrict__ xyz, int g, double px, double py, double pz,
+                                               double* __restrict__ chi, double* __restrict__ gx, double* __restrict__ gy,
+                                               double* __restrict__ gz, int ptp, int p, const double* __restrict__ c2s)
+{
+    const int pk = gt.desc[4 * g], poff = gt.desc[4 * g + 1], coff = gt.desc[4 * g + 2], ao12 = gt.desc[4 * g + 3];
+    const int ao0 = pk & 0xfff, l = (pk >> 12) & 0xf, at = (pk >> 16) & 0xff, nc = (pk >> 24) & 0x3, np = (pk >> 26) & 0x3f;
+    const double dx = px - xyz[3 * at], dy = py - xyz[3 * at + 1], dz = pz - xyz[3 * at + 2];
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    const double* e = gt.exps + poff;
+    const double* c = gt.coefs + coff;
+    double rad[XC_GROUP_MAX], drad[XC_GROUP_MAX];
+#pragma unroll
+    for (int k = 0; k < XC_GROUP_MAX; ++k) { rad[k] = 0.0; drad[k] = 0.0; }
+    for (int i = 0; i < np; ++i) {
+        const double ei = e[i];
+        const double ar2 = ei * r2;
+        if (ar2 < XC_EXP_CUTOFF) {
+            const double ex = exp(-ar2), m2e = -2.0 * ei;
+#pragma unroll
+            for (int k = 0; k < XC_GROUP_MAX; ++k) {
+                if (k < nc) {
+                    const double t = c[k * np + i] * ex;
+                    rad[k] += t; drad[k] += m2e * t;
+                }
+            }
+        }
+    }
+    emit_shell<GGA>(l, ao0, dx, dy, dz, rad[0], drad[0], chi, gx, gy, gz, ptp, p, c2s);
+    if (nc > 1) emit_shell<GGA>(l, ao12 & 0xffff, dx, dy, dz, rad[1], drad[1], chi, gx, gy, gz, ptp, p, c2s);
+    if (nc > 2) emit_shell<GGA>(l, ao12 >> 16, dx, dy, dz, rad[2], drad[2], chi, gx, gy, gz, ptp, p, c2s);
 }
 
 // zero rows of a group for a point beyond the grid
@@ -649,6 +697,7 @@ static void xc_mfma_launch(const BatchView& bv, int oa, hipStream_t s)
 // (lane = point on wave 0 while the other workgroups of the CU compute), and n up to 144 uses the matrix cores
 // (benzene/cc-pVDZ n = 114, def2-TZVP water dimer n = 86).  Same arithmetic as mqc_libcint_xc.F90:796-927.
 constexpr int XV_NW = 4;
+constexpr bool XC_TWO_PASS = false;
 // MQC_HIP_XC_PROBE (timing experiments only, results are then meaningless): bit 0 skips the AO slab evaluation, bit 1 the
 // X = D chi jobs, bit 2 the functional (constants instead), bit 3 the accumulation A += a chi^T
 __device__ int g_xc_probe = 0;
@@ -656,14 +705,14 @@ __device__ int g_xc_probe = 0;
 template <bool GGA, int PT, int JMAX, int OCC>
 __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, int only_active)
 {
-    // A SUPER-TILE is 256 points = one per thread.  Pass 1 walks its sub-tiles of PT points (AO slab, X = D chi,
-    // rho / grad rho into LDS), then ALL 256 threads evaluate the functional, one point each -- at full lane and
-    // wave utilisation instead of PT lanes of one wave while three waves wait (that serial section was half of a
-    // tile's critical path) -- and pass 2 walks the sub-tiles again (AO slab rebuilt, a = ..., A += a chi^T).
+    // One tile = PT points: AO slab -> X = D chi, rho / grad rho -> functional (one lane per point) -> a -> A += a chi^T.
+    // (XC_TWO_PASS builds a 256-point super-tile in two passes so that the functional runs at full width; timing probes
+    // showed the functional to be ~0 % of the kernel and the AO slab 57 %, so rebuilding the slab costs far more than
+    // the full-width functional saves: measured 2.09 s against 1.99 s per evaluation.  Kept for the record, off.)
     extern __shared__ double lds[];
     const int f = blockIdx.y;
     if (only_active && bv.istate[4 * f] == ST_DONE) return;
-    constexpr int RS = PT + 1, PT16 = PT / 16, SUPER = 64 * XV_NW, NSUB = SUPER / PT;
+    constexpr int RS = PT + 1, PT16 = PT / 16, NTHR = 64 * XV_NW, SUPER = XC_TWO_PASS ? NTHR : PT, NSUB = SUPER / PT;
     const int n = bv.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lo = lane & 15, hi = lane >> 4;
     const int NT16 = (n + 15) >> 4, NP = NT16 << 4, KS = NP >> 2;
@@ -675,12 +724,27 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
     double* gz = gy + (GGA ? (size_t)NP * RS : 0);
     double* red = gz + (GGA ? (size_t)NP * RS : 0);           // [SUPER][4] rho, grad rho sums of the super-tile
     double* coef = red + 4 * SUPER;                           // [SUPER][4] w v_rho / 2, 2 w v_sigma grad rho
+    double* tab = coef + 4 * SUPER;                           // radial-group tables: desc ints, exponents, coefficients
+    const int ng = tp.ngroup, ngp = tp.gprim_total, ngc = tp.gcoef_total;
+    int* tdesc = (int*)tab;
+    double* texps = tab + 2 * ng;
+    double* tcoefs = texps + ngp;
     const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
     const double* __restrict__ D = bv.D + (size_t)f * n * n;
     const double* __restrict__ wts = gd.weights + (size_t)f * gd.npts;
 
     // rows n..NP-1 stay zero for the whole kernel; the sums start at zero
-    for (int idx = tid; idx < (GGA ? 4 : 2) * NP * RS + 8 * SUPER; idx += SUPER) lds[idx] = 0.0;
+    for (int idx = tid; idx < (GGA ? 4 : 2) * NP * RS + 8 * SUPER; idx += NTHR) lds[idx] = 0.0;
+    for (int g = tid; g < ng; g += NTHR) {
+        const int sh0 = tp.grp_first[g], nc = tp.grp_count[g], npg = tp.grp_nprim[g];
+        tdesc[4 * g] = tp.sh_aoff[sh0] | (tp.sh_l[sh0] << 12) | (tp.sh_atom[sh0] << 16) | (nc << 24) | (npg << 26);
+        tdesc[4 * g + 1] = tp.grp_poff[g];
+        tdesc[4 * g + 2] = tp.grp_coff[g];
+        tdesc[4 * g + 3] = (nc > 1 ? tp.sh_aoff[sh0 + 1] : 0) | ((nc > 2 ? tp.sh_aoff[sh0 + 2] : 0) << 16);
+    }
+    for (int idx = tid; idx < ngp; idx += NTHR) texps[idx] = tp.gexps[idx];
+    for (int idx = tid; idx < ngc; idx += NTHR) tcoefs[idx] = tp.gcoefs[idx];
+    const GroupTables gt{tdesc, texps, tcoefs};
     v4f64 vacc[JMAX];
 #pragma unroll
     for (int j = 0; j < JMAX; ++j) vacc[j] = (v4f64){0.0, 0.0, 0.0, 0.0};
@@ -691,13 +755,13 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
     auto ao_slab = [&](int g0) {
         if (probe & 1) return;
         // AO values (and gradients) of PT points: (radial group, point) items, point fastest
-        for (int idx = tid; idx < tp.ngroup * PT; idx += SUPER) {
+        for (int idx = tid; idx < tp.ngroup * PT; idx += NTHR) {
             const int rg = idx / PT, p = idx - rg * PT;
             const int g = g0 + p;
             if (g < gd.npts) {
                 const int oa = gd.pt_atom[g], it = gd.pt_tmpl[g];
-                eval_group<GGA>(tp, xyz, rg, xyz[3 * oa] + gd.tmpl_xyz[3 * it], xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1],
-                                xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2], chi, gx, gy, gz, RS, p, bv.c2s);
+                eval_group_lds<GGA>(gt, xyz, rg, xyz[3 * oa] + gd.tmpl_xyz[3 * it], xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1],
+                                    xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2], chi, gx, gy, gz, RS, p, bv.c2s);
             } else {
                 zero_group<GGA>(tp, rg, chi, gx, gy, gz, RS, p);
             }
@@ -720,11 +784,19 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
                 const int mu_a = 16 * mt + lo;
                 const double* __restrict__ drow = D + (size_t)mu_a * n;
                 const bool row_ok = mu_a < n;
-                for (int ks = 0; ks < KS; ++ks) {
-                    const int nu = 4 * ks + hi;
-                    const double a = (row_ok && nu < n) ? drow[nu] : 0.0;
-                    const double b = chi[nu * RS + 16 * pt + lo];
-                    xacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, xacc, 0, 0, 0);
+                // eight k-steps at a time: the density elements (global, L1/L2) and the AO values (LDS) of a batch are all
+                // in flight before the MFMAs that consume them -- one load per MFMA made the loop a chain of L2 latencies
+                for (int k0 = 0; k0 < KS; k0 += 8) {
+                    double av[8], bw[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int nu = 4 * (k0 + u) + hi;
+                        const bool ok = (k0 + u < KS) && row_ok && nu < n;
+                        av[u] = ok ? drow[nu] : 0.0;
+                        bw[u] = (k0 + u < KS) ? chi[nu * RS + 16 * pt + lo] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) xacc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bw[u], xacc, 0, 0, 0);
                 }
                 double rho = 0.0, rx = 0.0, ry = 0.0, rz = 0.0;
 #pragma unroll
@@ -749,7 +821,7 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
             __syncthreads();
         }
         // ---- the functional: thread = point
-        {
+        if (tid < SUPER) {
             const int p = tid;
             double* rp = red + 4 * p;
             const double rho = rp[0], rx = 2.0 * rp[1], ry = 2.0 * rp[2], rz = 2.0 * rp[3];
@@ -771,10 +843,9 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
             const int g0 = s0 + sub * PT;
             if (g0 >= gd.npts) break;
             __syncthreads();          // coef written / the previous sub-tile's MFMA reads are done
-            ao_slab(g0);
-            __syncthreads();
+            if (NSUB > 1) { ao_slab(g0); __syncthreads(); }       // single pass: the slab of pass 1 is still in LDS
             // a[mu][p] = w v_rho / 2 chi + 2 w v_sigma grad rho . grad chi, written over gx
-            for (int idx = tid; idx < n * PT; idx += SUPER) {
+            for (int idx = tid; idx < n * PT; idx += NTHR) {
                 const int mu = idx / PT, p = idx - mu * PT;
                 const int o = mu * RS + p;
                 const double* cp = coef + 4 * (sub * PT + p);
@@ -826,10 +897,14 @@ template <bool GGA, int PT, int JMAX, int OCC>
 static void xc_tile_launch(const BatchView& bv, int oa, hipStream_t s)
 {
     const int np = ((bv.n + 15) / 16) * 16;
-    const size_t lds = sizeof(double) * ((size_t)(GGA ? 4 : 2) * np * (PT + 1) + 8 * 64 * XV_NW);
+    // + radial-group tables: 2 doubles of descriptor per group, the exponents and up to XC_GROUP_MAX coefficient rows;
+    // groups <= shells <= n, primitives per group <= 63 (descriptor field); bounded by the topology's own totals
+    const size_t tab = 2 * (size_t)bv.topo.ngroup + (size_t)bv.topo.gprim_total + (size_t)bv.topo.gcoef_total + 8;
+    const size_t lds = sizeof(double) * ((size_t)(GGA ? 4 : 2) * np * (PT + 1) + 8 * (XC_TWO_PASS ? 64 * XV_NW : PT) + tab);
     auto kern = xc_tile_kernel<GGA, PT, JMAX, OCC>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int ntiles = (bv.grid.npts + 64 * XV_NW - 1) / (64 * XV_NW);      // super-tiles of 256 points
+    const int tile_pts = XC_TWO_PASS ? 64 * XV_NW : PT;
+    const int ntiles = (bv.grid.npts + tile_pts - 1) / tile_pts;
     int gx = (6144 + bv.nfrag - 1) / bv.nfrag;       // ~3 workgroups per CU x 8 in flight over the batch; many tiles each
     if (gx > ntiles) gx = ntiles;
     if (gx < 1) gx = 1;
