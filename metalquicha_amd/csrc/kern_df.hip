@@ -204,6 +204,174 @@ __global__ void __launch_bounds__(DF_NT) df_cholesky_kernel(BatchView bv)
     }
 }
 
+// The same factorisation and inverse, blocked 16 x 16 on the FP64 matrix cores (default; MQC_HIP_DF_CHOL_V1=1 runs the
+// kernel above).  Left-looking by block columns kb:
+//   panel   P[rt] = M[rt][kb] - sum_{jb<kb} L[rt][jb] L[kb][jb]^T      MFMA jobs (row tile rt >= kb), result to LDS
+//   factor  the 16 x 16 diagonal block in LDS (16 rank-1 steps), its triangular inverse Dinv (one column per lane)
+//   solve   L[rt][kb] = P[rt] Dinv^T for rt > kb                        MFMA, 4 k-steps per tile
+// then L^{-1} by block rows:  X[rb][cb] = -Dinv[rb] sum_{cb<=sb<rb} L[rb][sb] X[sb][cb]  -- the accumulator of the inner
+// product is already in B-operand layout for the product with Dinv (C/D row = hi + 4r  <->  B k = 4 ks + hi).
+// Rows and columns beyond na behave as an identity block, so the last, ragged block needs no special code.
+// The unblocked kernel re-reads the trailing matrix from L2 na times (87 GB for 2016 dimers) and its inverse walks
+// O(na^3) dependent loads: 28 ms; this one moves each block O(nb) times.
+__global__ void __launch_bounds__(DF_NT) df_cholesky_mfma_kernel(BatchView bv)
+{
+    extern __shared__ double lds[];
+    const int f = blockIdx.x, tid = threadIdx.x, na = bv.naux;
+    const int lane = tid & 63, wave = tid >> 6, lo = lane & 15, hi = lane >> 4;
+    const int nb = (na + 15) >> 4, NP = nb << 4;
+    double* M = bv.df_metric + (size_t)f * na * na;
+    double* Li = bv.df_linv + (size_t)f * na * na;
+    double* save = bv.df_work + (size_t)f * na * na;
+    double* P = lds;                   // [NP][16] panel of the current block column
+    double* Dg = P + (size_t)NP * 16;  // [16][17] diagonal block
+    double* Di = Dg + 16 * 17;         // [16][17] its inverse
+    __shared__ double s_red[DF_NT / 64];
+    __shared__ int s_bad;
+    if (tid == 0) s_bad = 0;
+    for (int i = tid; i < na; i += DF_NT) save[i] = M[(size_t)i * na + i];
+    __syncthreads();
+    auto Lat = [&](int r, int c) -> double { return (r < na && c < na) ? M[(size_t)r * na + c] : (r == c ? 1.0 : 0.0); };
+
+    for (int kb = 0; kb < nb; ++kb) {
+        // ---- panel update
+        for (int rt = kb + wave; rt < nb; rt += DF_NT / 64) {
+            v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+            for (int jb = 0; jb < kb; ++jb) {
+                double a[4], b[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    a[ks] = Lat(16 * rt + lo, 16 * jb + 4 * ks + hi);
+                    b[ks] = Lat(16 * kb + lo, 16 * jb + 4 * ks + hi);
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * rt + hi + 4 * r, col = 16 * kb + lo;
+                // block column kb of M is still the original metric (left-looking: it is written only after this step), and
+                // so is the upper triangle, which nothing ever writes: the diagonal tile reads symmetric values
+                const double m = Lat(row, col);
+                P[(size_t)row * 16 + lo] = m - acc[r];
+            }
+        }
+        __syncthreads();
+        // ---- diagonal block: copy (lower part is authoritative), factor, invert
+        for (int idx = tid; idx < 256; idx += DF_NT) {
+            const int i = idx >> 4, j = idx & 15;
+            Dg[i * 17 + j] = (i >= j) ? P[(size_t)(16 * kb + i) * 16 + j] : 0.0;
+            Di[i * 17 + j] = 0.0;
+        }
+        __syncthreads();
+        for (int k = 0; k < 16; ++k) {
+            if (tid == 0) {
+                const double akk = Dg[k * 17 + k];
+                const bool pad = 16 * kb + k >= na;
+                if (!pad && !(akk > DF_PIVOT_FLOOR)) s_bad = 1;
+                Dg[k * 17 + k] = sqrt((akk > DF_PIVOT_FLOOR) ? akk : 1.0);
+            }
+            __syncthreads();
+            const double dk = Dg[k * 17 + k];
+            if (tid < 16 && tid > k) Dg[tid * 17 + k] /= dk;
+            __syncthreads();
+            {
+                const int i = tid >> 4, j = tid & 15;
+                if (i >= j && j > k) Dg[i * 17 + j] -= Dg[i * 17 + k] * Dg[j * 17 + k];
+            }
+            __syncthreads();
+        }
+        if (tid < 16) {
+            // column tid of Dinv by forward substitution
+            const int c = tid;
+            for (int r = c; r < 16; ++r) {
+                double sum = (r == c) ? 1.0 : 0.0;
+                for (int t = c; t < r; ++t) sum -= Dg[r * 17 + t] * Di[t * 17 + c];
+                Di[r * 17 + c] = sum / Dg[r * 17 + r];
+            }
+        }
+        __syncthreads();
+        // diagonal block of L and of L^{-1} to global (lower parts only)
+        for (int idx = tid; idx < 256; idx += DF_NT) {
+            const int i = idx >> 4, j = idx & 15;
+            const int row = 16 * kb + i, col = 16 * kb + j;
+            if (i >= j && row < na && col < na) { M[(size_t)row * na + col] = Dg[i * 17 + j]; Li[(size_t)row * na + col] = Di[i * 17 + j]; }
+        }
+        // ---- solve the rows below: L[rt][kb] = P[rt] Dinv^T
+        for (int rt = kb + 1 + wave; rt < nb; rt += DF_NT / 64) {
+            v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const double a = P[(size_t)(16 * rt + lo) * 16 + 4 * ks + hi];
+                const double b = Di[lo * 17 + 4 * ks + hi];          // B[k][j] = Dinv[j][k]
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * rt + hi + 4 * r, col = 16 * kb + lo;
+                if (row < na && col < na) M[(size_t)row * na + col] = acc[r];
+            }
+        }
+        __syncthreads();
+    }
+    // ---- L^{-1} by block rows (diagonal blocks are in place)
+    double fro = 0.0;
+    for (int rb = 0; rb < nb; ++rb) {
+        for (int cb = wave; cb < rb; cb += DF_NT / 64) {
+            v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+            for (int sb = cb; sb < rb; ++sb) {
+                double a[4], b[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    a[ks] = Lat(16 * rb + lo, 16 * sb + 4 * ks + hi);
+                    const int xr = 16 * sb + 4 * ks + hi, xc = 16 * cb + lo;
+                    // X[sb][cb]: lower-triangular inverse; inside the diagonal block only xr >= xc is stored
+                    b[ks] = (xr < na && xc < na && xr >= xc) ? Li[(size_t)xr * na + xc] : ((xr == xc) ? 1.0 : 0.0);
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
+            }
+            v4f64 x = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int dr = 16 * rb + lo, dc = 16 * rb + 4 * ks + hi;
+                const double a = (dr < na && dc < na && dr >= dc) ? Li[(size_t)dr * na + dc] : ((dr == dc) ? 1.0 : 0.0);
+                x = __builtin_amdgcn_mfma_f64_16x16x4f64(a, -acc[ks], x, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * rb + hi + 4 * r, col = 16 * cb + lo;
+                if (row < na && col < na) { Li[(size_t)row * na + col] = x[r]; fro += x[r] * x[r]; }
+            }
+        }
+        __syncthreads();
+    }
+    // diagonal blocks' share of the Frobenius norm
+    for (int idx = tid; idx < nb * 256; idx += DF_NT) {
+        const int b_ = idx >> 8, i = (idx >> 4) & 15, j = idx & 15;
+        const int row = 16 * b_ + i, col = 16 * b_ + j;
+        if (i >= j && row < na && col < na) { const double v = Li[(size_t)row * na + col]; fro += v * v; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) fro += __shfl_xor(fro, off, 64);
+    if (lane == 0) s_red[wave] = fro;
+    __syncthreads();
+    if (tid == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < DF_NT / 64; ++w) tot += s_red[w];
+        const bool safe = !s_bad && tot > 0.0 && (1.0 / tot) > 2.0 * DF_PIVOT_FLOOR;
+        bv.scal[(size_t)f * 8 + 7] = safe ? 0.0 : 1.0;
+        s_bad = safe ? 0 : 1;
+    }
+    __syncthreads();
+    if (s_bad) {
+        for (int i = wave; i < na; i += DF_NT / 64)
+            for (int j = lane; j < i; j += 64) M[(size_t)i * na + j] = M[(size_t)j * na + i];
+        __syncthreads();
+        for (int i = tid; i < na; i += DF_NT) M[(size_t)i * na + i] = save[i];
+    }
+}
+
 // Eigen path for flagged fragments: the reference's J^{-1/2} = U s^{-1/2} U^T over eigenvalues > 1e-10.
 // One-sided (Hestenes) Jacobi on the ROWS of B = V^T M: plane rotations make the rows orthogonal; then row p of V^T is
 // eigenvector p and lambda_p = b_p . v_p.  Rows are contiguous, a wave owns a pair of rows, the pairs of one round of
@@ -673,7 +841,17 @@ void launch_df_build(const BatchView& bv, const Topology& topo, const Topology& 
 #define DF2(p, q) df2c_launch<p, q>(bv, t2[p][q], d + off, s); off += t2[p][q].size();
     DF2(0, 0) DF2(1, 0) DF2(1, 1) DF2(2, 0) DF2(2, 1) DF2(2, 2) DF2(3, 0) DF2(3, 1) DF2(3, 2) DF2(3, 3)
 #undef DF2
-    hipLaunchKernelGGL(df_cholesky_kernel, dim3(bv.nfrag), dim3(DF_NT), sizeof(double) * (size_t)(bv.naux + 8), s, bv);
+    {
+        static const bool v1 = [] { const char* e = std::getenv("MQC_HIP_DF_CHOL_V1"); return e && e[0] == '1'; }();
+        const size_t npad = (size_t)((bv.naux + 15) / 16) * 16;
+        const size_t lds_m = sizeof(double) * (npad * 16 + 2 * 16 * 17 + 8);
+        if (v1 || lds_m > 150 * 1024) {
+            hipLaunchKernelGGL(df_cholesky_kernel, dim3(bv.nfrag), dim3(DF_NT), sizeof(double) * (size_t)(bv.naux + 8), s, bv);
+        } else {
+            (void)hipFuncSetAttribute((const void*)df_cholesky_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
+            hipLaunchKernelGGL(df_cholesky_mfma_kernel, dim3(bv.nfrag), dim3(DF_NT), lds_m, s, bv);
+        }
+    }
     hipLaunchKernelGGL(df_metric_eig_kernel, dim3(bv.nfrag), dim3(DF_NT), 0, s, bv);      // flagged fragments only
     {
         const int jobs = ((bv.naux + 15) / 16) * ((bv.npair + 15) / 16);

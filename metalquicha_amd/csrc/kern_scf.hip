@@ -471,12 +471,14 @@ __host__ __device__ inline int diis_slot_of_age(int newest, int n_stored, int ma
 
 // DIIS weights, oldest first, from the slot-indexed overlap cache: the reference's
 // diis_coefficients + solve_diis (mqc_diis.f90:164-273) transcribed operation for operation.
+// aug: (DIIS_MAX + 1) x (DIIS_MAX + 2) doubles of workspace supplied by the caller (LDS in the kernels: a private array
+// indexed at run time would live in scratch memory)
+constexpr int DIIS_AUG = (DIIS_MAX + 1) * (DIIS_MAX + 2);
 __host__ __device__ inline bool diis_solve(const double* overlap /* [maxv*maxv] slot coords */, int newest,
-                                           int n_stored, int max_vectors, double* coef /* n_stored+1 */)
+                                           int n_stored, int max_vectors, double* coef /* n_stored+1 */, double* aug)
 {
     if (n_stored < 2) return false;
     const int n = n_stored, N = n + 1;
-    double aug[(DIIS_MAX + 1) * (DIIS_MAX + 2)];
     const int ld = N + 1;
     for (int i = 0; i < N; ++i)
         for (int j = 0; j < N; ++j) aug[i * ld + j] = -1.0;
@@ -583,11 +585,10 @@ __global__ void __launch_bounds__(NT) scf_step_kernel(BatchView bv)
         double* coef = jl.rc;     // reuse LDS (>= 9 doubles: mp/2 >= 9 needs m >= 18; fall back to red otherwise)
         __shared__ double coef_s[DIIS_MAX + 2];
         __shared__ int ok_s;
+        __shared__ double aug_s[DIIS_AUG];
         if (tid == 0) {
-            double cf[DIIS_MAX + 2];
-            const bool ok = diis_solve(p.diis_b, newest, n_stored, maxv, cf);
+            const bool ok = diis_solve(p.diis_b, newest, n_stored, maxv, coef_s, aug_s);
             ok_s = ok ? 1 : 0;
-            for (int i = 0; i <= n_stored; ++i) coef_s[i] = cf[i];
             p.diis_state[0] = n_stored; p.diis_state[1] = newest;
         }
         (void)coef;
@@ -702,11 +703,10 @@ __global__ void __launch_bounds__(NT) scf_step_uhf_kernel(BatchView bv)
         __syncthreads();
         __shared__ double coef_u[DIIS_MAX + 2];
         __shared__ int ok_u;
+        __shared__ double aug_u[DIIS_AUG];
         if (tid == 0) {
-            double cf[DIIS_MAX + 2];
-            const bool ok = (iter >= UHF_DIIS_START) && diis_solve(pa.diis_b, newest, n_stored, maxv, cf);
+            const bool ok = (iter >= UHF_DIIS_START) && diis_solve(pa.diis_b, newest, n_stored, maxv, coef_u, aug_u);
             ok_u = ok ? 1 : 0;
-            if (ok) for (int i = 0; i <= n_stored; ++i) coef_u[i] = cf[i];
             pa.diis_state[0] = n_stored; pa.diis_state[1] = newest;
         }
         __syncthreads();
@@ -861,10 +861,11 @@ void launch_syev(int n, double* dA, double* dw, double* dV, hipStream_t s)
 
 __global__ void diis_coeff_kernel(int n_stored, const double* overlap, double* coef, int* ok)
 {
+    __shared__ double aug_s[DIIS_AUG];
+    __shared__ double cf[DIIS_MAX + 2];
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double cf[DIIS_MAX + 2];
         // the caller's matrix is already age-ordered: newest = n_stored, max_vectors = n_stored
-        const bool good = diis_solve(overlap, n_stored, n_stored, n_stored, cf);
+        const bool good = diis_solve(overlap, n_stored, n_stored, n_stored, cf, aug_s);
         *ok = good ? 1 : 0;
         for (int i = 0; i < n_stored; ++i) coef[i] = good ? cf[i] : 0.0;
     }

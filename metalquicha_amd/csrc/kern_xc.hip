@@ -702,7 +702,7 @@ constexpr bool XC_TWO_PASS = false;
 // X = D chi jobs, bit 2 the functional (constants instead), bit 3 the accumulation A += a chi^T
 __device__ int g_xc_probe = 0;
 
-template <bool GGA, int PT, int JMAX, int OCC>
+template <bool GGA, int PT, int JMAX, int OCC, bool DREG>
 __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, int only_active)
 {
     // One tile = PT points: AO slab -> X = D chi, rho / grad rho -> functional (one lane per point) -> a -> A += a chi^T.
@@ -745,6 +745,23 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
     for (int idx = tid; idx < ngp; idx += NTHR) texps[idx] = tp.gexps[idx];
     for (int idx = tid; idx < ngc; idx += NTHR) tcoefs[idx] = tp.gcoefs[idx];
     const GroupTables gt{tdesc, texps, tcoefs};
+    // DREG (n <= 64): the X = D chi jobs of a wave are the same (row tile, point tile) pairs in every tile, so the wave
+    // keeps its density fragments in registers for the whole kernel -- reading them from L2 per tile made the phase a
+    // chain of load latencies (probes: 30 % of the kernel for 10 % of its MFMA work)
+    constexpr int DJ = DREG ? 2 : 1, DK = DREG ? 16 : 1;
+    double dfrag[DJ][DK];
+    if (DREG) {
+#pragma unroll
+        for (int j = 0; j < DJ; ++j) {
+            const int job = wave + XV_NW * j;
+            const int mt = job / PT16;
+#pragma unroll
+            for (int ks = 0; ks < DK; ++ks) {
+                const int mu = 16 * mt + lo, nu = 4 * ks + hi;
+                dfrag[j][ks] = (job < NT16 * PT16 && mu < n && nu < n) ? D[(size_t)mu * n + nu] : 0.0;
+            }
+        }
+    }
     v4f64 vacc[JMAX];
 #pragma unroll
     for (int j = 0; j < JMAX; ++j) vacc[j] = (v4f64){0.0, 0.0, 0.0, 0.0};
@@ -778,12 +795,23 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
             ao_slab(g0);
             __syncthreads();
             // X = D chi, job = (row tile mt, point tile pt); rho and grad rho from the accumulator rows
-            for (int job = wave; job < NT16 * PT16 && !(probe & 2); job += XV_NW) {
+#pragma unroll 2
+            for (int jj = 0; jj < (DREG ? DJ : 64); ++jj) {
+                const int job = wave + XV_NW * jj;
+                if (job >= NT16 * PT16 || (probe & 2)) break;
                 const int mt = job / PT16, pt = job - mt * PT16;
                 v4f64 xacc = (v4f64){0.0, 0.0, 0.0, 0.0};
                 const int mu_a = 16 * mt + lo;
                 const double* __restrict__ drow = D + (size_t)mu_a * n;
                 const bool row_ok = mu_a < n;
+                if (DREG) {
+                    double bw[DK];
+#pragma unroll
+                    for (int ks = 0; ks < DK; ++ks) bw[ks] = (ks < KS) ? chi[(4 * ks + hi) * RS + 16 * pt + lo] : 0.0;
+#pragma unroll
+                    for (int ks = 0; ks < DK; ++ks)
+                        if (ks < KS) xacc = __builtin_amdgcn_mfma_f64_16x16x4f64(dfrag[jj < DJ ? jj : 0][ks], bw[ks], xacc, 0, 0, 0);
+                } else
                 // eight k-steps at a time: the density elements (global, L1/L2) and the AO values (LDS) of a batch are all
                 // in flight before the MFMAs that consume them -- one load per MFMA made the loop a chain of L2 latencies
                 for (int k0 = 0; k0 < KS; k0 += 8) {
@@ -893,7 +921,7 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
     }
 }
 
-template <bool GGA, int PT, int JMAX, int OCC>
+template <bool GGA, int PT, int JMAX, int OCC, bool DREG>
 static void xc_tile_launch(const BatchView& bv, int oa, hipStream_t s)
 {
     const int np = ((bv.n + 15) / 16) * 16;
@@ -901,7 +929,7 @@ static void xc_tile_launch(const BatchView& bv, int oa, hipStream_t s)
     // groups <= shells <= n, primitives per group <= 63 (descriptor field); bounded by the topology's own totals
     const size_t tab = 2 * (size_t)bv.topo.ngroup + (size_t)bv.topo.gprim_total + (size_t)bv.topo.gcoef_total + 8;
     const size_t lds = sizeof(double) * ((size_t)(GGA ? 4 : 2) * np * (PT + 1) + 8 * (XC_TWO_PASS ? 64 * XV_NW : PT) + tab);
-    auto kern = xc_tile_kernel<GGA, PT, JMAX, OCC>;
+    auto kern = xc_tile_kernel<GGA, PT, JMAX, OCC, DREG>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int tile_pts = XC_TWO_PASS ? 64 * XV_NW : PT;
     const int ntiles = (bv.grid.npts + tile_pts - 1) / tile_pts;
@@ -920,19 +948,19 @@ static bool xc_tile_dispatch(const BatchView& bv, int oa, hipStream_t s)
     const int nt = (bv.n + 15) / 16, jobs = (nt * nt + XV_NW - 1) / XV_NW;
     if (nt <= 4) {                       // n <= 64: 32-point tiles
         if (occ >= 3) {
-            if (jobs <= 1) xc_tile_launch<GGA, 32, 1, 3>(bv, oa, s);
-            else if (jobs <= 3) xc_tile_launch<GGA, 32, 3, 3>(bv, oa, s);
-            else xc_tile_launch<GGA, 32, 4, 3>(bv, oa, s);
+            if (jobs <= 1) xc_tile_launch<GGA, 32, 1, 3, true>(bv, oa, s);
+            else if (jobs <= 3) xc_tile_launch<GGA, 32, 3, 3, true>(bv, oa, s);
+            else xc_tile_launch<GGA, 32, 4, 3, true>(bv, oa, s);
         } else {
-            if (jobs <= 1) xc_tile_launch<GGA, 32, 1, 2>(bv, oa, s);
-            else if (jobs <= 3) xc_tile_launch<GGA, 32, 3, 2>(bv, oa, s);
-            else xc_tile_launch<GGA, 32, 4, 2>(bv, oa, s);
+            if (jobs <= 1) xc_tile_launch<GGA, 32, 1, 2, true>(bv, oa, s);
+            else if (jobs <= 3) xc_tile_launch<GGA, 32, 3, 2, true>(bv, oa, s);
+            else xc_tile_launch<GGA, 32, 4, 2, true>(bv, oa, s);
         }
         return true;
     }
-    if (jobs <= 9) xc_tile_launch<GGA, 16, 9, 1>(bv, oa, s);             // n <= 96
-    else if (jobs <= 16) xc_tile_launch<GGA, 16, 16, 1>(bv, oa, s);      // n <= 128
-    else if (jobs <= 21) xc_tile_launch<GGA, 16, 21, 1>(bv, oa, s);      // n <= 144
+    if (jobs <= 9) xc_tile_launch<GGA, 16, 9, 1, false>(bv, oa, s);             // n <= 96
+    else if (jobs <= 16) xc_tile_launch<GGA, 16, 16, 1, false>(bv, oa, s);      // n <= 128
+    else if (jobs <= 21) xc_tile_launch<GGA, 16, 21, 1, false>(bv, oa, s);      // n <= 144
     else return false;
     return true;
 }
