@@ -236,7 +236,7 @@ static int validate_options(const mqc_hip_scf_options_t& o, const Topology& topo
     if (!o.density_fitting && o.eri_mode == MQC_HIP_ERI_INCORE && !incore_supported(topo.nao)) { msg = "fragment too large for the in-core exact-ERI path (n_ao <= 116); use eri_mode auto/direct or density fitting"; return MQC_HIP_ERR_UNSUPPORTED; }
     if (topo.lmax > CLASS_LMAX) {
         const bool direct = !o.density_fitting && (o.eri_mode == MQC_HIP_ERI_DIRECT || (o.eri_mode == MQC_HIP_ERI_AUTO && !incore_supported(topo.nao)));
-        if (direct) { msg = "orbital f shells: the direct (integral-recomputing) Fock build covers s, p, d shells; this fragment is too large for the in-core path (n_ao <= 116)"; return MQC_HIP_ERR_UNSUPPORTED; }
+        (void)direct;       // f classes are digested by the LDS kernel: the direct build covers them
         if (o.density_fitting) { msg = "orbital f shells with density fitting are not available in this build of the HIP backend (three-centre kernels cover s, p, d orbital shells)"; return MQC_HIP_ERR_UNSUPPORTED; }
     }
     if (topo.nao > 140) { msg = "fragment too large for the LDS eigen-solver (n_ao <= 140)"; return MQC_HIP_ERR_UNSUPPORTED; }

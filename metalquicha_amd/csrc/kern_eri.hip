@@ -10,6 +10,22 @@
 
 namespace mqc {
 
+bool launch_digest_general(const BatchView& bv, int la, int lb, int lc, int ld, const int* d_list, int nq, const double* Q,
+                           const double* Dmax, double thresh, double* Jt, double* Kt, int only_active, hipStream_t s);   // kern_eri_general.hip
+
+// Which launcher forms a class.  The per-class register kernels cover s, p, d; two of them keep whole blocks in scratch
+// memory -- the one-shot / digest kernels of (dd|dp) and (dd|dd) hold a 648- or 1296-number block per LANE (5-23 KB of
+// private segment), and the runtime reserves scratch per hardware queue for a full device of such waves (12 GB for the
+// (dd|dd) digest): with the pools holding most of HBM that reservation fails and the process aborts
+// (HSA_STATUS_ERROR_OUT_OF_RESOURCES, recorded in round 1 under GPU_MAX_HW_QUEUES=8 and in round 2 inside the test
+// suite).  Those classes, the (dd| Schwarz bounds (11.5 KB) and everything with an f shell go through the
+// wave-cooperative LDS kernel, which has no private segment at all.
+static bool class_is_general(int la, int lb, int lc, int ld, int gen_from)
+{
+    if (la > CLASS_LMAX) return true;
+    return eri_uses_passes(la, lb, lc, ld) && la + lb + lc + ld >= gen_from;
+}
+
 #define ERI_DECL(a, b, c, d) \
     extern template void launch_eri_class<a, b, c, d>(const BatchView&, const int*, int, const int*, int, const double*, double, hipStream_t);
 #define SCHWARZ_DECL(a, b) \
@@ -286,11 +302,12 @@ void launch_eri_bounds(const BatchView& bv, const Topology& topo, double schwarz
 #define SCHWARZ_CASE(a, b)                                                                                                      \
     launch_schwarz_class<a, b>(bv, st.bucket[a][b].data(), (int)st.bucket[a][b].size() / 2, d_pairs + off, Q, st.side[rr++ % ERI_SIDE_STREAMS]); \
     off += st.bucket[a][b].size();
-    SCHWARZ_CASE(2, 2) SCHWARZ_CASE(0, 0) SCHWARZ_CASE(2, 1) SCHWARZ_CASE(1, 1)
+    SCHWARZ_CASE(0, 0) SCHWARZ_CASE(2, 1) SCHWARZ_CASE(1, 1)
     SCHWARZ_CASE(1, 0) SCHWARZ_CASE(2, 0)
 #undef SCHWARZ_CASE
-    for (int a = CLASS_LMAX + 1; a <= KERNEL_LMAX; ++a)
-        for (int b = 0; b <= a; ++b) {
+    // (dd| bounds (the pass kernel carries 11.5 KB of scratch per lane) and the f classes: LDS kernel
+    for (int a = CLASS_LMAX; a <= KERNEL_LMAX; ++a)
+        for (int b = (a == CLASS_LMAX ? CLASS_LMAX : 0); b <= a; ++b) {
             auto& bk = st.bucket[a][b];
             if (bk.empty()) continue;
             hipStream_t ss = st.side[rr++ % ERI_SIDE_STREAMS];
@@ -468,10 +485,9 @@ void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, h
     auto dense_stream = [&]() { if (!spread) return s; const int k = lane_of[li]; return k == 0 ? s : st.side[k - 1]; };
     // MQC_HIP_ERI_GENERAL=k: classes whose total angular momentum is >= k AND that would take the pass kernels go
     // through the wave-cooperative LDS kernel instead (no scratch, one wave per quartet and fragment); default: off
-    static const int gen_from = [] { const char* e = std::getenv("MQC_HIP_ERI_GENERAL"); return e ? std::atoi(e) : 99; }();
-    auto to_general = [&](const Topology::ClassList& c) {
-        return c.la > CLASS_LMAX || (eri_uses_passes(c.la, c.lb, c.lc, c.ld) && c.la + c.lb + c.lc + c.ld >= gen_from);
-    };
+    // default 7: (dd|dp) and (dd|dd); MQC_HIP_ERI_GENERAL=k moves the border (4 = every pass class, 99 = f shells only)
+    static const int gen_from = [] { const char* e = std::getenv("MQC_HIP_ERI_GENERAL"); return e ? std::atoi(e) : 7; }();
+    auto to_general = [&](const Topology::ClassList& c) { return class_is_general(c.la, c.lb, c.lc, c.ld, gen_from); };
 #define ERI_CASE(a, b, c, d_)                                                                                         \
     if (!general && cl.la == a && cl.lb == b && cl.lc == c && cl.ld == d_) {                                          \
         launch_eri_class<a, b, c, d_>(bv, d + L.dense_off, L.dense_n, nullptr, 0, Q, thresh, dense_stream());         \
@@ -581,13 +597,21 @@ void launch_direct_setup(const BatchView& bv, const Topology& topo, hipStream_t 
     launch_schwarz_class<a, b>(bv, bucket[a][b].data(), (int)bucket[a][b].size() / 2, d_list + off, Q, s);   \
     off += bucket[a][b].size();
     SCHWARZ_CASE(0, 0) SCHWARZ_CASE(1, 0) SCHWARZ_CASE(1, 1)
-    SCHWARZ_CASE(2, 0) SCHWARZ_CASE(2, 1) SCHWARZ_CASE(2, 2)
+    SCHWARZ_CASE(2, 0) SCHWARZ_CASE(2, 1)
 #undef SCHWARZ_CASE
+    for (int a = CLASS_LMAX; a <= KERNEL_LMAX; ++a)
+        for (int b = (a == CLASS_LMAX ? CLASS_LMAX : 0); b <= a; ++b) {
+            auto& bk = bucket[a][b];
+            if (bk.empty()) continue;
+            (void)hipMemcpyAsync(d_list + off, bk.data(), bk.size() * sizeof(int), hipMemcpyHostToDevice, s);
+            launch_schwarz_general(bv, a, b, d_list + off, (int)bk.size() / 2, Q, s);
+            off += bk.size();
+        }
     (void)hipStreamSynchronize(s);
 }
 
 #define DIG_CASE(a, b, c, d)                                                                          \
-    if (cl.la == a && cl.lb == b && cl.lc == c && cl.ld == d)                                         \
+    if (!general && cl.la == a && cl.lb == b && cl.lc == c && cl.ld == d)                             \
         launch_eri_digest_class<a, b, c, d>(bv, d_list + off, (int)cl.quartets.size() / 4, Q, Dmax, thresh, Jt, Kt, oa, s);
 
 void launch_jk_direct(const BatchView& bv, const Topology& topo, double thresh, bool only_active, hipStream_t s)
@@ -606,6 +630,10 @@ void launch_jk_direct(const BatchView& bv, const Topology& topo, double thresh, 
     hipLaunchKernelGGL(density_block_max_kernel, dim3((ns * ns + 255) / 256, bv.nfrag), dim3(256), 0, s, bv, Dmax);
     size_t off = 0;
     for (auto& cl : topo.classes) {
+        // classes whose digest kernel would hold the whole block in scratch (more than ERI_UNROLL_LIMIT numbers per lane),
+        // and the f classes: LDS kernel
+        const bool general = cl.la > CLASS_LMAX || ncart(cl.la) * ncart(cl.lb) * ncart(cl.lc) * ncart(cl.ld) > ERI_UNROLL_LIMIT;
+        if (general) launch_digest_general(bv, cl.la, cl.lb, cl.lc, cl.ld, d_list + off, (int)cl.quartets.size() / 4, Q, Dmax, thresh, Jt, Kt, oa, s);
         DIG_CASE(0, 0, 0, 0)
         DIG_CASE(1, 0, 0, 0) DIG_CASE(1, 0, 1, 0)
         DIG_CASE(1, 1, 0, 0) DIG_CASE(1, 1, 1, 0) DIG_CASE(1, 1, 1, 1)

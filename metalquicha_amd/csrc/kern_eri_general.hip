@@ -86,13 +86,22 @@ struct GenLayout {      // LDS offsets in doubles, computed by the host for the 
 
 }  // namespace
 
-enum { GEN_MODE_STORE = 0, GEN_MODE_SCHWARZ = 1 };
+enum { GEN_MODE_STORE = 0, GEN_MODE_SCHWARZ = 1, GEN_MODE_DIGEST = 2 };
+
+// what the direct (integral-recomputing) Fock build hands the digest mode
+struct GenDigest {
+    const double* Dmax;     // [nfrag][nshell][nshell] block maxima of |D|
+    double* Jt;             // [nfrag][n][n] accumulators (symmetrised afterwards)
+    double* Kt;
+    int only_active;
+};
 
 template <int MODE>
 __global__ void __launch_bounds__(64) eri_general_kernel(BatchView bv, int la, int lb, int lc, int ld, GenLayout lay,
                                                          const int* __restrict__ list, int nq,
                                                          const int* __restrict__ tasks, int ntasks,
-                                                         const double* __restrict__ Q, double thresh, double* __restrict__ Qout)
+                                                         const double* __restrict__ Q, double thresh, double* __restrict__ Qout,
+                                                         GenDigest dg)
 {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
@@ -107,7 +116,20 @@ __global__ void __launch_bounds__(64) eri_general_kernel(BatchView bv, int la, i
         const double* q = Q + (size_t)f * ns * ns;
         if (!(q[A * ns + B] * q[C * ns + D] >= thresh)) return;        // wave-uniform: the whole wave leaves
     }
-    if (MODE == GEN_MODE_STORE && lane == 0 && bv.eri_count) atomicAdd(bv.eri_count, 1ull);
+    double deg = 1.0;
+    if (MODE == GEN_MODE_DIGEST) {
+        // screening of build_fock_direct (mqc_libcint_direct.f90:266-288,533-551), wave-uniform
+        if (dg.only_active && bv.istate[4 * f] == ST_DONE) return;
+        const double sab = (A == B) ? 1.0 : 2.0, scd = (C == D) ? 1.0 : 2.0;
+        const bool same = (A == C && B == D) || (A == D && B == C);
+        deg = sab * scd * (same ? 1.0 : 2.0);
+        const double* q = Q + (size_t)f * ns * ns;
+        const double* dm = dg.Dmax + (size_t)f * ns * ns;
+        const double dj = 0.5 * fmax(dm[A * ns + B], dm[C * ns + D]);
+        const double dk = 0.125 * bv.exx * fmax(fmax(dm[A * ns + C], dm[A * ns + D]), fmax(dm[B * ns + C], dm[B * ns + D]));
+        if (!(q[A * ns + B] * q[C * ns + D] * deg * fmax(dj, dk) >= thresh)) return;
+    }
+    if (MODE != GEN_MODE_SCHWARZ && lane == 0 && bv.eri_count) atomicAdd(bv.eri_count, 1ull);
 
     const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
     const ShellRef sa = make_shell(tp, xyz, A), sb = make_shell(tp, xyz, B), sc = make_shell(tp, xyz, C), sd = make_shell(tp, xyz, D);
@@ -311,6 +333,53 @@ __global__ void __launch_bounds__(64) eri_general_kernel(BatchView bv, int la, i
         return;
     }
     const int oa = tp.sh_aoff[A], ob = tp.sh_aoff[B], oc = tp.sh_aoff[C], od = tp.sh_aoff[D];
+    if (MODE == GEN_MODE_DIGEST) {
+        // the six pre-contracted scatter updates of eri_digest_kernel, lanes over the output pair of each
+        const int n = bv.n;
+        const double* __restrict__ Dm = bv.D + (size_t)f * n * n;
+        double* __restrict__ J = dg.Jt + (size_t)f * n * n;
+        double* __restrict__ K = dg.Kt + (size_t)f * n * n;
+        const double wj = 4.0 * deg / 8.0, wk = 2.0 * deg / 8.0;
+#define GV(i, j, k, l) OUT[(((i) * nsb + (j)) * nsc + (k)) * nsd + (l)]
+        for (int idx = lane; idx < nsa * nsb; idx += 64) {
+            const int i = idx / nsb, j = idx - i * nsb;
+            double sm = 0.0;
+            for (int k = 0; k < nsc; ++k) for (int l = 0; l < nsd; ++l) sm += GV(i, j, k, l) * Dm[(oc + k) * n + od + l];
+            atomicAdd(&J[(oa + i) * n + ob + j], wj * sm);
+        }
+        for (int idx = lane; idx < nsc * nsd; idx += 64) {
+            const int k = idx / nsd, l = idx - k * nsd;
+            double sm = 0.0;
+            for (int i = 0; i < nsa; ++i) for (int j = 0; j < nsb; ++j) sm += GV(i, j, k, l) * Dm[(oa + i) * n + ob + j];
+            atomicAdd(&J[(oc + k) * n + od + l], wj * sm);
+        }
+        for (int idx = lane; idx < nsa * nsc; idx += 64) {
+            const int i = idx / nsc, k = idx - i * nsc;
+            double sm = 0.0;
+            for (int j = 0; j < nsb; ++j) for (int l = 0; l < nsd; ++l) sm += GV(i, j, k, l) * Dm[(ob + j) * n + od + l];
+            atomicAdd(&K[(oa + i) * n + oc + k], wk * sm);
+        }
+        for (int idx = lane; idx < nsa * nsd; idx += 64) {
+            const int i = idx / nsd, l = idx - i * nsd;
+            double sm = 0.0;
+            for (int j = 0; j < nsb; ++j) for (int k = 0; k < nsc; ++k) sm += GV(i, j, k, l) * Dm[(ob + j) * n + oc + k];
+            atomicAdd(&K[(oa + i) * n + od + l], wk * sm);
+        }
+        for (int idx = lane; idx < nsb * nsc; idx += 64) {
+            const int j = idx / nsc, k = idx - j * nsc;
+            double sm = 0.0;
+            for (int i = 0; i < nsa; ++i) for (int l = 0; l < nsd; ++l) sm += GV(i, j, k, l) * Dm[(oa + i) * n + od + l];
+            atomicAdd(&K[(ob + j) * n + oc + k], wk * sm);
+        }
+        for (int idx = lane; idx < nsb * nsd; idx += 64) {
+            const int j = idx / nsd, l = idx - j * nsd;
+            double sm = 0.0;
+            for (int i = 0; i < nsa; ++i) for (int k = 0; k < nsc; ++k) sm += GV(i, j, k, l) * Dm[(oa + i) * n + oc + k];
+            atomicAdd(&K[(ob + j) * n + od + l], wk * sm);
+        }
+#undef GV
+        return;
+    }
     const size_t np = (size_t)bv.npair;
     double* M = bv.eri + (size_t)f * np * np;
     for (int idx = lane; idx < nout; idx += 64) {
@@ -368,7 +437,23 @@ bool launch_eri_general(const BatchView& bv, int la, int lb, int lc, int ld, con
     auto kern = eri_general_kernel<GEN_MODE_STORE>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(64), lds, s, bv, la, lb, lc, ld, lay, d_list, nq, d_tasks, ntasks, Q, thresh,
-                       (double*)nullptr);
+                       (double*)nullptr, GenDigest{});
+    return true;
+}
+
+// Direct Fock build: the quartets of one class digested into J~ / K~ (same contract as launch_eri_digest_class<>)
+bool launch_digest_general(const BatchView& bv, int la, int lb, int lc, int ld, const int* d_list, int nq, const double* Q,
+                           const double* Dmax, double thresh, double* Jt, double* Kt, int only_active, hipStream_t s)
+{
+    const long total = (long)nq * bv.nfrag;
+    if (total == 0) return true;
+    const GenLayout lay = gen_layout(la, lb, lc, ld);
+    const size_t lds = sizeof(double) * (size_t)lay.total;
+    if (lds > 160 * 1024 || total > 0x7fffffffL) return false;
+    auto kern = eri_general_kernel<GEN_MODE_DIGEST>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(64), lds, s, bv, la, lb, lc, ld, lay, d_list, nq, (const int*)nullptr, 0, Q, thresh,
+                       (double*)nullptr, GenDigest{Dmax, Jt, Kt, only_active});
     return true;
 }
 
@@ -383,7 +468,7 @@ bool launch_schwarz_general(const BatchView& bv, int la, int lb, const int* d_pa
     auto kern = eri_general_kernel<GEN_MODE_SCHWARZ>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(64), lds, s, bv, la, lb, la, lb, lay, d_pairs, npairs, (const int*)nullptr, 0,
-                       (const double*)nullptr, 0.0, Qout);
+                       (const double*)nullptr, 0.0, Qout, GenDigest{});
     return true;
 }
 
