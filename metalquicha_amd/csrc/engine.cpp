@@ -19,6 +19,9 @@
 namespace mqc {
 const std::string& last_error_string();
 void eri_plan_lists(const BatchView& bv, const Topology& topo, hipStream_t s, const double* host_xyz);   // kern_eri.hip
+bool launch_gradient(const BatchView& bv, const Topology& topo, double* d_grad, double* work, int* d_lists, size_t list_capacity_ints,
+                     hipStream_t s, std::string& err);                                                      // kern_grad.hip
+static DevicePool g_grad_pool[2];
 
 static int stage_check(const char* stage)
 {
@@ -215,7 +218,13 @@ static int validate_options(const mqc_hip_scf_options_t& o, const Topology& topo
         if (!parse_functional(o.functional, tmp, e)) { msg = e; return MQC_HIP_ERR_UNSUPPORTED; }
         if (tmp.ncomp > 0 && topo.natoms > 64) { msg = "XC grid: fragments above 64 atoms are not supported yet"; return MQC_HIP_ERR_UNSUPPORTED; }
     }
-    if (o.want_gradient) { msg = "analytic gradients are not available in this build of the HIP backend"; return MQC_HIP_ERR_UNSUPPORTED; }
+    if (o.want_gradient) {
+        XcSpec tg; std::string eg;
+        parse_functional(o.functional, tg, eg);
+        if (tg.ncomp > 0) { msg = "analytic gradients are available for Hartree-Fock (restricted and unrestricted); the Kohn-Sham exchange-correlation term is not built yet"; return MQC_HIP_ERR_UNSUPPORTED; }
+        if (o.density_fitting) { msg = "analytic gradients are available on the exact-ERI path; the density-fitted two-electron derivative is not built yet"; return MQC_HIP_ERR_UNSUPPORTED; }
+        if (topo.lmax > 2) { msg = "analytic gradients cover s, p and d shells"; return MQC_HIP_ERR_UNSUPPORTED; }
+    }
     // restricted iff multiplicity 1, even electron count and not forced (mqc_cuest_driver.f90:127)
     const bool uhf = o.unrestricted || topo.multiplicity != 1 || (topo.nelec % 2) != 0;
     if (uhf) {
@@ -541,6 +550,23 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         std::vector<double> scal((size_t)nf * 8), eps((size_t)nf * n), dip((size_t)nf * 4);
         std::vector<int> ist((size_t)nf * 4);
         unsigned long long formed = 0;
+        // ---- analytic gradient (compute_scf_gradient, mqc_cuest_gradient.f90:91-175): device terms here, E_nuc' on the host
+        std::vector<double> hgrad;
+        if (opts.want_gradient) {
+            size_t lint = topo.pairs.size() + 64;
+            for (auto& cl : topo.classes) lint += cl.quartets.size();
+            const size_t nnh = (size_t)n * n;
+            const size_t bytes = sizeof(double) * ((size_t)nf * topo.natoms * 3 + 2 * (size_t)nf * nnh + 8) + sizeof(int) * (lint + 64);
+            char* gb = (char*)g_grad_pool[sl.id & 1].ensure(bytes);
+            if (!gb) return fail(MQC_HIP_ERR_DEVICE, "out of device memory (gradient)");
+            double* d_grad = (double*)gb;
+            double* gwork = d_grad + (((size_t)nf * topo.natoms * 3 + 7) & ~size_t(7));
+            int* glists = (int*)(gwork + 2 * (size_t)nf * nnh);
+            std::string gerr;
+            if (!launch_gradient(bv, topo, d_grad, gwork, glists, lint, s, gerr)) return fail(MQC_HIP_ERR_UNSUPPORTED, gerr);
+            hgrad.resize((size_t)nf * topo.natoms * 3);
+            HIP_CHECK_RET(hipMemcpyAsync(hgrad.data(), d_grad, sizeof(double) * hgrad.size(), hipMemcpyDeviceToHost, s));
+        }
         launch_dipole(bv, topo, s);
         std::vector<double> epsb;
         if (uhf) {
@@ -579,6 +605,22 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
             r->lumo = nocc < nmo ? eps[(size_t)f * n + nocc] : 0.0;
             r->has_orbitals = 1;
             r->n_alpha = nalpha; r->n_beta = nbeta; r->s_squared = 0.0;
+            if (opts.want_gradient && r->gradient) {
+                // + nuclear repulsion: dE_nuc/dR_A = -sum_B Z_A Z_B (R_A - R_B)/|R_AB|^3 (ghosts carry no charge)
+                const double* x = xyz[job.start + f];
+                for (int a = 0; a < topo.natoms; ++a) {
+                    double g3[3] = {hgrad[((size_t)f * topo.natoms + a) * 3], hgrad[((size_t)f * topo.natoms + a) * 3 + 1], hgrad[((size_t)f * topo.natoms + a) * 3 + 2]};
+                    for (int b = 0; b < topo.natoms; ++b) {
+                        if (b == a || topo.zeff[a] == 0.0 || topo.zeff[b] == 0.0) continue;
+                        const double dx = x[3 * a] - x[3 * b], dy = x[3 * a + 1] - x[3 * b + 1], dz = x[3 * a + 2] - x[3 * b + 2];
+                        const double r2 = dx * dx + dy * dy + dz * dz, r3 = r2 * std::sqrt(r2);
+                        const double zz = topo.zeff[a] * topo.zeff[b] / r3;
+                        g3[0] -= zz * dx; g3[1] -= zz * dy; g3[2] -= zz * dz;
+                    }
+                    r->gradient[3 * a] = g3[0]; r->gradient[3 * a + 1] = g3[1]; r->gradient[3 * a + 2] = g3[2];
+                }
+                r->has_gradient = 1;
+            }
             if (uhf) {
                 // <S^2> = S_z (S_z + 1) + n_beta - sum_ij |<a_i|S|b_j>|^2  (spin_contamination, mqc_libcint_rhf.f90)
                 const size_t nnh = (size_t)n * n;

@@ -1,0 +1,676 @@
+// kern_grad.hip -- analytic nuclear gradient of a converged Hartree-Fock SCF (restricted or unrestricted), exact ERIs.
+//
+// Terms and signs of compute_scf_gradient (backends/cuest/backend/mqc_cuest_gradient.f90:91-175) and of the CPU path
+// the goldens come from (libcint_scf_gradient, backends/libcint/mqc_libcint_gradient.f90:105-329):
+//     g = dE_nuc/dR                                            host arithmetic
+//       + sum D (dT/dR + dV/dR)                                grad1e_kernel   (basis-function and Hellmann-Feynman parts)
+//       - sum W dS/dR,   W = occ * sum_i eps_i C_i C_i^T       grad1e_kernel   (Pulay term, energy-weighted density)
+//       + sum_{unique quartets} Gamma . d(ab|cd)/dR            eri_grad_kernel
+// with, per unique shell quartet of degeneracy deg (1, 2, 4, 8 as in build_fock_direct),
+//     Gamma_ijkl = deg/8 [ 4 Dt_ij Dt_kl - 2 exx sum_spin (Ds_ik Ds_jl + Ds_il Ds_jk) ]     (Ds = D/2 when restricted).
+// Nothing here solves a response equation: the SCF energy is stationary in the orbitals.
+//
+// Kernel design = kern_eri_general.hip's: ONE WAVE per (shell pair | shell quartet, fragment), run-time angular momenta,
+// every table in the wave's LDS, lanes over Cartesian components.  A derivative with respect to the centre of a Cartesian
+// Gaussian raises and lowers its angular momentum, d/dA_x x_A^i e^{-a r_A^2} = 2a x_A^{i+1} (..) - i x_A^{i-1} (..), so the
+// Hermite tables are built one unit higher and the density factor (Gamma, D, W) is brought to the CARTESIAN basis
+// once per block; the derivative integrals are then contracted on the fly -- nine numbers per quartet (centres A, B, C;
+// D by translational invariance), never stored.  Shells up to d (the f classes have no gradient yet).
+#include "eri_kernels.hpp"
+
+namespace mqc {
+
+namespace {
+
+__device__ __forceinline__ int gr_hidx(int t, int u, int v) { return hidx(t, u, v); }
+
+// index of the Cartesian component (lx, ly, lz) inside shell l (inverse of cart_lmn)
+__device__ __forceinline__ int cart_index(int l, int lx, int lz)
+{
+    const int r = l - lx;
+    return r * (r + 1) / 2 + lz;
+}
+
+__device__ __forceinline__ double gr_c2s(const double* __restrict__ table, int l, int s, int c)
+{
+    if (l < 2) return s == c ? 1.0 : 0.0;
+    if (l == 2) return c2s_coef<2>(nullptr, s, c);
+    return table[c2s_table_offset(l) + s * ncart(l) + c];
+}
+
+// one axis of E^{ij}_t for i <= la, j <= lb: e[(i*(lb+1)+j)*(la+lb+1)+t]
+__device__ void gr_build_e(int la, int lb, double xpa, double xpb, double hp, double* __restrict__ e)
+{
+    const int nt = la + lb + 1;
+    for (int k = 0; k < (la + 1) * (lb + 1) * nt; ++k) e[k] = 0.0;
+    e[0] = 1.0;
+    for (int i = 0; i <= la; ++i) {
+        if (i > 0) {
+            const double* prev = e + ((i - 1) * (lb + 1)) * nt;
+            double* cur = e + (i * (lb + 1)) * nt;
+            for (int t = 0; t <= i; ++t) {
+                double v = xpa * prev[t];
+                if (t > 0) v += hp * prev[t - 1];
+                if (t + 1 <= i - 1) v += (t + 1) * prev[t + 1];
+                cur[t] = v;
+            }
+        }
+        for (int j = 1; j <= lb; ++j) {
+            const double* prev = e + (i * (lb + 1) + j - 1) * nt;
+            double* cur = e + (i * (lb + 1) + j) * nt;
+            for (int t = 0; t <= i + j; ++t) {
+                double v = xpb * prev[t];
+                if (t > 0) v += hp * prev[t - 1];
+                if (t + 1 <= i + j - 1) v += (t + 1) * prev[t + 1];
+                cur[t] = v;
+            }
+        }
+    }
+}
+
+// (t,u,v) table of the packed Hermite indices up to degree L, lanes round-robin
+__device__ void gr_fill_tuv(int L, int* tuv, int lane)
+{
+    int cnt = 0;
+    for (int N = 0; N <= L; ++N)
+        for (int tt = N; tt >= 0; --tt)
+            for (int uu = N - tt; uu >= 0; --uu, ++cnt)
+                if ((cnt & 63) == lane) tuv[gr_hidx(tt, uu, N - tt - uu)] = tt | (uu << 8) | ((N - tt - uu) << 16);
+}
+
+// Boys values F_n(T) (-2 alpha)^n, n = 0..L, into LDS (lane n takes order n; asymptotic branch on lane 0)
+__device__ void gr_boys(const double* __restrict__ table, int L, double alpha, double T, double* Fb, int lane)
+{
+    if (T < BOYS_TMAX) {
+        if (lane <= L) {
+            const int r = (int)(T * (1.0 / BOYS_STEP) + 0.5);
+            const double dt = r * BOYS_STEP - T;
+            const double* cc = table + r * BOYS_COLS + lane;
+            double acc = cc[7] * (1.0 / 5040.0);
+            acc = acc * dt + cc[6] * (1.0 / 720.0);
+            acc = acc * dt + cc[5] * (1.0 / 120.0);
+            acc = acc * dt + cc[4] * (1.0 / 24.0);
+            acc = acc * dt + cc[3] * (1.0 / 6.0);
+            acc = acc * dt + cc[2] * 0.5;
+            acc = acc * dt + cc[1];
+            acc = acc * dt + cc[0];
+            double sc = 1.0;
+            for (int n = 0; n < lane; ++n) sc *= -2.0 * alpha;
+            Fb[lane] = acc * sc;
+        }
+    } else if (lane == 0) {
+        const double inv = 1.0 / T;
+        const double et = exp(-T);
+        double fn = 0.886226925452758014 * sqrt(inv), sc = 1.0;
+        for (int n = 0; n <= L; ++n) {
+            Fb[n] = fn * sc;
+            fn = ((2 * n + 1) * fn - et) * (0.5 * inv);
+            sc *= -2.0 * alpha;
+        }
+    }
+}
+
+// R_{tuv} for t+u+v <= L by the level recursion; returns the buffer that holds level 0 (call with all lanes, Fb ready)
+__device__ const double* gr_hermite_r(int L, double X, double Y, double Z, const double* Fb, const int* tuv, double* R0, double* R1, int lane)
+{
+    double* prev = R0;
+    double* cur = R1;
+    if (lane == 0) prev[0] = Fb[L];
+    for (int n = L - 1; n >= 0; --n) {
+        __syncthreads();
+        const int cnt = nherm(L - n);
+        for (int h = lane; h < cnt; h += 64) {
+            const int pk = tuv[h];
+            const int tt = pk & 0xff, uu = (pk >> 8) & 0xff, vv = pk >> 16;
+            double val;
+            if (h == 0) val = Fb[n];
+            else if (tt > 0) {
+                val = X * prev[gr_hidx(tt - 1, uu, vv)];
+                if (tt > 1) val += (tt - 1) * prev[gr_hidx(tt - 2, uu, vv)];
+            } else if (uu > 0) {
+                val = Y * prev[gr_hidx(tt, uu - 1, vv)];
+                if (uu > 1) val += (uu - 1) * prev[gr_hidx(tt, uu - 2, vv)];
+            } else {
+                val = Z * prev[gr_hidx(tt, uu, vv - 1)];
+                if (vv > 1) val += (vv - 1) * prev[gr_hidx(tt, uu, vv - 2)];
+            }
+            cur[h] = val;
+        }
+        double* sw = prev; prev = cur; cur = sw;
+    }
+    __syncthreads();
+    return prev;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// W = occ sum_{i occupied} eps_i C_i C_i^T  (energy_weighted_density, mqc_cuest_gradient.f90:58-88); thread per element
+__global__ void grad_weighted_density_kernel(BatchView bv, double* __restrict__ Wout)
+{
+    const int f = blockIdx.y, n = bv.n;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * n) return;
+    const int i = idx / n, j = idx - i * n;
+    const size_t nn = (size_t)n * n;
+    double s = 0.0;
+    const double* C = bv.C + f * nn; const double* eps = bv.eps + (size_t)f * n;
+    if (bv.uhf) {
+        for (int o = 0; o < bv.nalpha; ++o) s += eps[o] * C[i * n + o] * C[j * n + o];
+        const double* Cb = bv.Cb + f * nn; const double* eb = bv.epsb + (size_t)f * n;
+        for (int o = 0; o < bv.nbeta; ++o) s += eb[o] * Cb[i * n + o] * Cb[j * n + o];
+    } else {
+        for (int o = 0; o < bv.nocc; ++o) s += eps[o] * C[i * n + o] * C[j * n + o];
+        s *= 2.0;
+    }
+    Wout[f * nn + idx] = s;
+}
+
+__global__ void grad_total_density_kernel(BatchView bv, double* __restrict__ Dtot)
+{
+    const size_t total = (size_t)bv.nfrag * bv.n * bv.n;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < total) Dtot[idx] = bv.D[idx] + bv.Db[idx];
+}
+
+// ---------------------------------------------------------------------------------------
+// One-electron terms: wave = (shell pair A >= B, fragment).  Dt = total density, W = energy-weighted density.
+//   g_A += w sum_ab [ Dt_ab (dT_ab/dA + dV_ab/dA) - W_ab dS_ab/dA ],   g_B -= (the S and T parts), g_B += w Dt dV/dB,
+//   g_C += w Dt_ab dV_ab/dC for every nucleus C,   dV/dB = -(dV/dA + dV/dC) per nucleus;   w = 1 (A == B) or 2.
+struct Grad1eLayout { int e, r0, r1, tuv, fb, dc, wc, total; };
+
+__global__ void __launch_bounds__(64) grad1e_kernel(BatchView bv, int la, int lb, Grad1eLayout lay, const int* __restrict__ pairs, int npairs,
+                                                    const double* __restrict__ Dtot, const double* __restrict__ Wmat,
+                                                    double* __restrict__ grad /* [nfrag][natoms][3] */)
+{
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const long t = blockIdx.x;
+    const int ip_ = (int)(t / bv.nfrag), f = (int)(t % bv.nfrag);
+    const int A = pairs[2 * ip_], B = pairs[2 * ip_ + 1];
+    const TopologyDev& tp = bv.topo;
+    const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
+    const ShellRef sa = make_shell(tp, xyz, A), sb = make_shell(tp, xyz, B);
+    const int atA = tp.sh_atom[A], atB = tp.sh_atom[B];
+    const int nca = ncart(la), ncb = ncart(lb), nsa = nsph(la), nsb = nsph(lb);
+    const int LA1 = la + 1, LB2 = lb + 2;               // table bounds: bra raised once, ket twice (kinetic)
+    const int nt = LA1 + LB2 + 1;
+    const int ne = (LA1 + 1) * (LB2 + 1) * nt;
+    const int LR = la + lb + 2;                          // Hermite order: raised bra + Hellmann-Feynman shift
+    double* E = lds + lay.e;                             // [3][ne]
+    double* R0 = lds + lay.r0; double* R1 = lds + lay.r1;
+    int* tuv = (int*)(lds + lay.tuv);
+    double* Fb = lds + lay.fb;
+    double* Dc = lds + lay.dc;                           // [nca][ncb] Cartesian density block
+    double* Wc = lds + lay.wc;
+    const int n = bv.n;
+    const size_t nn = (size_t)n * n;
+    const double* Dm = Dtot + f * nn; const double* Wm = Wmat + f * nn;
+    const int oa = tp.sh_aoff[A], ob = tp.sh_aoff[B];
+
+    gr_fill_tuv(LR, tuv, lane);
+    // density blocks to the Cartesian basis: Dc[ia][ib] = sum_ij c2s_a[i][ia] D[i][j] c2s_b[j][ib]
+    for (int idx = lane; idx < nca * ncb; idx += 64) {
+        const int ia = idx / ncb, ib = idx - ia * ncb;
+        double d = 0.0, w = 0.0;
+        for (int i = 0; i < nsa; ++i) {
+            const double ca = gr_c2s(bv.c2s, la, i, ia);
+            if (ca == 0.0) continue;
+            for (int j = 0; j < nsb; ++j) {
+                const double cb = gr_c2s(bv.c2s, lb, j, ib);
+                if (cb == 0.0) continue;
+                d += ca * cb * Dm[(size_t)(oa + i) * n + ob + j];
+                w += ca * cb * Wm[(size_t)(oa + i) * n + ob + j];
+            }
+        }
+        Dc[idx] = d; Wc[idx] = w;
+    }
+    __syncthreads();
+    const double wsym = (A == B) ? 1.0 : 2.0;
+    const double dabx = sa.x - sb.x, daby = sa.y - sb.y, dabz = sa.z - sb.z;
+    const double ab2 = dabx * dabx + daby * daby + dabz * dabz;
+    double gA[3] = {0.0, 0.0, 0.0}, gB[3] = {0.0, 0.0, 0.0};      // per-lane partial sums
+    double* gf = grad + (size_t)f * tp.natoms * 3;
+
+    for (int ipa = 0; ipa < sa.nprim; ++ipa)
+        for (int jpb = 0; jpb < sb.nprim; ++jpb) {
+            const double a = sa.exps[ipa], b = sb.exps[jpb], p = a + b, rp = 1.0 / p;
+            const double arg = a * b * rp * ab2;
+            if (!(arg < PRIM_EXP_CUTOFF)) continue;
+            const double kab = exp(-arg) * sa.coefs[ipa] * sb.coefs[jpb];
+            const double px = (a * sa.x + b * sb.x) * rp, py = (a * sa.y + b * sb.y) * rp, pz = (a * sa.z + b * sb.z) * rp;
+            __syncthreads();
+            if (lane < 3) {
+                const double pa = lane == 0 ? px - sa.x : (lane == 1 ? py - sa.y : pz - sa.z);
+                const double pb = lane == 0 ? px - sb.x : (lane == 1 ? py - sb.y : pz - sb.z);
+                gr_build_e(LA1, LB2, pa, pb, 0.5 * rp, E + lane * ne);
+            }
+            __syncthreads();
+            const double* Ex = E; const double* Ey = E + ne; const double* Ez = E + 2 * ne;
+            auto e0 = [&](const double* Eax, int i, int j) { return (i < 0 || j < 0) ? 0.0 : Eax[(i * (LB2 + 1) + j) * nt]; };
+            // 1-D kinetic factor t(i,j) = -2b(2j+1) s(i,j) + 4b^2 s(i,j+2) + j(j-1) s(i,j-2)
+            auto t1 = [&](const double* Eax, int i, int j) {
+                if (i < 0) return 0.0;
+                double v = -2.0 * b * (2 * j + 1) * e0(Eax, i, j) + 4.0 * b * b * e0(Eax, i, j + 2);
+                if (j >= 2) v += j * (j - 1) * e0(Eax, i, j - 2);
+                return v;
+            };
+            const double s3 = kab * M_PI * rp * sqrt(M_PI * rp);
+            // ---- overlap and kinetic derivatives with respect to A
+            for (int idx = lane; idx < nca * ncb; idx += 64) {
+                const int ia = idx / ncb, ib = idx - ia * ncb;
+                int ax, ay, az, bx, by, bz;
+                cart_lmn(la, ia, ax, ay, az);
+                cart_lmn(lb, ib, bx, by, bz);
+                const double sx = e0(Ex, ax, bx), sy = e0(Ey, ay, by), sz = e0(Ez, az, bz);
+                const double tx = t1(Ex, ax, bx), ty = t1(Ey, ay, by), tz = t1(Ez, az, bz);
+                // d/dA_x: f(ax) -> 2a f(ax+1) - ax f(ax-1) on the x factors only
+                const double dsx = 2.0 * a * e0(Ex, ax + 1, bx) - ax * e0(Ex, ax - 1, bx);
+                const double dsy = 2.0 * a * e0(Ey, ay + 1, by) - ay * e0(Ey, ay - 1, by);
+                const double dsz = 2.0 * a * e0(Ez, az + 1, bz) - az * e0(Ez, az - 1, bz);
+                const double dtx = 2.0 * a * t1(Ex, ax + 1, bx) - ax * t1(Ex, ax - 1, bx);
+                const double dty = 2.0 * a * t1(Ey, ay + 1, by) - ay * t1(Ey, ay - 1, by);
+                const double dtz = 2.0 * a * t1(Ez, az + 1, bz) - az * t1(Ez, az - 1, bz);
+                const double dS[3] = {dsx * sy * sz, sx * dsy * sz, sx * sy * dsz};
+                const double dT[3] = {-0.5 * (dtx * sy * sz + dsx * ty * sz + dsx * sy * tz),
+                                      -0.5 * (tx * dsy * sz + sx * dty * sz + sx * dsy * tz),
+                                      -0.5 * (tx * sy * dsz + sx * ty * dsz + sx * sy * dtz)};
+                const double dcw = Dc[idx], wcw = Wc[idx];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const double v = wsym * s3 * (dcw * dT[c] - wcw * dS[c]);
+                    gA[c] += v; gB[c] -= v;              // two-centre integrals: d/dB = -d/dA
+                }
+            }
+            // ---- nuclear attraction: basis-function part (A), operator part (nucleus C), B by invariance
+            const double pref0 = 2.0 * M_PI * rp * kab;
+            for (int at = 0; at < tp.natoms; ++at) {
+                const double zq = tp.zeff[at];
+                if (zq == 0.0) continue;
+                const double X = px - xyz[3 * at], Y = py - xyz[3 * at + 1], Z = pz - xyz[3 * at + 2];
+                __syncthreads();
+                gr_boys(bv.boys, LR, p, p * (X * X + Y * Y + Z * Z), Fb, lane);
+                __syncthreads();
+                const double* R = gr_hermite_r(LR, X, Y, Z, Fb, tuv, R0, R1, lane);
+                double vA[3] = {0.0, 0.0, 0.0}, vC[3] = {0.0, 0.0, 0.0};
+                for (int idx = lane; idx < nca * ncb; idx += 64) {
+                    const int ia = idx / ncb, ib = idx - ia * ncb;
+                    int ax, ay, az, bx, by, bz;
+                    cart_lmn(la, ia, ax, ay, az);
+                    cart_lmn(lb, ib, bx, by, bz);
+                    // V(a', b; shift) = sum_tuv Ex[a'x][bx][t] Ey[..][u] Ez[..][v] R[t+sx, u+sy, v+sz]
+                    auto vint = [&](int a0, int a1, int a2, int s0, int s1, int s2) {
+                        if (a0 < 0 || a1 < 0 || a2 < 0) return 0.0;
+                        const double* ex = Ex + (a0 * (LB2 + 1) + bx) * nt;
+                        const double* ey = Ey + (a1 * (LB2 + 1) + by) * nt;
+                        const double* ez = Ez + (a2 * (LB2 + 1) + bz) * nt;
+                        double s = 0.0;
+                        for (int tt = 0; tt <= a0 + bx; ++tt)
+                            for (int uu = 0; uu <= a1 + by; ++uu) {
+                                const double exy = ex[tt] * ey[uu];
+                                for (int vv = 0; vv <= a2 + bz; ++vv) s += exy * ez[vv] * R[gr_hidx(tt + s0, uu + s1, vv + s2)];
+                            }
+                        return s;
+                    };
+                    const double dcw = wsym * Dc[idx] * (-zq) * pref0;
+                    // basis function on A moves
+                    vA[0] += dcw * (2.0 * a * vint(ax + 1, ay, az, 0, 0, 0) - ax * vint(ax - 1, ay, az, 0, 0, 0));
+                    vA[1] += dcw * (2.0 * a * vint(ax, ay + 1, az, 0, 0, 0) - ay * vint(ax, ay - 1, az, 0, 0, 0));
+                    vA[2] += dcw * (2.0 * a * vint(ax, ay, az + 1, 0, 0, 0) - az * vint(ax, ay, az - 1, 0, 0, 0));
+                    // the nucleus moves: d/dC_x R_tuv(P - C) = -R_{t+1,u,v}
+                    vC[0] -= dcw * vint(ax, ay, az, 1, 0, 0);
+                    vC[1] -= dcw * vint(ax, ay, az, 0, 1, 0);
+                    vC[2] -= dcw * vint(ax, ay, az, 0, 0, 1);
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    gA[c] += vA[c];
+                    gB[c] -= vA[c] + vC[c];              // translational invariance of the three-centre integral
+                    const double tot = wave_sum(vC[c]);
+                    if (lane == 0 && tot != 0.0) atomicAdd(&gf[3 * at + c], tot);
+                }
+            }
+        }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double ta = wave_sum(gA[c]), tb = wave_sum(gB[c]);
+        if (lane == 0) {
+            if (ta != 0.0) atomicAdd(&gf[3 * atA + c], ta);
+            if (tb != 0.0) atomicAdd(&gf[3 * atB + c], tb);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Two-electron term: wave = (unique shell quartet, fragment).
+struct Grad2eLayout { int e_ab, e_cd, r0, r1, tuv, fb, gc, tmp, g0, gp, gm, total; };
+
+__global__ void __launch_bounds__(64) eri_grad_kernel(BatchView bv, int la, int lb, int lc, int ld, Grad2eLayout lay,
+                                                      const int* __restrict__ list, int nq, const double* __restrict__ Dtot,
+                                                      const double* __restrict__ Dbeta /* nullptr: restricted */,
+                                                      double* __restrict__ grad)
+{
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const long t = blockIdx.x;
+    const int iq = (int)(t / bv.nfrag), f = (int)(t % bv.nfrag);
+    const int A = list[4 * iq], B = list[4 * iq + 1], C = list[4 * iq + 2], D = list[4 * iq + 3];
+    const TopologyDev& tp = bv.topo;
+    const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
+    const ShellRef sa = make_shell(tp, xyz, A), sb = make_shell(tp, xyz, B), sc = make_shell(tp, xyz, C), sd = make_shell(tp, xyz, D);
+    const int atA = tp.sh_atom[A], atB = tp.sh_atom[B], atC = tp.sh_atom[C], atD = tp.sh_atom[D];
+    if (atA == atB && atB == atC && atC == atD) return;          // one centre: translational invariance, no force
+    const int nca = ncart(la), ncb = ncart(lb), ncc = ncart(lc), ncd = ncart(ld);
+    const int nsa = nsph(la), nsb = nsph(lb), nsc = nsph(lc), nsd = nsph(ld);
+    const int ncab = nca * ncb, nccd = ncc * ncd, nc4 = ncab * nccd;
+    // tables one unit higher on A, B and C
+    const int LA1 = la + 1, LB1 = lb + 1, LC1 = lc + 1;
+    const int ntb = LA1 + LB1 + 1, ntc = LC1 + ld + 1;
+    const int ne_ab = (LA1 + 1) * (LB1 + 1) * ntb, ne_cd = (LC1 + 1) * (ld + 1) * ntc;
+    const int lab = la + lb, lcd = lc + ld;
+    const int LR = lab + lcd + 1;
+    const int nh1 = nherm(lab + 1), nh0 = nherm(lab);
+    const int ncp = ncart(lc + 1) * ncd, ncm = (lc > 0 ? ncart(lc - 1) : 0) * ncd;
+    double* Eab = lds + lay.e_ab; double* Ecd = lds + lay.e_cd;
+    double* R0 = lds + lay.r0; double* R1 = lds + lay.r1;
+    int* tuv = (int*)(lds + lay.tuv);
+    double* Fb = lds + lay.fb;
+    double* GC = lds + lay.gc;          // [nc4] Gamma in the Cartesian basis
+    double* TMP = lds + lay.tmp;        // staging of the transform
+    double* G0 = lds + lay.g0;          // [nh1][nccd]  ket (lc, ld)
+    double* GP = lds + lay.gp;          // [nh0][ncp]   ket (lc+1, ld)
+    double* GM = lds + lay.gm;          // [nh0][ncm]   ket (lc-1, ld)
+    const int n = bv.n;
+    const size_t nn = (size_t)n * n;
+    const double* Dt = Dtot + f * nn;
+    const double* Db = Dbeta ? Dbeta + f * nn : nullptr;
+    const int oa = tp.sh_aoff[A], ob = tp.sh_aoff[B], oc = tp.sh_aoff[C], od = tp.sh_aoff[D];
+
+    gr_fill_tuv(LR, tuv, lane);
+    // ---- Gamma block in the spherical basis (into TMP), then four index transforms to Cartesian (-> GC)
+    {
+        const double sab = (A == B) ? 1.0 : 2.0, scd = (C == D) ? 1.0 : 2.0;
+        const bool same = (A == C && B == D) || (A == D && B == C);
+        const double w = sab * scd * (same ? 1.0 : 2.0) / 8.0;
+        const double exx = bv.exx;
+        for (int idx = lane; idx < nsa * nsb * nsc * nsd; idx += 64) {
+            int r = idx;
+            const int l = r % nsd; r /= nsd;
+            const int k = r % nsc; r /= nsc;
+            const int j = r % nsb;
+            const int i = r / nsb;
+            const int I = oa + i, J = ob + j, K = oc + k, Lx = od + l;
+            double g = 4.0 * Dt[(size_t)I * n + J] * Dt[(size_t)K * n + Lx];
+            if (Db) {
+                const double aik = Dt[(size_t)I * n + K] - Db[(size_t)I * n + K], ajl = Dt[(size_t)J * n + Lx] - Db[(size_t)J * n + Lx];
+                const double ail = Dt[(size_t)I * n + Lx] - Db[(size_t)I * n + Lx], ajk = Dt[(size_t)J * n + K] - Db[(size_t)J * n + K];
+                g -= 2.0 * exx * (aik * ajl + ail * ajk + Db[(size_t)I * n + K] * Db[(size_t)J * n + Lx] + Db[(size_t)I * n + Lx] * Db[(size_t)J * n + K]);
+            } else {
+                g -= exx * (Dt[(size_t)I * n + K] * Dt[(size_t)J * n + Lx] + Dt[(size_t)I * n + Lx] * Dt[(size_t)J * n + K]);
+            }
+            GC[idx] = w * g;
+        }
+        __syncthreads();
+        // sph -> cart on one index: out[pre][nc][post] = sum_s coef(s, c) in[pre][ns][post]
+        auto stage = [&](int l, int pre, int post, const double* in, double* out) {
+            const int nc = ncart(l), ns = nsph(l);
+            for (int idx = lane; idx < pre * nc * post; idx += 64) {
+                const int a = idx / (nc * post), rem = idx - a * (nc * post);
+                const int c = rem / post, r = rem - c * post;
+                double v = 0.0;
+                for (int s = 0; s < ns; ++s) {
+                    const double w2 = gr_c2s(bv.c2s, l, s, c);
+                    if (w2 != 0.0) v += w2 * in[(a * ns + s) * post + r];
+                }
+                out[idx] = v;
+            }
+            __syncthreads();
+        };
+        stage(ld, nsa * nsb * nsc, 1, GC, TMP);
+        stage(lc, nsa * nsb, ncd, TMP, GC);
+        stage(lb, nsa, ncc * ncd, GC, TMP);
+        stage(la, 1, ncb * ncc * ncd, TMP, GC);
+    }
+    const double dabx = sa.x - sb.x, daby = sa.y - sb.y, dabz = sa.z - sb.z;
+    const double ab2 = dabx * dabx + daby * daby + dabz * dabz;
+    const double dcdx = sc.x - sd.x, dcdy = sc.y - sd.y, dcdz = sc.z - sd.z;
+    const double cd2 = dcdx * dcdx + dcdy * dcdy + dcdz * dcdz;
+    constexpr double TWO_PI_25 = 34.986836655249725693;
+    double gA[3] = {0.0, 0.0, 0.0}, gB[3] = {0.0, 0.0, 0.0}, gCc[3] = {0.0, 0.0, 0.0};
+
+    for (int ip = 0; ip < sa.nprim; ++ip)
+        for (int jp = 0; jp < sb.nprim; ++jp) {
+            const double a = sa.exps[ip], b = sb.exps[jp], p = a + b, rp = 1.0 / p;
+            const double argab = a * b * rp * ab2;
+            if (!(argab < PRIM_EXP_CUTOFF)) continue;
+            const double kab = exp(-argab) * sa.coefs[ip] * sb.coefs[jp] * rp;
+            const double px = (a * sa.x + b * sb.x) * rp, py = (a * sa.y + b * sb.y) * rp, pz = (a * sa.z + b * sb.z) * rp;
+            __syncthreads();
+            if (lane < 3) {
+                const double pa = lane == 0 ? px - sa.x : (lane == 1 ? py - sa.y : pz - sa.z);
+                const double pb = lane == 0 ? px - sb.x : (lane == 1 ? py - sb.y : pz - sb.z);
+                gr_build_e(LA1, LB1, pa, pb, 0.5 * rp, Eab + lane * ne_ab);
+            }
+            for (int kp = 0; kp < sc.nprim; ++kp)
+                for (int lp = 0; lp < sd.nprim; ++lp) {
+                    const double c = sc.exps[kp], d = sd.exps[lp], q = c + d, rq = 1.0 / q;
+                    const double argcd = c * d * rq * cd2;
+                    if (!(argcd < PRIM_EXP_CUTOFF)) continue;
+                    const double kcd = exp(-argcd) * sc.coefs[kp] * sd.coefs[lp] * rq;
+                    const double qx = (c * sc.x + d * sd.x) * rq, qy = (c * sc.y + d * sd.y) * rq, qz = (c * sc.z + d * sd.z) * rq;
+                    __syncthreads();
+                    if (lane >= 3 && lane < 6) {
+                        const int ax = lane - 3;
+                        const double qc = ax == 0 ? qx - sc.x : (ax == 1 ? qy - sc.y : qz - sc.z);
+                        const double qd = ax == 0 ? qx - sd.x : (ax == 1 ? qy - sd.y : qz - sd.z);
+                        gr_build_e(LC1, ld, qc, qd, 0.5 * rq, Ecd + ax * ne_cd);
+                    }
+                    const double rs = 1.0 / sqrt(p + q);
+                    const double alpha = p * q * rs * rs;
+                    const double pref = TWO_PI_25 * rs * kab * kcd;
+                    const double X = px - qx, Y = py - qy, Z = pz - qz;
+                    gr_boys(bv.boys, LR, alpha, alpha * (X * X + Y * Y + Z * Z), Fb, lane);
+                    __syncthreads();
+                    const double* R = gr_hermite_r(LR, X, Y, Z, Fb, tuv, R0, R1, lane);
+                    const double* Fx = Ecd; const double* Fy = Ecd + ne_cd; const double* Fz = Ecd + 2 * ne_cd;
+                    // ket-contracted intermediates: G[h][k] = sum (-1)^{tau+nu+phi} F F F R_{t+tau,u+nu,v+phi}
+                    auto ket = [&](int lcx, int nh, int nk, double* G) {
+                        const int nck = ncart(lcx);
+                        (void)nck;
+                        for (int idx = lane; idx < nh * nk; idx += 64) {
+                            const int h = idx / nk, k = idx - h * nk;
+                            const int ic = k / ncd, id = k - ic * ncd;
+                            int cx, cy, cz, dx, dy, dz;
+                            cart_lmn(lcx, ic, cx, cy, cz);
+                            cart_lmn(ld, id, dx, dy, dz);
+                            const int pk = tuv[h];
+                            const int t0 = pk & 0xff, u0 = (pk >> 8) & 0xff, v0 = pk >> 16;
+                            const double* fx = Fx + (cx * (ld + 1) + dx) * ntc;
+                            const double* fy = Fy + (cy * (ld + 1) + dy) * ntc;
+                            const double* fz = Fz + (cz * (ld + 1) + dz) * ntc;
+                            double g = 0.0;
+                            for (int tt = 0; tt <= cx + dx; ++tt)
+                                for (int uu = 0; uu <= cy + dy; ++uu) {
+                                    const double fxy = fx[tt] * fy[uu];
+                                    for (int ww = 0; ww <= cz + dz; ++ww) {
+                                        const double term = fxy * fz[ww] * R[gr_hidx(t0 + tt, u0 + uu, v0 + ww)];
+                                        g += ((tt + uu + ww) & 1) ? -term : term;
+                                    }
+                                }
+                            G[idx] = g;
+                        }
+                    };
+                    ket(lc, nh1, nccd, G0);
+                    ket(lc + 1, nh0, ncp, GP);
+                    if (lc > 0) ket(lc - 1, nh0, ncm, GM);
+                    __syncthreads();
+                    const double* Ex = Eab; const double* Ey = Eab + ne_ab; const double* Ez = Eab + 2 * ne_ab;
+                    // bra contraction: sum_tuv E[a'][b'] G[hidx(t,u,v)][col], stride = columns of that G
+                    auto bra = [&](int a0, int a1, int a2, int b0, int b1, int b2, const double* G, int stride, int col) {
+                        if (a0 < 0 || a1 < 0 || a2 < 0 || b0 < 0 || b1 < 0 || b2 < 0) return 0.0;
+                        const double* ex = Ex + (a0 * (LB1 + 1) + b0) * ntb;
+                        const double* ey = Ey + (a1 * (LB1 + 1) + b1) * ntb;
+                        const double* ez = Ez + (a2 * (LB1 + 1) + b2) * ntb;
+                        double s = 0.0;
+                        for (int tt = 0; tt <= a0 + b0; ++tt)
+                            for (int uu = 0; uu <= a1 + b1; ++uu) {
+                                const double exy = ex[tt] * ey[uu];
+                                for (int vv = 0; vv <= a2 + b2; ++vv) s += exy * ez[vv] * G[gr_hidx(tt, uu, vv) * stride + col];
+                            }
+                        return s;
+                    };
+                    for (int idx = lane; idx < nc4; idx += 64) {
+                        const double gam = GC[idx];
+                        if (gam == 0.0) continue;
+                        const int iab = idx / nccd, icd = idx - iab * nccd;
+                        const int ia = iab / ncb, ib = iab - ia * ncb;
+                        const int ic = icd / ncd, id = icd - ic * ncd;
+                        int ax, ay, az, bx, by, bz, cx, cy, cz;
+                        cart_lmn(la, ia, ax, ay, az);
+                        cart_lmn(lb, ib, bx, by, bz);
+                        cart_lmn(lc, ic, cx, cy, cz);
+                        const double pg = pref * gam;
+                        // centre A
+                        gA[0] += pg * (2.0 * a * bra(ax + 1, ay, az, bx, by, bz, G0, nccd, icd) - ax * bra(ax - 1, ay, az, bx, by, bz, G0, nccd, icd));
+                        gA[1] += pg * (2.0 * a * bra(ax, ay + 1, az, bx, by, bz, G0, nccd, icd) - ay * bra(ax, ay - 1, az, bx, by, bz, G0, nccd, icd));
+                        gA[2] += pg * (2.0 * a * bra(ax, ay, az + 1, bx, by, bz, G0, nccd, icd) - az * bra(ax, ay, az - 1, bx, by, bz, G0, nccd, icd));
+                        // centre B
+                        gB[0] += pg * (2.0 * b * bra(ax, ay, az, bx + 1, by, bz, G0, nccd, icd) - bx * bra(ax, ay, az, bx - 1, by, bz, G0, nccd, icd));
+                        gB[1] += pg * (2.0 * b * bra(ax, ay, az, bx, by + 1, bz, G0, nccd, icd) - by * bra(ax, ay, az, bx, by - 1, bz, G0, nccd, icd));
+                        gB[2] += pg * (2.0 * b * bra(ax, ay, az, bx, by, bz + 1, G0, nccd, icd) - bz * bra(ax, ay, az, bx, by, bz - 1, G0, nccd, icd));
+                        // centre C: ket raised / lowered on c
+                        {
+                            const int kxp = cart_index(lc + 1, cx + 1, cz) * ncd + id;
+                            const int kyp = cart_index(lc + 1, cx, cz) * ncd + id;
+                            const int kzp = cart_index(lc + 1, cx, cz + 1) * ncd + id;
+                            double vx = 2.0 * c * bra(ax, ay, az, bx, by, bz, GP, ncp, kxp);
+                            double vy = 2.0 * c * bra(ax, ay, az, bx, by, bz, GP, ncp, kyp);
+                            double vz = 2.0 * c * bra(ax, ay, az, bx, by, bz, GP, ncp, kzp);
+                            if (cx > 0) vx -= cx * bra(ax, ay, az, bx, by, bz, GM, ncm, cart_index(lc - 1, cx - 1, cz) * ncd + id);
+                            if (cy > 0) vy -= cy * bra(ax, ay, az, bx, by, bz, GM, ncm, cart_index(lc - 1, cx, cz) * ncd + id);
+                            if (cz > 0) vz -= cz * bra(ax, ay, az, bx, by, bz, GM, ncm, cart_index(lc - 1, cx, cz - 1) * ncd + id);
+                            gCc[0] += pg * vx; gCc[1] += pg * vy; gCc[2] += pg * vz;
+                        }
+                    }
+                }
+            __syncthreads();
+        }
+    double* gf = grad + (size_t)f * tp.natoms * 3;
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+        const double ta = wave_sum(gA[cc]), tb = wave_sum(gB[cc]), tc = wave_sum(gCc[cc]);
+        if (lane == 0) {
+            atomicAdd(&gf[3 * atA + cc], ta);
+            atomicAdd(&gf[3 * atB + cc], tb);
+            atomicAdd(&gf[3 * atC + cc], tc);
+            atomicAdd(&gf[3 * atD + cc], -(ta + tb + tc));      // translational invariance
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+static Grad1eLayout grad1e_layout(int la, int lb)
+{
+    Grad1eLayout g;
+    const int LA1 = la + 1, LB2 = lb + 2, nt = LA1 + LB2 + 1, ne = (LA1 + 1) * (LB2 + 1) * nt, LR = la + lb + 2;
+    int off = 0;
+    auto take = [&off](int n) { const int o = off; off += (n + 1) & ~1; return o; };
+    g.e = take(3 * ne); g.r0 = take(nherm(LR)); g.r1 = take(nherm(LR)); g.tuv = take((nherm(LR) + 1) / 2 + 1);
+    g.fb = take(LR + 2); g.dc = take(ncart(la) * ncart(lb)); g.wc = take(ncart(la) * ncart(lb));
+    g.total = off;
+    return g;
+}
+
+static Grad2eLayout grad2e_layout(int la, int lb, int lc, int ld)
+{
+    Grad2eLayout g;
+    const int LA1 = la + 1, LB1 = lb + 1, LC1 = lc + 1;
+    const int ne_ab = (LA1 + 1) * (LB1 + 1) * (LA1 + LB1 + 1), ne_cd = (LC1 + 1) * (ld + 1) * (LC1 + ld + 1);
+    const int LR = la + lb + lc + ld + 1;
+    const int nc4 = ncart(la) * ncart(lb) * ncart(lc) * ncart(ld);
+    // staging buffer of the sph -> cart transform: the largest intermediate
+    int tmp = nsph(la) * nsph(lb) * nsph(lc) * ncart(ld);
+    const int t3 = nsph(la) * ncart(lb) * ncart(lc) * ncart(ld);
+    if (t3 > tmp) tmp = t3;
+    int off = 0;
+    auto take = [&off](int n) { const int o = off; off += (n + 1) & ~1; return o; };
+    g.e_ab = take(3 * ne_ab); g.e_cd = take(3 * ne_cd);
+    g.r0 = take(nherm(LR)); g.r1 = take(nherm(LR)); g.tuv = take((nherm(LR) + 1) / 2 + 1); g.fb = take(LR + 2);
+    int gcsz = nc4;
+    const int t2 = nsph(la) * nsph(lb) * ncart(lc) * ncart(ld), t0 = nsph(la) * nsph(lb) * nsph(lc) * nsph(ld);
+    if (t2 > gcsz) gcsz = t2;
+    if (t0 > gcsz) gcsz = t0;
+    g.gc = take(gcsz); g.tmp = take(tmp);
+    g.g0 = take(nherm(la + lb + 1) * ncart(lc) * ncart(ld));
+    g.gp = take(nherm(la + lb) * ncart(lc + 1) * ncart(ld));
+    g.gm = take(lc > 0 ? nherm(la + lb) * ncart(lc - 1) * ncart(ld) : 2);
+    g.total = off;
+    return g;
+}
+
+// Gradient of the whole batch into d_grad [nfrag][natoms][3] (zeroed here); Dtot = D (restricted) or D_a + D_b.
+// work: device scratch of at least 2 * nfrag * n * n doubles (energy-weighted density, total density of a UHF run).
+bool launch_gradient(const BatchView& bv, const Topology& topo, double* d_grad, double* work, int* d_lists, size_t list_capacity_ints,
+                     hipStream_t s, std::string& err)
+{
+    const int n = bv.n, nf = bv.nfrag;
+    const size_t nn = (size_t)n * n;
+    if (topo.lmax > 2) { err = "analytic gradients cover s, p and d shells"; return false; }
+    double* Wm = work;
+    double* Dtot = bv.D;
+    (void)hipMemsetAsync(d_grad, 0, sizeof(double) * (size_t)nf * topo.natoms * 3, s);
+    hipLaunchKernelGGL(grad_weighted_density_kernel, dim3((unsigned)((nn + 255) / 256), nf), dim3(256), 0, s, bv, Wm);
+    if (bv.uhf) {
+        Dtot = work + (size_t)nf * nn;
+        const size_t tot = (size_t)nf * nn;
+        hipLaunchKernelGGL(grad_total_density_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, bv, Dtot);
+    }
+    // ---- one-electron: pairs bucketed by (la >= lb)
+    static std::vector<int> bucket[2][3][3];
+    auto& bk = bucket[bv.slot & 1];
+    for (auto& row : bk) for (auto& b : row) b.clear();
+    for (size_t k = 0; k + 1 < topo.pairs.size(); k += 2) {
+        int A = topo.pairs[k], B = topo.pairs[k + 1];
+        int la = topo.shells[A].l, lb = topo.shells[B].l;
+        if (la < lb) { std::swap(A, B); std::swap(la, lb); }
+        bk[la][lb].push_back(A); bk[la][lb].push_back(B);
+    }
+    size_t need = topo.pairs.size();
+    for (auto& cl : topo.classes) need += cl.quartets.size();
+    if (need + 64 > list_capacity_ints) { err = "gradient: list buffer too small"; return false; }
+    size_t off = 0;
+    (void)hipFuncSetAttribute((const void*)grad1e_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)eri_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (int la = 0; la <= 2; ++la)
+        for (int lb = 0; lb <= la; ++lb) {
+            auto& v = bk[la][lb];
+            if (v.empty()) continue;
+            (void)hipMemcpyAsync(d_lists + off, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, s);
+            const Grad1eLayout lay = grad1e_layout(la, lb);
+            const long total = (long)(v.size() / 2) * nf;
+            hipLaunchKernelGGL(grad1e_kernel, dim3((unsigned)total), dim3(64), sizeof(double) * (size_t)lay.total, s, bv, la, lb, lay,
+                               d_lists + off, (int)(v.size() / 2), Dtot, Wm, d_grad);
+            off += v.size();
+        }
+    // ---- two-electron: every canonical class
+    for (auto& cl : topo.classes) {
+        if (cl.quartets.empty()) continue;
+        (void)hipMemcpyAsync(d_lists + off, cl.quartets.data(), cl.quartets.size() * sizeof(int), hipMemcpyHostToDevice, s);
+        const Grad2eLayout lay = grad2e_layout(cl.la, cl.lb, cl.lc, cl.ld);
+        if (sizeof(double) * (size_t)lay.total > 160 * 1024) { err = "gradient: class too large for LDS"; return false; }
+        const long total = (long)(cl.quartets.size() / 4) * nf;
+        hipLaunchKernelGGL(eri_grad_kernel, dim3((unsigned)total), dim3(64), sizeof(double) * (size_t)lay.total, s, bv, cl.la, cl.lb, cl.lc, cl.ld, lay,
+                           d_lists + off, (int)(cl.quartets.size() / 4), Dtot, bv.uhf ? bv.Db : (const double*)nullptr, d_grad);
+        off += cl.quartets.size();
+    }
+    return true;
+}
+
+}  // namespace mqc

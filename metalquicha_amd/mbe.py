@@ -181,6 +181,7 @@ class MbeRun:
     iterations: np.ndarray
     owned: np.ndarray
     errors: List[str]
+    gradient: Optional[np.ndarray] = None      # (n_atoms, 3) weighted sum of the owned fragments' gradients (zero-padded share)
 
 
 def _group_layout(system: FragmentedSystem, term_list: Sequence[Tuple[int, ...]]):
@@ -234,7 +235,7 @@ def build_fragment_groups(system: FragmentedSystem, term_list: Sequence[Tuple[in
 
 def run_mbe(system: FragmentedSystem, settings: ScfSettings, level: int = 2,
             cutoffs: Optional[Dict[int, float]] = None, rank: int = 0, world: int = 1,
-            terms: Optional[List[Tuple[int, ...]]] = None) -> MbeRun:
+            terms: Optional[List[Tuple[int, ...]]] = None, want_gradient: bool = False) -> MbeRun:
     from .methods import run_hip_scf_groups
     terms = terms if terms is not None else generate_mbe_term_list(system, level, cutoffs)
     owned = partition_terms(len(terms), rank, world)
@@ -243,7 +244,23 @@ def run_mbe(system: FragmentedSystem, settings: ScfSettings, level: int = 2,
     energies = np.zeros(len(terms))
     iters = np.zeros(len(terms), dtype=np.int64)
     errors = []
-    for pos, rec in zip(positions, run_hip_scf_groups(settings, groups)):
+    grads_out: list = []
+    gradient_total = None
+    recs = run_hip_scf_groups(settings, groups, want_gradient=want_gradient, gradients_out=grads_out)
+    if want_gradient:
+        # weighted sum of the fragment gradients on the system's atoms (mqc_mbe.f90: the gradient twin of
+        # E = sum_i c_i E_i; the reference all-reduces this 3 N vector next to the energies)
+        coef = compute_mbe_coefficients(terms)
+        total = np.zeros((len(system.element_numbers), 3))
+        layout = _group_layout(system, [terms[i] for i in owned])
+        for (z, atoms, charges, pos), rec, ga in zip(layout, recs, grads_out):
+            tix = owned_arr[pos]
+            for k in range(len(pos)):
+                if rec["has_error"][k] or not rec["has_gradient"][k]:
+                    continue
+                np.add.at(total, atoms[k], coef[tix[k]] * ga[k])
+        gradient_total = total
+    for pos, rec in zip(positions, recs):
         tix = owned_arr[pos]
         ok = rec["has_error"] == 0
         energies[tix[ok]] = rec["e_total"][ok]
@@ -251,7 +268,7 @@ def run_mbe(system: FragmentedSystem, settings: ScfSettings, level: int = 2,
         for k in np.nonzero(~ok)[0]:
             msg = bytes(rec["message"][k]).split(b"\0", 1)[0].decode(errors="replace")
             errors.append("term %s: %s" % (terms[tix[k]], msg))
-    return MbeRun(terms, energies, iters, owned, errors)
+    return MbeRun(terms, energies, iters, owned, errors, gradient_total)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -248,11 +248,17 @@ def run_hip_scf(settings: ScfSettings, fragment: PhysicalFragment, result: Optio
         r = capi.ScfResult()
         r.orbital_energies = capi.dptr(eps)
         r.orbital_energies_beta = capi.dptr(epsb)
+        grad = np.zeros((fragment.n_atoms, 3)) if want_gradient else None
+        if grad is not None:
+            r.gradient = capi.dptr(grad)
         rc = lib.mqc_hip_scf_run(ctx, C.byref(m.mol), C.byref(m.bas), C.byref(m.aux_bas) if aux is not None else None,
                                  C.byref(opts), C.byref(r))
         if rc != capi.MQC_HIP_OK and not r.has_error:
             capi.check(rc)
         _fill(result, r, eps)
+        if grad is not None and r.has_gradient and not r.has_error:
+            result.gradient = grad.T.copy()              # (3, n_atoms) like result%gradient
+            result.has_gradient = True
         if result.has_energy and int(r.n_alpha) != int(r.n_beta) or settings.unrestricted:
             result.orbital_energies_beta = epsb[: int(r.n_mo)].copy()
         return result
@@ -313,7 +319,8 @@ class FragmentGroup:
     nelec: Optional[np.ndarray] = None     # (m,), default sum(Z of real atoms) - charge
 
 
-def run_hip_scf_groups(settings: ScfSettings, groups: Sequence[FragmentGroup]) -> List[np.ndarray]:
+def run_hip_scf_groups(settings: ScfSettings, groups: Sequence[FragmentGroup], want_gradient: bool = False,
+                       gradients_out: Optional[list] = None) -> List[np.ndarray]:
     """All fragments of all groups in ONE mqc_hip_scf_run_batch call; returns, per group, a structured array
     viewing the engine's result records (fields of capi.ScfResult: e_total, iterations, has_error, message ...).
 
@@ -326,7 +333,7 @@ def run_hip_scf_groups(settings: ScfSettings, groups: Sequence[FragmentGroup]) -
         return [np.zeros(0, dtype=_RES_DTYPE) for _ in groups]
     lib = capi.load_library()
     ctx = capi.get_context(settings.device_rank)
-    opts = _options(settings, False)
+    opts = _options(settings, want_gradient)
     df = settings.density_fitting
     mols = np.zeros(n, dtype=_MOL_DTYPE)
     bass = np.zeros(n, dtype=_BAS_DTYPE)
@@ -365,6 +372,20 @@ def run_hip_scf_groups(settings: ScfSettings, groups: Sequence[FragmentGroup]) -
             keep.append(ab)
             auxs[sl] = _basis_record(ab, na)
     res = (capi.ScfResult * n)()
+    grads = []
+    if want_gradient:
+        # one (m, n_atoms, 3) array per group; every record points at its own slice
+        rec0 = np.frombuffer(res, dtype=_RES_DTYPE)
+        lo = 0
+        for g, m in zip(groups, sizes):
+            na = int(len(g.element_numbers))
+            ga = np.zeros((m, na, 3))
+            grads.append(ga)
+            if m:
+                rec0["gradient"][lo:lo + m] = ga.ctypes.data + np.arange(m, dtype=np.uint64) * np.uint64(na * 3 * 8)
+            lo += m
+        if gradients_out is not None:
+            gradients_out.extend(grads)
     rc = lib.mqc_hip_scf_run_batch(ctx, n, mols.ctypes.data_as(C.POINTER(capi.Molecule)),
                                    bass.ctypes.data_as(C.POINTER(capi.Basis)),
                                    auxs.ctypes.data_as(C.POINTER(capi.Basis)) if df else None, C.byref(opts), res)
@@ -443,12 +464,14 @@ class HFMethod:
         return run_hip_scf(self.settings, fragment, result)
 
     def calc_gradient(self, fragment, result=None):
+        """hf_calc_gradient (src/methods/mqc_method_hf.F90): the SCF with want_gradient, result%gradient (3, n_atoms)."""
+        return run_hip_scf(self.settings, fragment, result, want_gradient=True)
+
+    def calc_hessian(self, fragment, result=None):
         r = result or CalculationResult()
         r.has_error = True
-        r.error_message = "analytic gradients are not available in this build of the HIP backend"
+        r.error_message = "Hessians are not available in this build of the HIP backend"
         return r
-
-    calc_hessian = calc_gradient
 
 
 def get_stats() -> capi.Stats:

@@ -147,3 +147,60 @@ def test_ghost_atom_fragment_matches_oracle(functional):
     real = fragment_bohr([8, 1, 1], xyz[:3])
     r0 = methods.run_hip_scf(st, real)
     assert 0.0 < r0.energy.scf - r.energy.scf < 5e-3
+
+
+# ---- analytic gradients -----------------------------------------------------------
+_GRAD = [c for c in _CASES if c.get("expected_gradient") and c["method"] == "hf" and not c["density_fitting"]
+         and "*" not in c["basis"] and "mbe_level" not in c]
+
+
+@pytest.mark.parametrize("case", _GRAD, ids=[c["name"] for c in _GRAD])
+def test_manifest_hf_gradient_goldens(case):
+    """validation_tests_cpu.json gradient/ rows the engine can run (RHF H2O STO-3G, RHF NH3 cc-pVDZ, UHF CH3 cc-pVDZ):
+    energy to 1e-9, every gradient component to the manifest's own tolerance (1e-8), translational invariance."""
+    z = [SYMBOL_TO_Z[s.lower()] for s in case["symbols"]]
+    frag = fragment_bohr(z, np.array(case["xyz_angstrom"]) * ANGSTROM_TO_BOHR, multiplicity=case["multiplicity"])
+    st = methods.ScfSettings(basis_set=case["basis"], energy_tol=1e-12, density_tol=1e-10, guess="gwh", max_iter=200)
+    r = methods.HFMethod(st).calc_gradient(frag)
+    assert not r.has_error, r.error_message
+    assert r.has_gradient and r.gradient.shape == (3, len(z))
+    assert abs(r.energy.scf - case["expected_energy"]) < 1e-9
+    ref = np.array(case["expected_gradient"]).T
+    assert np.max(np.abs(r.gradient - ref)) < max(case["gradient_tolerance"], 2e-8), np.max(np.abs(r.gradient - ref))
+    assert np.max(np.abs(r.gradient.sum(axis=1))) < 1e-9
+
+
+def test_gradient_matches_finite_differences_of_the_oracle_energy():
+    """check_gradient's procedure (validation/check_gradient.f90: central differences, bound 3.5e-8 Eh/a0) with the
+    oracle as the energy function: a bent, asymmetric water in cc-pVDZ (d shells, every class of the gradient kernel)."""
+    xyz = np.array([[0.03, -0.02, -0.13], [0.10, 1.45, 1.05], [-0.05, -1.38, 1.12]])
+    frag = fragment_bohr([8, 1, 1], xyz)
+    st = methods.ScfSettings(basis_set="cc-pvdz", energy_tol=1e-12, density_tol=1e-10, guess="gwh", max_iter=200)
+    r = methods.HFMethod(st).calc_gradient(frag)
+    assert not r.has_error, r.error_message
+    h = 1e-3
+    fd = np.zeros((3, 3))
+    for a in range(3):
+        for c in range(3):
+            e = []
+            for sgn in (+1, -1):
+                x = xyz.copy(); x[a, c] += sgn * h
+                e.append(so.run_rhf(oracle_mol("cc-pvdz", fragment_bohr([8, 1, 1], x)), 10, 200, 1e-12, 1e-10).energy)
+            fd[c, a] = (e[0] - e[1]) / (2 * h)
+    assert np.max(np.abs(r.gradient - fd)) < 2e-6, np.max(np.abs(r.gradient - fd))       # O(h^2) error of the differences
+    assert np.max(np.abs(r.gradient.sum(axis=1))) < 1e-9
+
+
+def test_mbe2_water_dimer_gradient_golden():
+    """'MBE(2) RHF gradient (H2O)2 cc-pvdz (CPU)': the 6 x 3 MBE(2) gradient (tolerance 1e-7) assembled from the
+    fragment gradients with the MBE coefficients, fragments run as one batch."""
+    case = [c for c in _CASES if c.get("mbe_level") == 2 and c.get("expected_gradient")][0]
+    system = mbe.system_from_xyz(case["symbols"], np.array(case["xyz_angstrom"]), case["fragments"])
+    st = methods.ScfSettings(basis_set=case["basis"], energy_tol=1e-12, density_tol=1e-10, guess="gwh", max_iter=200)
+    run = mbe.run_mbe(system, st, level=2, want_gradient=True)
+    assert not run.errors, run.errors
+    total, _, _ = mbe.compute_mbe(run.terms, run.energies)
+    assert abs(total - case["expected_energy"]) < 1e-9
+    ref = np.array(case["expected_gradient"])
+    assert run.gradient is not None and run.gradient.shape == ref.shape
+    assert np.max(np.abs(run.gradient - ref)) < case["gradient_tolerance"], np.max(np.abs(run.gradient - ref))
