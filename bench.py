@@ -301,7 +301,13 @@ def main():
             "eri": {"kernel": "eri class kernels (integral stage, all streams)", "bound": "fp64 valu", "seconds": st.eri_kernel_seconds,
                     "quartets_formed": int(st.eri_survivors), "canonical_quartets": int(st.eri_quartets),
                     "quartets_per_s": (st.eri_survivors / st.eri_kernel_seconds) if st.eri_kernel_seconds > 0 else None,
-                    "fp64_tflops_from_counters": (pmc or {}).get("eri_fp64_tflops")},
+                    # FP64 flop of the eri_* / schwarz_* kernels from the SQ instruction counters of a separate --pmc pass of
+                    # this command (profiles/r02_pmc_summary.json), divided by THIS run's stage time per evaluation
+                    "fp64_tflops_from_counters": ((pmc["eri_fp64_flop_total"] / pmc.get("eri_fp64_evaluations_in_pass", 1)
+                                                   / (st.eri_kernel_seconds / n_steps) / 1e12)
+                                                  if (pmc and pmc.get("eri_fp64_flop_total") and st.eri_kernel_seconds > 0) else None),
+                    "hbm_bytes_per_evaluation_from_counters": ((pmc["eri_stage_hbm_bytes_total"] / pmc.get("eri_fp64_evaluations_in_pass", 1))
+                                                               if (pmc and pmc.get("eri_stage_hbm_bytes_total")) else None)},
             "xc": {"kernel": "xc quadrature", "bound": "mfma", "seconds": st.xc_kernel_seconds, "points": st.xc_points,
                    "algorithmic_tflops": (st.xc_flops / st.xc_kernel_seconds / 1e12) if st.xc_kernel_seconds > 0 else None,
                    "frac_of_fp64_peak": (st.xc_flops / st.xc_kernel_seconds / 1e12 / FP64_PEAK_TFLOPS) if st.xc_kernel_seconds > 0 else None},
@@ -357,6 +363,18 @@ def main():
             "roofline": roof,
         }
         line["secondary"] = secondary
+        pm_all = committed_pmc()
+        if pm_all and "passes" in pm_all:
+            # MFMA-utilisation counters (SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU_MFMA_MOPS_F64) of the B3LYP and DF commands,
+            # collected in their own rocprofv3 --pmc passes and committed under profiles/
+            def _mf(tag, sub):
+                for k, v in pm_all["passes"].get(tag, {}).get("kernels", {}).items():
+                    if k.startswith(sub) and "mfma_busy_fraction" in v:
+                        return {"kernel": k, "mfma_busy_fraction": v["mfma_busy_fraction"], "mfma_tflops": v["mfma_tflops"],
+                                "valu_fp64_tflops": v.get("valu_fp64_tflops"), "peak_tflops": FP64_PEAK_TFLOPS}
+                return None
+            line["mfma_counters"] = {"xc": _mf("sq_b3lyp", "xc_tile_kernel"), "df_jk": _mf("sq_df", "df_jk_mfma_kernel"),
+                                     "df_fit": _mf("sq_df", "df_fit_mfma_kernel"), "source": "profiles/r02_pmc_summary.json"}
         if not args.no_cpu_baseline and world == 1 and not args.functional and not args.df:
             line["cpu_baseline"] = cpu_baseline(system0, terms, args.basis, energies0, args)
             line["parity_max_abs_diff"] = line["cpu_baseline"]["parity_max_abs_diff"]

@@ -30,6 +30,19 @@ def read_pass(directory):
     return table, {k: len(v) for k, v in launches.items()}
 
 
+def read_durations(directory):
+    """kernel name -> summed duration in seconds, from the kernel trace of the same pass"""
+    out = collections.defaultdict(float)
+    for f in glob.glob(os.path.join(directory, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            out[r["Kernel_Name"]] += (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-9
+    return out
+
+
+N_SIMD = 1024            # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9         # nominal; the chip runs lower under load (MI355X_MICROARCH.md, DVFS): fractions below are lower bounds
+
+
 def short(name):
     return name.replace("void mqc::", "").replace("mqc::", "").split("(")[0]
 
@@ -46,7 +59,19 @@ def main():
             w.writerow(["Kernel", "Launches"] + counters)
             for k, v in rows:
                 w.writerow([k, launches[k]] + ["%.6g" % v.get(c, 0.0) for c in counters])
-        out["passes"][tag] = {"counters": counters, "kernels": {short(k): dict(v, launches=launches[k]) for k, v in rows[:40]}}
+        dur = read_durations(directory)
+        kern = {}
+        for k, v in rows[:40]:
+            e = dict(v, launches=launches[k], seconds_in_this_pass=dur.get(k, 0.0))
+            if v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) > 0 and dur.get(k, 0.0) > 0:
+                # MFMA-busy SIMD-cycles over the SIMD-cycles the kernel had; MOPS_F64 counts 512-flop units
+                e["mfma_busy_fraction"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (dur[k] * N_SIMD * CLOCK_HZ)
+                e["mfma_tflops"] = 512.0 * v.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0) / dur[k] / 1e12
+            fl = 64.0 * (2.0 * v.get("SQ_INSTS_VALU_FMA_F64", 0.0) + v.get("SQ_INSTS_VALU_ADD_F64", 0.0) + v.get("SQ_INSTS_VALU_MUL_F64", 0.0))
+            if fl > 0 and dur.get(k, 0.0) > 0:
+                e["valu_fp64_tflops"] = fl / dur[k] / 1e12
+            kern[short(k)] = e
+        out["passes"][tag] = {"counters": counters, "kernels": kern}
     p = out["passes"]
     # J/K stream: HBM bytes per launch of the tuned dimer kernel
     if "fetch" in p and "write" in p:
@@ -70,6 +95,7 @@ def main():
             if k.startswith(("eri_", "schwarz_")):
                 fl += 64.0 * (2.0 * v.get("SQ_INSTS_VALU_FMA_F64", 0.0) + v.get("SQ_INSTS_VALU_ADD_F64", 0.0) + v.get("SQ_INSTS_VALU_MUL_F64", 0.0))
         out["eri_fp64_flop_total"] = fl
+        out["eri_fp64_evaluations_in_pass"] = 2          # bench.py --steps 1 --warmup 1: the cold evaluation + one timed step
         out["eri_fp64_note"] = "64 lanes x (2 FMA + ADD + MUL) wave-instructions of the eri_* / schwarz_* kernels; upper bound (inactive lanes counted)"
     with open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json"), "w") as f:
         json.dump(out, f, indent=1)
