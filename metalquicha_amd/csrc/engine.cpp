@@ -358,7 +358,12 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
     const size_t np = (size_t)topo.npair;
     const size_t two_e = use_df ? (2 * (size_t)naux * np + 3 * (size_t)naux * naux) : (use_direct ? 2 * (size_t)n * n : np * np);
     const bool uhf_mem = opts.unrestricted || topo.multiplicity != 1 || (topo.nelec % 2) != 0;
-    const size_t per_frag = sizeof(double) * (per_fragment_main_doubles(n, topo.natoms, uhf_mem) + two_e + (xc.ncomp > 0 ? (size_t)n * n + grid.npts : 0));
+    // radial cache of the quadrature (MQC_HIP_XC_RADIAL_CACHE=0 turns it off): 2 doubles per shell and (padded) grid point
+    static const bool rad_cache_on = [] { const char* e = std::getenv("MQC_HIP_XC_RADIAL_CACHE"); return !(e && e[0] == '0'); }();
+    const int rad_pt = xc_tile_points(n);
+    const size_t rad_tiles = xc.ncomp > 0 ? ((size_t)grid.npts + rad_pt - 1) / rad_pt : 0;
+    const size_t rad_doubles = (xc.ncomp > 0 && rad_cache_on) ? rad_tiles * topo.shells.size() * 2 * rad_pt : 0;
+    const size_t per_frag = sizeof(double) * (per_fragment_main_doubles(n, topo.natoms, uhf_mem) + two_e + (xc.ncomp > 0 ? (size_t)n * n + grid.npts : 0) + rad_doubles);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     free_b += ctx->pool_main.capacity() + ctx->pool_eri.capacity() + ctx->pool_df.capacity() + ctx->pool_gridw.capacity()
@@ -429,10 +434,12 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         bv.nocc = nocc; bv.exx = xc.exx; bv.e_tol = opts.energy_tol; bv.d_tol = opts.density_tol;
         bv.xc = xc; bv.grid = grid; bv.Vxc = nullptr;
         if (xc.ncomp > 0) {
-            char* gw = (char*)sl.gridw->ensure(sizeof(double) * (size_t)nf * ((size_t)grid.npts + (size_t)n * n) + 512);
+            char* gw = (char*)sl.gridw->ensure(sizeof(double) * (size_t)nf * ((size_t)grid.npts + (size_t)n * n + rad_doubles) + 1024);
             if (!gw) return fail(MQC_HIP_ERR_DEVICE, "out of device memory (grid weights)");
             bv.grid.weights = (double*)gw;
             bv.Vxc = (double*)(gw + ((sizeof(double) * (size_t)nf * grid.npts + 255) & ~size_t(255)));
+            bv.grid.rad = nullptr; bv.grid.rad_pt = rad_pt;
+            if (rad_doubles) bv.grid.rad = (double*)((char*)bv.Vxc + ((sizeof(double) * (size_t)nf * n * n + 255) & ~size_t(255)));
         }
         bv.max_iter = opts.max_iter; bv.diis_size = opts.use_diis ? opts.diis_size : 0;
         job.hx.resize((size_t)nf * topo.natoms * 3);
@@ -459,7 +466,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         launch_guess(bv, opts.guess == MQC_HIP_GUESS_CORE ? MQC_HIP_GUESS_CORE : MQC_HIP_GUESS_GWH, so);
         if ((rc = stage_check("guess")) != MQC_HIP_OK) return rc;
         HIP_CHECK_RET(hipEventRecord(ctx->evo[sl.id & 1][1], so));
-        if (xc.ncomp > 0) launch_becke_weights(bv, s);
+        if (xc.ncomp > 0) { launch_becke_weights(bv, s); if (bv.grid.rad) launch_xc_radial_cache(bv, s); }
         if ((rc = stage_check("grid weights")) != MQC_HIP_OK) return rc;
         const double t2 = now_s();
         sx->stats.t_int1e += t2 - t1;

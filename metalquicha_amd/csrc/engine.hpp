@@ -99,6 +99,11 @@ struct GridDev {
     const double* tmpl_w = nullptr;     // [ntmpl] 4 pi r^2 dr w_leb
     const double* sqrt_bragg = nullptr; // [natoms] sqrt(Bragg radius), Treutler size adjustment
     double* weights = nullptr;          // [nfrag][npts] product weight x Becke cell weight
+    // radial cache (optional): per fragment, per tile of rad_pt points, per shell: rad_pt radial values then rad_pt
+    // radial derivative factors -- R_s(r) = sum_k c_k exp(-a_k r^2) and sum_k -2 a_k c_k exp(-a_k r^2) of every
+    // contracted shell at every grid point, formed ONCE per SCF (the geometry is fixed) instead of in every iteration
+    double* rad = nullptr;              // [nfrag][ntiles][nshell][2][rad_pt] or nullptr
+    int rad_pt = 0;
 };
 
 struct TopologyDev {
@@ -239,6 +244,9 @@ void launch_scf_step(const BatchView& bv, hipStream_t s);
 void launch_syev(int n, double* dA, double* dw, double* dV, hipStream_t s);
 void launch_diis_coeff(int n_stored, const double* d_overlap, double* d_coef, int* d_ok, hipStream_t s);
 void launch_becke_weights(const BatchView& bv, hipStream_t s);
+void launch_xc_radial_cache(const BatchView& bv, hipStream_t s);
+// points per tile of the quadrature kernel for n basis functions (kern_xc.hip) = granularity of the radial cache
+inline int xc_tile_points(int n) { return ((n + 15) / 16 <= 4) ? 32 : 16; }
 void launch_df_build(const BatchView& bv, const Topology& topo, const Topology& aux, hipStream_t s);
 void launch_df_jk(const BatchView& bv, bool only_active, hipStream_t s);
 void launch_xc(const BatchView& bv, bool only_active, hipStream_t s);

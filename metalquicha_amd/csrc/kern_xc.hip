@@ -142,15 +142,17 @@ __device__ __forceinline__ Dual f_pbe_c(Dual rho, Dual r13, Dual sigma)
     return rho * (ec + H);
 }
 
-// f = rho * eps_xc per volume and its derivatives, zero below the density threshold
-__device__ __forceinline__ void eval_functional(const XcSpec& xc, double rho, double sigma, double& f, double& vr, double& vs)
+// f = rho * eps_xc per volume and its derivatives, zero below the density threshold; components k0, k0 + kstep, ...
+// (the tiled kernel deals the components of a functional to its waves: B3LYP's four run side by side)
+__device__ __forceinline__ void eval_functional(const XcSpec& xc, double rho, double sigma, double& f, double& vr, double& vs,
+                                                int k0 = 0, int kstep = 1)
 {
     f = 0.0; vr = 0.0; vs = 0.0;
-    if (!(rho > XC_DENS_THRESHOLD)) return;
+    if (!(rho > XC_DENS_THRESHOLD) || k0 >= xc.ncomp) return;
     const Dual R = {rho, 1.0, 0.0};
     const Dual S = {fmax(sigma, 1.0e-40), 0.0, 1.0};
     const Dual R13 = dcbrt(R);          // every component needs rho^(1/3): formed once
-    for (int k = 0; k < xc.ncomp; ++k) {
+    for (int k = k0; k < xc.ncomp; k += kstep) {
         Dual d;
         switch (xc.id[k]) {
             case XC_LDA_X: d = f_lda_x(R, R13); break;
@@ -347,7 +349,7 @@ __device__ __forceinline__ void eval_group_lds(const GroupTables& gt, const doub
                                                double* __restrict__ chi, double* __restrict__ gx, double* __restrict__ gy,
                                                double* __restrict__ gz, int ptp, int p, const double* __restrict__ c2s)
 {
-    const int pk = gt.desc[4 * g], poff = gt.desc[4 * g + 1], coff = gt.desc[4 * g + 2], ao12 = gt.desc[4 * g + 3];
+    const int pk = gt.desc[6 * g], poff = gt.desc[6 * g + 1], coff = gt.desc[6 * g + 2], ao12 = gt.desc[6 * g + 3];
     const int ao0 = pk & 0xfff, l = (pk >> 12) & 0xf, at = (pk >> 16) & 0xff, nc = (pk >> 24) & 0x3, np = (pk >> 26) & 0x3f;
     const double dx = px - xyz[3 * at], dy = py - xyz[3 * at + 1], dz = pz - xyz[3 * at + 2];
     const double r2 = dx * dx + dy * dy + dz * dz;
@@ -373,6 +375,76 @@ __device__ __forceinline__ void eval_group_lds(const GroupTables& gt, const doub
     emit_shell<GGA>(l, ao0, dx, dy, dz, rad[0], drad[0], chi, gx, gy, gz, ptp, p, c2s);
     if (nc > 1) emit_shell<GGA>(l, ao12 & 0xffff, dx, dy, dz, rad[1], drad[1], chi, gx, gy, gz, ptp, p, c2s);
     if (nc > 2) emit_shell<GGA>(l, ao12 >> 16, dx, dy, dz, rad[2], drad[2], chi, gx, gy, gz, ptp, p, c2s);
+}
+
+// the same item from the radial cache: rad / drad of the group's shells are loaded (rad_pt values of a tile are
+// contiguous, lanes along the points), only the angular part is formed
+template <bool GGA>
+__device__ __forceinline__ void eval_group_cached(const GroupTables& gt, const double* __restrict__ xyz, int g, double px, double py, double pz,
+                                                  const double* __restrict__ radt /* this tile: [nshell][2][PT] */, int pt_stride,
+                                                  double* __restrict__ chi, double* __restrict__ gx, double* __restrict__ gy,
+                                                  double* __restrict__ gz, int ptp, int p, const double* __restrict__ c2s)
+{
+    const int pk = gt.desc[6 * g], ao12 = gt.desc[6 * g + 3], sh0 = gt.desc[6 * g + 4];
+    const int ao0 = pk & 0xfff, l = (pk >> 12) & 0xf, at = (pk >> 16) & 0xff, nc = (pk >> 24) & 0x3;
+    const double dx = px - xyz[3 * at], dy = py - xyz[3 * at + 1], dz = pz - xyz[3 * at + 2];
+    const double* r0 = radt + (size_t)sh0 * 2 * pt_stride + p;
+    emit_shell<GGA>(l, ao0, dx, dy, dz, r0[0], r0[pt_stride], chi, gx, gy, gz, ptp, p, c2s);
+    if (nc > 1) emit_shell<GGA>(l, ao12 & 0xffff, dx, dy, dz, r0[2 * pt_stride], r0[3 * pt_stride], chi, gx, gy, gz, ptp, p, c2s);
+    if (nc > 2) emit_shell<GGA>(l, ao12 >> 16, dx, dy, dz, r0[4 * pt_stride], r0[5 * pt_stride], chi, gx, gy, gz, ptp, p, c2s);
+}
+
+// fills the radial cache: thread = (radial group, point) of one fragment, the exponentials of eval_group once per SCF
+__global__ void __launch_bounds__(256) xc_radial_cache_kernel(BatchView bv)
+{
+    const int f = blockIdx.y;
+    const TopologyDev& tp = bv.topo;
+    const GridDev& gd = bv.grid;
+    const int PTC = gd.rad_pt;
+    const int ntiles = (gd.npts + PTC - 1) / PTC;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)tp.ngroup * ntiles * PTC;
+    if (idx >= total) return;
+    const int rg = (int)(idx / ((long)ntiles * PTC));
+    const int gp = (int)(idx - (long)rg * ntiles * PTC);          // padded point index
+    const int tile = gp / PTC, p = gp - tile * PTC;
+    const int sh0 = tp.grp_first[rg], nc = tp.grp_count[rg], np = tp.grp_nprim[rg];
+    double rad[XC_GROUP_MAX], drad[XC_GROUP_MAX];
+#pragma unroll
+    for (int k = 0; k < XC_GROUP_MAX; ++k) { rad[k] = 0.0; drad[k] = 0.0; }
+    if (gp < gd.npts) {
+        const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
+        const int oa = gd.pt_atom[gp], it = gd.pt_tmpl[gp], at = tp.sh_atom[sh0];
+        const double dx = xyz[3 * oa] + gd.tmpl_xyz[3 * it] - xyz[3 * at], dy = xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1] - xyz[3 * at + 1],
+                     dz = xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2] - xyz[3 * at + 2];
+        const double r2 = dx * dx + dy * dy + dz * dz;
+        const double* e = tp.gexps + tp.grp_poff[rg];
+        const double* c = tp.gcoefs + tp.grp_coff[rg];
+        for (int i = 0; i < np; ++i) {
+            const double ei = e[i], ar2 = ei * r2;
+            if (ar2 < XC_EXP_CUTOFF) {
+                const double ex = exp(-ar2), m2e = -2.0 * ei;
+#pragma unroll
+                for (int k = 0; k < XC_GROUP_MAX; ++k)
+                    if (k < nc) { const double t = c[k * np + i] * ex; rad[k] += t; drad[k] += m2e * t; }
+            }
+        }
+    }
+    double* base = gd.rad + ((size_t)f * ntiles + tile) * tp.nshell * 2 * PTC;
+#pragma unroll
+    for (int k = 0; k < XC_GROUP_MAX; ++k)
+        if (k < nc) {
+            double* r0 = base + (size_t)(sh0 + k) * 2 * PTC + p;
+            r0[0] = rad[k]; r0[PTC] = drad[k];
+        }
+}
+
+void launch_xc_radial_cache(const BatchView& bv, hipStream_t s)
+{
+    const int PTC = bv.grid.rad_pt;
+    const long ntiles = (bv.grid.npts + PTC - 1) / PTC;
+    const long total = (long)bv.topo.ngroup * ntiles * PTC;
+    hipLaunchKernelGGL(xc_radial_cache_kernel, dim3((unsigned)((total + 255) / 256), bv.nfrag), dim3(256), 0, s, bv);
 }
 
 // zero rows of a group for a point beyond the grid
@@ -724,10 +796,11 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
     double* gz = gy + (GGA ? (size_t)NP * RS : 0);
     double* red = gz + (GGA ? (size_t)NP * RS : 0);           // [SUPER][4] rho, grad rho sums of the super-tile
     double* coef = red + 4 * SUPER;                           // [SUPER][4] w v_rho / 2, 2 w v_sigma grad rho
-    double* tab = coef + 4 * SUPER;                           // radial-group tables: desc ints, exponents, coefficients
+    double* part = coef + 4 * SUPER;                          // [XV_NW][PT][3] per-wave partial f, v_rho, v_sigma
+    double* tab = part + 3 * XV_NW * PT;                      // radial-group tables: desc ints, exponents, coefficients
     const int ng = tp.ngroup, ngp = tp.gprim_total, ngc = tp.gcoef_total;
     int* tdesc = (int*)tab;
-    double* texps = tab + 2 * ng;
+    double* texps = tab + 3 * ng;
     double* tcoefs = texps + ngp;
     const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
     const double* __restrict__ D = bv.D + (size_t)f * n * n;
@@ -737,10 +810,12 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
     for (int idx = tid; idx < (GGA ? 4 : 2) * NP * RS + 8 * SUPER; idx += NTHR) lds[idx] = 0.0;
     for (int g = tid; g < ng; g += NTHR) {
         const int sh0 = tp.grp_first[g], nc = tp.grp_count[g], npg = tp.grp_nprim[g];
-        tdesc[4 * g] = tp.sh_aoff[sh0] | (tp.sh_l[sh0] << 12) | (tp.sh_atom[sh0] << 16) | (nc << 24) | (npg << 26);
-        tdesc[4 * g + 1] = tp.grp_poff[g];
-        tdesc[4 * g + 2] = tp.grp_coff[g];
-        tdesc[4 * g + 3] = (nc > 1 ? tp.sh_aoff[sh0 + 1] : 0) | ((nc > 2 ? tp.sh_aoff[sh0 + 2] : 0) << 16);
+        tdesc[6 * g] = tp.sh_aoff[sh0] | (tp.sh_l[sh0] << 12) | (tp.sh_atom[sh0] << 16) | (nc << 24) | (npg << 26);
+        tdesc[6 * g + 1] = tp.grp_poff[g];
+        tdesc[6 * g + 2] = tp.grp_coff[g];
+        tdesc[6 * g + 3] = (nc > 1 ? tp.sh_aoff[sh0 + 1] : 0) | ((nc > 2 ? tp.sh_aoff[sh0 + 2] : 0) << 16);
+        tdesc[6 * g + 4] = sh0;
+        tdesc[6 * g + 5] = 0;
     }
     for (int idx = tid; idx < ngp; idx += NTHR) texps[idx] = tp.gexps[idx];
     for (int idx = tid; idx < ngc; idx += NTHR) tcoefs[idx] = tp.gcoefs[idx];
@@ -748,7 +823,7 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
     // DREG (n <= 64): the X = D chi jobs of a wave are the same (row tile, point tile) pairs in every tile, so the wave
     // keeps its density fragments in registers for the whole kernel -- reading them from L2 per tile made the phase a
     // chain of load latencies (probes: 30 % of the kernel for 10 % of its MFMA work)
-    constexpr int DJ = DREG ? 2 : 1, DK = DREG ? 16 : 1;
+    constexpr int DJ = DREG ? 2 : 1, DK = DREG ? (JMAX == 1 ? 8 : (JMAX == 3 ? 12 : 16)) : 1;      // k-steps = 4 row tiles' worth at most
     double dfrag[DJ][DK];
     if (DREG) {
 #pragma unroll
@@ -769,6 +844,9 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
     __syncthreads();
 
     const int probe = g_xc_probe;
+    // radial cache of this fragment (tiles of PT points), when the engine filled one with this tile size
+    const double* __restrict__ radf = (gd.rad && gd.rad_pt == PT)
+                                          ? gd.rad + (size_t)f * ((size_t)(gd.npts + PT - 1) / PT) * tp.nshell * 2 * PT : nullptr;
     auto ao_slab = [&](int g0) {
         if (probe & 1) return;
         // AO values (and gradients) of PT points: (radial group, point) items, point fastest
@@ -777,8 +855,13 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
             const int g = g0 + p;
             if (g < gd.npts) {
                 const int oa = gd.pt_atom[g], it = gd.pt_tmpl[g];
-                eval_group_lds<GGA>(gt, xyz, rg, xyz[3 * oa] + gd.tmpl_xyz[3 * it], xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1],
-                                    xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2], chi, gx, gy, gz, RS, p, bv.c2s);
+                if (radf)
+                    eval_group_cached<GGA>(gt, xyz, rg, xyz[3 * oa] + gd.tmpl_xyz[3 * it], xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1],
+                                           xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2], radf + (size_t)(g0 / PT) * tp.nshell * 2 * PT, PT,
+                                           chi, gx, gy, gz, RS, p, bv.c2s);
+                else
+                    eval_group_lds<GGA>(gt, xyz, rg, xyz[3 * oa] + gd.tmpl_xyz[3 * it], xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1],
+                                        xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2], chi, gx, gy, gz, RS, p, bv.c2s);
             } else {
                 zero_group<GGA>(tp, rg, chi, gx, gy, gz, RS, p);
             }
@@ -848,7 +931,22 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
             }
             __syncthreads();
         }
-        // ---- the functional: thread = point
+        // ---- the functional: lane = point, the components of the functional dealt to the four waves (one long
+        // dual-number instruction stream on 32 lanes of one wave was the critical path of a tile); partial sums
+        // f, v_rho, v_sigma meet in LDS
+        if (!XC_TWO_PASS) {
+            if (lane < PT) {
+                const double* rp = red + 4 * lane;
+                const double rho = rp[0], rx = 2.0 * rp[1], ry = 2.0 * rp[2], rz = 2.0 * rp[3];
+                const double sigma = GGA ? rx * rx + ry * ry + rz * rz : 0.0;
+                double fx, vr, vs;
+                if (probe & 4) { fx = wave == 0 ? -rho : 0.0; vr = wave == 0 ? -1.0 : 0.0; vs = 0.0; }
+                else eval_functional(bv.xc, rho, sigma, fx, vr, vs, wave, XV_NW);
+                double* pp = part + 3 * (wave * PT + lane);
+                pp[0] = fx; pp[1] = vr; pp[2] = vs;
+            }
+            __syncthreads();
+        }
         if (tid < SUPER) {
             const int p = tid;
             double* rp = red + 4 * p;
@@ -856,8 +954,13 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
             rp[0] = 0.0; rp[1] = 0.0; rp[2] = 0.0; rp[3] = 0.0;
             const double sigma = GGA ? rx * rx + ry * ry + rz * rz : 0.0;
             double fx, vr, vs;
-            if (probe & 4) { fx = -rho; vr = -1.0; vs = 0.0; }
+            if (!XC_TWO_PASS) {
+                fx = 0.0; vr = 0.0; vs = 0.0;
+#pragma unroll
+                for (int w4 = 0; w4 < XV_NW; ++w4) { const double* pp = part + 3 * (w4 * PT + p); fx += pp[0]; vr += pp[1]; vs += pp[2]; }
+            } else if (probe & 4) { fx = -rho; vr = -1.0; vs = 0.0; }
             else eval_functional(bv.xc, rho, sigma, fx, vr, vs);
+            (void)sigma;
             const double w = (s0 + p < gd.npts) ? wts[s0 + p] : 0.0;
             e_acc += w * fx;
             n_acc += w * rho;
@@ -927,8 +1030,8 @@ static void xc_tile_launch(const BatchView& bv, int oa, hipStream_t s)
     const int np = ((bv.n + 15) / 16) * 16;
     // + radial-group tables: 2 doubles of descriptor per group, the exponents and up to XC_GROUP_MAX coefficient rows;
     // groups <= shells <= n, primitives per group <= 63 (descriptor field); bounded by the topology's own totals
-    const size_t tab = 2 * (size_t)bv.topo.ngroup + (size_t)bv.topo.gprim_total + (size_t)bv.topo.gcoef_total + 8;
-    const size_t lds = sizeof(double) * ((size_t)(GGA ? 4 : 2) * np * (PT + 1) + 8 * (XC_TWO_PASS ? 64 * XV_NW : PT) + tab);
+    const size_t tab = 3 * (size_t)bv.topo.ngroup + (size_t)bv.topo.gprim_total + (size_t)bv.topo.gcoef_total + 8;
+    const size_t lds = sizeof(double) * ((size_t)(GGA ? 4 : 2) * np * (PT + 1) + 8 * (XC_TWO_PASS ? 64 * XV_NW : PT) + 3 * XV_NW * PT + tab);
     auto kern = xc_tile_kernel<GGA, PT, JMAX, OCC, DREG>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int tile_pts = XC_TWO_PASS ? 64 * XV_NW : PT;
