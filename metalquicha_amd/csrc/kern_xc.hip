@@ -773,8 +773,21 @@ constexpr bool XC_TWO_PASS = false;
 // MQC_HIP_XC_PROBE (timing experiments only, results are then meaningless): bit 0 skips the AO slab evaluation, bit 1 the
 // X = D chi jobs, bit 2 the functional (constants instead), bit 3 the accumulation A += a chi^T
 __device__ int g_xc_probe = 0;
+// In-kernel phase stamps (build with -DXC_STAMPS=1; never in the shipped library): every wave adds the cycles it spent
+// working in and waiting at the end of each phase of a tile; launch_xc prints the running totals to stderr.
+#ifndef XC_STAMPS
+#define XC_STAMPS 0
+#endif
+#if XC_STAMPS
+__device__ unsigned long long g_xc_stamps[16];
+#define XC_ST_DECL unsigned long long st_t = __builtin_amdgcn_s_memtime(), st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define XC_ST(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_t; st_t = t_; }
+#else
+#define XC_ST_DECL
+#define XC_ST(k)
+#endif
 
-template <bool GGA, int PT, int JMAX, int OCC, bool DREG>
+template <bool GGA, int PT, int JMAX, int OCC, bool DREG, int NTC>
 __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, int only_active)
 {
     // One tile = PT points: AO slab -> X = D chi, rho / grad rho -> functional (one lane per point) -> a -> A += a chi^T.
@@ -783,11 +796,15 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
     // the full-width functional saves: measured 2.09 s against 1.99 s per evaluation.  Kept for the record, off.)
     extern __shared__ double lds[];
     const int f = blockIdx.y;
-    if (only_active && bv.istate[4 * f] == ST_DONE) return;
+    const bool rad_in_lds = (only_active & 2) != 0;           // bit 1 of the flag word: radial tile staged in LDS
+    if ((only_active & 1) && bv.istate[4 * f] == ST_DONE) return;
     constexpr int RS = PT + 1, PT16 = PT / 16, NTHR = 64 * XV_NW, SUPER = XC_TWO_PASS ? NTHR : PT, NSUB = SUPER / PT;
     const int n = bv.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lo = lane & 15, hi = lane >> 4;
-    const int NT16 = (n + 15) >> 4, NP = NT16 << 4, KS = NP >> 2;
+    // NTC > 0: the number of 16-function tiles is a template constant (n <= 64), so that every k-loop and tile test
+    // below unrolls without a branch per step -- with a runtime count hipcc wrapped each LDS read and each MFMA of the
+    // X = D chi loop in its own scalar branch and spilled the loop's scalars into VGPR lanes
+    const int NT16 = NTC > 0 ? NTC : ((n + 15) >> 4), NP = NT16 << 4, KS = NP >> 2;
     const TopologyDev& tp = bv.topo;
     const GridDev& gd = bv.grid;
     double* chi = lds;                                        // [NP][RS]
@@ -796,12 +813,14 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
     double* gz = gy + (GGA ? (size_t)NP * RS : 0);
     double* red = gz + (GGA ? (size_t)NP * RS : 0);           // [SUPER][4] rho, grad rho sums of the super-tile
     double* coef = red + 4 * SUPER;                           // [SUPER][4] w v_rho / 2, 2 w v_sigma grad rho
-    double* part = coef + 4 * SUPER;                          // [XV_NW][PT][3] per-wave partial f, v_rho, v_sigma
-    double* tab = part + 3 * XV_NW * PT;                      // radial-group tables: desc ints, exponents, coefficients
+    double* axyz = coef + 4 * SUPER;                          // [64][3] this fragment's atoms
+    double* pxyz = axyz + 3 * 64;                             // [2][PT][3] grid points of the current / next tile
+    double* tab = pxyz + 6 * PT;                              // radial-group tables: desc ints, exponents, coefficients
     const int ng = tp.ngroup, ngp = tp.gprim_total, ngc = tp.gcoef_total;
     int* tdesc = (int*)tab;
     double* texps = tab + 3 * ng;
     double* tcoefs = texps + ngp;
+    double* radl = tab + (((size_t)(3 * ng + ngp + ngc + 8) + 1) & ~(size_t)1);      // [nshell][2][PT] radial tile (16-byte aligned)
     const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
     const double* __restrict__ D = bv.D + (size_t)f * n * n;
     const double* __restrict__ wts = gd.weights + (size_t)f * gd.npts;
@@ -820,10 +839,47 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
     for (int idx = tid; idx < ngp; idx += NTHR) texps[idx] = tp.gexps[idx];
     for (int idx = tid; idx < ngc; idx += NTHR) tcoefs[idx] = tp.gcoefs[idx];
     const GroupTables gt{tdesc, texps, tcoefs};
+    for (int idx = tid; idx < 3 * tp.natoms; idx += NTHR) axyz[idx] = xyz[idx];
+    // grid point coordinates of a tile into LDS (buffer b): one pair of dependent global loads per POINT, issued a tile
+    // ahead -- every (radial group, point) item used to walk pt_atom -> pt_tmpl -> tmpl_xyz itself, and the slab phase
+    // was a chain of L2 latencies
+    auto load_points = [&](int g0, int b, int q) {
+        const int g = g0 + q;
+        double x = 0.0, y = 0.0, z = 0.0;
+        if (g < gd.npts) {
+            const int oa = gd.pt_atom[g], it = gd.pt_tmpl[g];
+            x = xyz[3 * oa] + gd.tmpl_xyz[3 * it]; y = xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1]; z = xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2];
+        }
+        double* pp = pxyz + 3 * (b * PT + q);
+        pp[0] = x; pp[1] = y; pp[2] = z;
+    };
+    if (!XC_TWO_PASS && tid < PT) load_points(blockIdx.x * PT, 0, tid);
+    int pbuf = 0;
+    // radial cache of this fragment (tiles of PT points), when the engine filled one with this tile size
+    const double* __restrict__ radf = (gd.rad && gd.rad_pt == PT)
+                                          ? gd.rad + (size_t)f * ((size_t)(gd.npts + PT - 1) / PT) * tp.nshell * 2 * PT : nullptr;
+    // the radial values of a tile are one contiguous block of nshell x 2 x PT doubles in HBM: LDS-DMA moves it into
+    // LDS without registers (1 KiB per wave-instruction), issued as soon as the slab of the current tile has been
+    // built and landing under the MFMA phase -- read straight from HBM by the slab items, every item waited out an
+    // HBM round trip and the cache saved nothing over recomputing the exponentials
+    const int rad_bytes = tp.nshell * 2 * PT * 8;
+    auto stage_radial = [&](int tile) {
+        if (!rad_in_lds || tile * PT >= gd.npts) return;
+        const char* src = (const char*)(radf + (size_t)tile * tp.nshell * 2 * PT);
+        for (int c = wave; c * 1024 < rad_bytes; c += XV_NW) {
+            const int off = c * 1024 + lane * 16;
+            if (off < rad_bytes)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off),
+                                                 (__attribute__((address_space(3))) void*)((char*)radl + c * 1024), 16, 0, 0);
+        }
+    };
+    if (!XC_TWO_PASS) stage_radial(blockIdx.x);
+    int iter = 0;
     // DREG (n <= 64): the X = D chi jobs of a wave are the same (row tile, point tile) pairs in every tile, so the wave
     // keeps its density fragments in registers for the whole kernel -- reading them from L2 per tile made the phase a
     // chain of load latencies (probes: 30 % of the kernel for 10 % of its MFMA work)
-    constexpr int DJ = DREG ? 2 : 1, DK = DREG ? (JMAX == 1 ? 8 : (JMAX == 3 ? 12 : 16)) : 1;      // k-steps = 4 row tiles' worth at most
+    static_assert(!DREG || NTC > 0, "register-resident density fragments need a compile-time tile count");
+    constexpr int DJ = DREG ? (NTC * PT16 + XV_NW - 1) / XV_NW : 1, DK = DREG ? 4 * NTC : 1;      // X jobs per wave, k-steps per job
     double dfrag[DJ][DK];
     if (DREG) {
 #pragma unroll
@@ -842,11 +898,9 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
     for (int j = 0; j < JMAX; ++j) vacc[j] = (v4f64){0.0, 0.0, 0.0, 0.0};
     double e_acc = 0.0, n_acc = 0.0;
     __syncthreads();
+    XC_ST_DECL
 
     const int probe = g_xc_probe;
-    // radial cache of this fragment (tiles of PT points), when the engine filled one with this tile size
-    const double* __restrict__ radf = (gd.rad && gd.rad_pt == PT)
-                                          ? gd.rad + (size_t)f * ((size_t)(gd.npts + PT - 1) / PT) * tp.nshell * 2 * PT : nullptr;
     auto ao_slab = [&](int g0) {
         if (probe & 1) return;
         // AO values (and gradients) of PT points: (radial group, point) items, point fastest
@@ -854,14 +908,21 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
             const int rg = idx / PT, p = idx - rg * PT;
             const int g = g0 + p;
             if (g < gd.npts) {
-                const int oa = gd.pt_atom[g], it = gd.pt_tmpl[g];
-                if (radf)
-                    eval_group_cached<GGA>(gt, xyz, rg, xyz[3 * oa] + gd.tmpl_xyz[3 * it], xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1],
-                                           xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2], radf + (size_t)(g0 / PT) * tp.nshell * 2 * PT, PT,
+                double ptx, pty, ptz;
+                if (XC_TWO_PASS) {
+                    const int oa = gd.pt_atom[g], it = gd.pt_tmpl[g];
+                    ptx = xyz[3 * oa] + gd.tmpl_xyz[3 * it]; pty = xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1]; ptz = xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2];
+                } else {
+                    const double* pp = pxyz + 3 * (pbuf * PT + p);
+                    ptx = pp[0]; pty = pp[1]; ptz = pp[2];
+                }
+                if (rad_in_lds)
+                    eval_group_cached<GGA>(gt, axyz, rg, ptx, pty, ptz, radl, PT, chi, gx, gy, gz, RS, p, bv.c2s);
+                else if (radf)
+                    eval_group_cached<GGA>(gt, axyz, rg, ptx, pty, ptz, radf + (size_t)(g0 / PT) * tp.nshell * 2 * PT, PT,
                                            chi, gx, gy, gz, RS, p, bv.c2s);
                 else
-                    eval_group_lds<GGA>(gt, xyz, rg, xyz[3 * oa] + gd.tmpl_xyz[3 * it], xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1],
-                                        xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2], chi, gx, gy, gz, RS, p, bv.c2s);
+                    eval_group_lds<GGA>(gt, axyz, rg, ptx, pty, ptz, chi, gx, gy, gz, RS, p, bv.c2s);
             } else {
                 zero_group<GGA>(tp, rg, chi, gx, gy, gz, RS, p);
             }
@@ -875,11 +936,15 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
         for (int sub = 0; sub < NSUB; ++sub) {
             const int g0 = s0 + sub * PT;
             if (g0 >= gd.npts) break;
+            XC_ST(11)
             ao_slab(g0);
+            XC_ST(0)
             __syncthreads();
+            XC_ST(1)
+            if (!XC_TWO_PASS) stage_radial(st + (int)gridDim.x);      // lands under the MFMA phase below
             // X = D chi, job = (row tile mt, point tile pt); rho and grad rho from the accumulator rows
 #pragma unroll 2
-            for (int jj = 0; jj < (DREG ? DJ : 64); ++jj) {
+            for (int jj = 0; jj < (DREG ? DJ : 64); ++jj) {       // DREG: DJ <= 2, unrolled
                 const int job = wave + XV_NW * jj;
                 if (job >= NT16 * PT16 || (probe & 2)) break;
                 const int mt = job / PT16, pt = job - mt * PT16;
@@ -890,10 +955,10 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
                 if (DREG) {
                     double bw[DK];
 #pragma unroll
-                    for (int ks = 0; ks < DK; ++ks) bw[ks] = (ks < KS) ? chi[(4 * ks + hi) * RS + 16 * pt + lo] : 0.0;
+                    for (int ks = 0; ks < DK; ++ks) bw[ks] = chi[(4 * ks + hi) * RS + 16 * pt + lo];
 #pragma unroll
                     for (int ks = 0; ks < DK; ++ks)
-                        if (ks < KS) xacc = __builtin_amdgcn_mfma_f64_16x16x4f64(dfrag[jj < DJ ? jj : 0][ks], bw[ks], xacc, 0, 0, 0);
+                        xacc = __builtin_amdgcn_mfma_f64_16x16x4f64(dfrag[jj < DJ ? jj : 0][ks], bw[ks], xacc, 0, 0, 0);
                 } else
                 // eight k-steps at a time: the density elements (global, L1/L2) and the AO values (LDS) of a batch are all
                 // in flight before the MFMAs that consume them -- one load per MFMA made the loop a chain of L2 latencies
@@ -929,38 +994,41 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
                     if (GGA) { atomicAdd(&rp[1], rx); atomicAdd(&rp[2], ry); atomicAdd(&rp[3], rz); }
                 }
             }
+            XC_ST(2)
             __syncthreads();
+            XC_ST(3)
         }
-        // ---- the functional: lane = point, the components of the functional dealt to the four waves (one long
-        // dual-number instruction stream on 32 lanes of one wave was the critical path of a tile); partial sums
-        // f, v_rho, v_sigma meet in LDS
+        // ---- the functional: lane = point, on ONE wave -- a long dual-number instruction stream that keeps its SIMD's
+        // FP64 pipe busy by itself.  The wave ROTATES over the tiles: wave w of every workgroup sits on SIMD w, so with
+        // a fixed wave the functional phases of a CU's workgroups all queued on one SIMD while three idled.  (Dealing
+        // the functional's components to the four waves was measured slower: 1.39 s against 1.30 s per evaluation.)
         if (!XC_TWO_PASS) {
-            if (lane < PT) {
-                const double* rp = red + 4 * lane;
+            if (wave == ((iter + (int)blockIdx.x) & (XV_NW - 1)) && lane < PT) {
+                const int p = lane;
+                double* rp = red + 4 * p;
                 const double rho = rp[0], rx = 2.0 * rp[1], ry = 2.0 * rp[2], rz = 2.0 * rp[3];
+                rp[0] = 0.0; rp[1] = 0.0; rp[2] = 0.0; rp[3] = 0.0;
                 const double sigma = GGA ? rx * rx + ry * ry + rz * rz : 0.0;
                 double fx, vr, vs;
-                if (probe & 4) { fx = wave == 0 ? -rho : 0.0; vr = wave == 0 ? -1.0 : 0.0; vs = 0.0; }
-                else eval_functional(bv.xc, rho, sigma, fx, vr, vs, wave, XV_NW);
-                double* pp = part + 3 * (wave * PT + lane);
-                pp[0] = fx; pp[1] = vr; pp[2] = vs;
+                if (probe & 4) { fx = -rho; vr = -1.0; vs = 0.0; }
+                else eval_functional(bv.xc, rho, sigma, fx, vr, vs);
+                const double w = (s0 + p < gd.npts) ? wts[s0 + p] : 0.0;
+                e_acc += w * fx;
+                n_acc += w * rho;
+                double* cp = coef + 4 * p;
+                cp[0] = 0.5 * w * vr;
+                const double t2 = 2.0 * w * vs;
+                cp[1] = t2 * rx; cp[2] = t2 * ry; cp[3] = t2 * rz;
             }
-            __syncthreads();
-        }
-        if (tid < SUPER) {
+        } else if (tid < SUPER) {
             const int p = tid;
             double* rp = red + 4 * p;
             const double rho = rp[0], rx = 2.0 * rp[1], ry = 2.0 * rp[2], rz = 2.0 * rp[3];
             rp[0] = 0.0; rp[1] = 0.0; rp[2] = 0.0; rp[3] = 0.0;
             const double sigma = GGA ? rx * rx + ry * ry + rz * rz : 0.0;
             double fx, vr, vs;
-            if (!XC_TWO_PASS) {
-                fx = 0.0; vr = 0.0; vs = 0.0;
-#pragma unroll
-                for (int w4 = 0; w4 < XV_NW; ++w4) { const double* pp = part + 3 * (w4 * PT + p); fx += pp[0]; vr += pp[1]; vs += pp[2]; }
-            } else if (probe & 4) { fx = -rho; vr = -1.0; vs = 0.0; }
+            if (probe & 4) { fx = -rho; vr = -1.0; vs = 0.0; }
             else eval_functional(bv.xc, rho, sigma, fx, vr, vs);
-            (void)sigma;
             const double w = (s0 + p < gd.npts) ? wts[s0 + p] : 0.0;
             e_acc += w * fx;
             n_acc += w * rho;
@@ -973,18 +1041,28 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
         for (int sub = 0; sub < NSUB; ++sub) {
             const int g0 = s0 + sub * PT;
             if (g0 >= gd.npts) break;
+            XC_ST(4)
             __syncthreads();          // coef written / the previous sub-tile's MFMA reads are done
+            XC_ST(5)
             if (NSUB > 1) { ao_slab(g0); __syncthreads(); }       // single pass: the slab of pass 1 is still in LDS
+            // the next tile's grid points, a tile ahead (last PT threads)
+            if (!XC_TWO_PASS && tid >= NTHR - PT) load_points((st + (int)gridDim.x) * PT, pbuf ^ 1, tid - (NTHR - PT));
             // a[mu][p] = w v_rho / 2 chi + 2 w v_sigma grad rho . grad chi, written over gx
-            for (int idx = tid; idx < n * PT; idx += NTHR) {
-                const int mu = idx / PT, p = idx - mu * PT;
-                const int o = mu * RS + p;
+            {       // a thread's point is the same for all its elements (NTHR is a multiple of PT): its four weights once
+                const int p = tid % PT;
                 const double* cp = coef + 4 * (sub * PT + p);
-                double a = cp[0] * chi[o];
-                if (GGA) a += cp[1] * gx[o] + cp[2] * gy[o] + cp[3] * gz[o];
-                gx[o] = a;
+                const double c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
+#pragma unroll 3
+                for (int mu = tid / PT; mu < n; mu += NTHR / PT) {
+                    const int o = mu * RS + p;
+                    double a = c0 * chi[o];
+                    if (GGA) a += c1 * gx[o] + c2 * gy[o] + c3 * gz[o];
+                    gx[o] = a;
+                }
             }
+            XC_ST(6)
             __syncthreads();
+            XC_ST(7)
             // A += a chi^T: this wave's tiles t = wave, wave + XV_NW, ...
 #pragma unroll
             for (int j = 0; j < JMAX; ++j) {
@@ -998,8 +1076,17 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
                 }
             }
         }
+        pbuf ^= 1;
+        ++iter;
+        XC_ST(8)
         __syncthreads();
+        XC_ST(9)
     }
+#if XC_STAMPS
+    XC_ST(11)
+    if (lane == 0)
+        for (int k = 0; k < 12; ++k) atomicAdd(&g_xc_stamps[k], st_acc[k]);
+#endif
     // flush: lane holds A[mu = 16 mt + hi + 4 r][nu = 16 nt + lo]
     double* Vx = bv.Vxc + (size_t)f * n * n;
 #pragma unroll
@@ -1024,15 +1111,23 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
     }
 }
 
-template <bool GGA, int PT, int JMAX, int OCC, bool DREG>
+template <bool GGA, int PT, int JMAX, int OCC, bool DREG, int NTC>
 static void xc_tile_launch(const BatchView& bv, int oa, hipStream_t s)
 {
     const int np = ((bv.n + 15) / 16) * 16;
     // + radial-group tables: 2 doubles of descriptor per group, the exponents and up to XC_GROUP_MAX coefficient rows;
     // groups <= shells <= n, primitives per group <= 63 (descriptor field); bounded by the topology's own totals
     const size_t tab = 3 * (size_t)bv.topo.ngroup + (size_t)bv.topo.gprim_total + (size_t)bv.topo.gcoef_total + 8;
-    const size_t lds = sizeof(double) * ((size_t)(GGA ? 4 : 2) * np * (PT + 1) + 8 * (XC_TWO_PASS ? 64 * XV_NW : PT) + 3 * XV_NW * PT + tab);
-    auto kern = xc_tile_kernel<GGA, PT, JMAX, OCC, DREG>;
+    size_t lds = sizeof(double) * ((size_t)(GGA ? 4 : 2) * np * (PT + 1) + 8 * (XC_TWO_PASS ? 64 * XV_NW : PT) + 3 * 64 + 6 * PT + ((tab + 1) & ~(size_t)1));
+    // the radial tile rides in LDS when that does not cost a resident workgroup (OCC of them share 160 KB)
+    const size_t rad_lds = sizeof(double) * (size_t)bv.topo.nshell * 2 * PT;
+    static const bool rad_lds_on = [] { const char* e = std::getenv("MQC_HIP_XC_RADIAL_LDS"); return !(e && e[0] == '0'); }();
+    const size_t lds_cap = (size_t)160 * 1024 / (OCC < 1 ? 1 : OCC) - 512;
+    if (!XC_TWO_PASS && rad_lds_on && bv.grid.rad && bv.grid.rad_pt == PT && (lds + rad_lds <= lds_cap || (lds > lds_cap && lds + rad_lds <= 156 * 1024))) {
+        lds += rad_lds;
+        oa |= 2;
+    }
+    auto kern = xc_tile_kernel<GGA, PT, JMAX, OCC, DREG, NTC>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int tile_pts = XC_TWO_PASS ? 64 * XV_NW : PT;
     const int ntiles = (bv.grid.npts + tile_pts - 1) / tile_pts;
@@ -1045,25 +1140,19 @@ static void xc_tile_launch(const BatchView& bv, int oa, hipStream_t s)
 template <bool GGA>
 static bool xc_tile_dispatch(const BatchView& bv, int oa, hipStream_t s)
 {
-    // waves per SIMD the register allocation aims at for the 32-point kernels: 2 (224 registers, no scratch) or
-    // 3 (168 registers, ~160 B of scratch in the functional); MQC_HIP_XC_OCC picks, measured default below
-    static const int occ = [] { const char* e = std::getenv("MQC_HIP_XC_OCC"); return e ? std::atoi(e) : 2; }();
+    // 32-point tiles at two workgroups (eight waves) per CU: 256 registers, no scratch.  (A 168-register build for
+    // three waves per SIMD spilled ~300 B per lane in the functional and measured slower; removed.)
     const int nt = (bv.n + 15) / 16, jobs = (nt * nt + XV_NW - 1) / XV_NW;
-    if (nt <= 4) {                       // n <= 64: 32-point tiles
-        if (occ >= 3) {
-            if (jobs <= 1) xc_tile_launch<GGA, 32, 1, 3, true>(bv, oa, s);
-            else if (jobs <= 3) xc_tile_launch<GGA, 32, 3, 3, true>(bv, oa, s);
-            else xc_tile_launch<GGA, 32, 4, 3, true>(bv, oa, s);
-        } else {
-            if (jobs <= 1) xc_tile_launch<GGA, 32, 1, 2, true>(bv, oa, s);
-            else if (jobs <= 3) xc_tile_launch<GGA, 32, 3, 2, true>(bv, oa, s);
-            else xc_tile_launch<GGA, 32, 4, 2, true>(bv, oa, s);
-        }
+    if (nt <= 4) {                       // n <= 64
+        if (nt == 1) xc_tile_launch<GGA, 32, 1, 2, true, 1>(bv, oa, s);
+        else if (nt == 2) xc_tile_launch<GGA, 32, 1, 2, true, 2>(bv, oa, s);
+        else if (nt == 3) xc_tile_launch<GGA, 32, 3, 2, true, 3>(bv, oa, s);
+        else xc_tile_launch<GGA, 32, 4, 2, true, 4>(bv, oa, s);
         return true;
     }
-    if (jobs <= 9) xc_tile_launch<GGA, 16, 9, 1, false>(bv, oa, s);             // n <= 96
-    else if (jobs <= 16) xc_tile_launch<GGA, 16, 16, 1, false>(bv, oa, s);      // n <= 128
-    else if (jobs <= 21) xc_tile_launch<GGA, 16, 21, 1, false>(bv, oa, s);      // n <= 144
+    if (jobs <= 9) xc_tile_launch<GGA, 16, 9, 1, false, 0>(bv, oa, s);             // n <= 96
+    else if (jobs <= 16) xc_tile_launch<GGA, 16, 16, 1, false, 0>(bv, oa, s);      // n <= 128
+    else if (jobs <= 21) xc_tile_launch<GGA, 16, 21, 1, false, 0>(bv, oa, s);      // n <= 144
     else return false;
     return true;
 }
@@ -1101,7 +1190,16 @@ void launch_xc(const BatchView& bv, bool only_active, hipStream_t s)
     (void)probed;
     // MQC_HIP_XC_V1=1: the round-1 kernels (wave-private MFMA kernel for n <= 48, VALU kernel above), kept for A/B runs
     static const bool v1 = [] { const char* e = std::getenv("MQC_HIP_XC_V1"); return e && e[0] == '1'; }();
-    if (!v1 && (gga ? xc_tile_dispatch<true>(bv, oa, s) : xc_tile_dispatch<false>(bv, oa, s))) return;
+    if (!v1 && (gga ? xc_tile_dispatch<true>(bv, oa, s) : xc_tile_dispatch<false>(bv, oa, s))) {
+#if XC_STAMPS
+        (void)hipStreamSynchronize(s);
+        unsigned long long h[16];
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_xc_stamps), sizeof(h));
+        std::fprintf(stderr, "xc stamps n=%d nfrag=%d: slab %llu wait %llu | X %llu wait %llu | functional %llu wait %llu | a %llu wait %llu | A %llu wait %llu | other %llu\n",
+                     bv.n, bv.nfrag, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[11]);
+#endif
+        return;
+    }
     if (n <= 48) {
         // fragment sizes of an MBE run: both GEMMs on the FP64 matrix cores
         if (n <= 32) { if (gga) xc_mfma_launch<true, 2>(bv, oa, s); else xc_mfma_launch<false, 2>(bv, oa, s); }

@@ -361,8 +361,8 @@ print(json.dumps(out))
 
 def test_xc_tiled_kernel_matches_the_round1_kernels():
     """The workgroup-tiled MFMA quadrature kernel (default; n = 24, 48, 72 here) against the round-1 kernels
-    (MQC_HIP_XC_V1=1: wave-private MFMA kernel for n <= 48, VALU kernel above) and with both register targets
-    (MQC_HIP_XC_OCC=3): same iteration counts, energies within the summation-order noise of the quadrature."""
+    (MQC_HIP_XC_V1=1: wave-private MFMA kernel for n <= 48, VALU kernel above) and without the radial-value cache
+    (MQC_HIP_XC_RADIAL_CACHE=0: exponentials evaluated in the kernel): same iteration counts, energies within the summation-order noise of the quadrature."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -372,7 +372,7 @@ def test_xc_tiled_kernel_matches_the_round1_kernels():
                              timeout=900).stdout.strip().splitlines()[-1]
         return json.loads(out)
 
-    new, old, occ3 = run({}), run({"MQC_HIP_XC_V1": "1"}), run({"MQC_HIP_XC_OCC": "3"})
+    new, old, occ3 = run({}), run({"MQC_HIP_XC_V1": "1"}), run({"MQC_HIP_XC_RADIAL_CACHE": "0"})
     for fn in ("svwn", "b3lyp"):
         assert not new[fn]["err"] and not old[fn]["err"] and not occ3[fn]["err"], (new[fn]["err"], old[fn]["err"], occ3[fn]["err"])
         assert new[fn]["it"] == old[fn]["it"] == occ3[fn]["it"]
