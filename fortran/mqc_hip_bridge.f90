@@ -117,6 +117,7 @@ contains
       case ("gwh"); opts%guess = MQC_HIP_GUESS_GWH
       case ("auto"); opts%guess = MQC_HIP_GUESS_AUTO
       case ("sad"); opts%guess = MQC_HIP_GUESS_SAD
+      case ("sac"); opts%guess = MQC_HIP_GUESS_SAC
       case default
          ! refused rather than replaced by another guess, as the cuEST driver does (:104-121)
          call fail(result, ERROR_VALIDATION, "initial guess '"//trim(settings%guess)// &

@@ -16,7 +16,7 @@ module mqc_hip_c
    integer(c_int), parameter, public :: MQC_HIP_SCF_NOT_RUN = 0, MQC_HIP_SCF_CONVERGED = 1, &
                                         MQC_HIP_SCF_NOT_CONVERGED = 2
    integer(c_int), parameter, public :: MQC_HIP_GUESS_AUTO = 0, MQC_HIP_GUESS_CORE = 1, MQC_HIP_GUESS_GWH = 2, &
-                                        MQC_HIP_GUESS_SAD = 3
+                                        MQC_HIP_GUESS_SAD = 3, MQC_HIP_GUESS_SAC = 4
 
    type, bind(C), public :: mqc_hip_molecule_t
       integer(c_int32_t) :: n_atoms

@@ -55,7 +55,10 @@ enum { MQC_HIP_SCF_NOT_RUN = 0, MQC_HIP_SCF_CONVERGED = 1, MQC_HIP_SCF_NOT_CONVE
 
 /* initial guess (cuest_scf_settings_t%guess, src/methods/mqc_cuest_iface.f90:104-121).
  * AUTO resolves to GWH, as the cuEST backend does. */
-enum { MQC_HIP_GUESS_AUTO = 0, MQC_HIP_GUESS_CORE = 1, MQC_HIP_GUESS_GWH = 2, MQC_HIP_GUESS_SAD = 3 };
+enum { MQC_HIP_GUESS_AUTO = 0, MQC_HIP_GUESS_CORE = 1, MQC_HIP_GUESS_GWH = 2, MQC_HIP_GUESS_SAD = 3,
+       MQC_HIP_GUESS_SAC = 4 };   /* AUTO = GWH, as run_cuest_scf's default (mqc_cuest_driver.f90:107-114); SAD / SAC =
+                                     superposed free-atom densities, spherically averaged / as converged
+                                     (mqc_libcint_atomic_guess.f90:295-378; SAC restricted only) */
 
 /* two-electron path.  AUTO = in-core packed ERIs in HBM when they fit the per-fragment
  * budget, else the direct build (the reference's choice at mqc_libcint_bridge.f90:819-892,

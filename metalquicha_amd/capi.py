@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmqc_hip.
 MQC_HIP_OK = 0
 ERR_VALIDATION, ERR_GENERIC, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_DEVICE = 1, 2, 3, 4, 5
 SCF_NOT_RUN, SCF_CONVERGED, SCF_NOT_CONVERGED = 0, 1, 2
-GUESS_AUTO, GUESS_CORE, GUESS_GWH = 0, 1, 2
+GUESS_AUTO, GUESS_CORE, GUESS_GWH, GUESS_SAD, GUESS_SAC = 0, 1, 2, 3, 4
 ERI_AUTO, ERI_INCORE, ERI_DIRECT = 0, 1, 2
 
 c_double_p = C.POINTER(C.c_double)

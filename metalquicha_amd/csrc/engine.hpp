@@ -196,6 +196,8 @@ struct mqc_hip_context {
     std::mutex stats_mutex;
     // topologies of recent calls (shell tables, quartet class lists): an MBE driver sends the same few again and again
     std::map<std::string, std::shared_ptr<mqc::Topology>> topo_cache;
+    // converged free atoms of the superposed-atom guesses: total density (n_atom_ao^2, row-major) per element + shells
+    std::map<std::string, std::shared_ptr<std::vector<double>>> atom_cache;
     int concurrent_groups = 1;          // 1: topology groups of one batch call run two at a time (one per slot)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     size_t hbm_budget_bytes = 0;
@@ -240,6 +242,7 @@ void launch_direct_setup(const BatchView& bv, const Topology& topo, hipStream_t 
 void launch_jk_direct(const BatchView& bv, const Topology& topo, double thresh, bool only_active, hipStream_t s);
 void launch_orthogonalizer(const BatchView& bv, hipStream_t s);
 void launch_guess(const BatchView& bv, int guess_kind, hipStream_t s);
+void launch_broadcast(double* dst, const double* src, size_t count, int nfrag, hipStream_t s);   // dst[f][i] = src[i]
 void launch_scf_step(const BatchView& bv, hipStream_t s);
 void launch_syev(int n, double* dA, double* dw, double* dV, hipStream_t s);
 void launch_diis_coeff(int n_stored, const double* d_overlap, double* d_coef, int* d_ok, hipStream_t s);

@@ -436,6 +436,9 @@ __global__ void __launch_bounds__(NT) guess_kernel(BatchView bv, int guess_kind)
         const int i = idx / n, j = idx - i * n;
         double v = p.H[idx];
         if (guess_kind == MQC_HIP_GUESS_GWH && i != j) v = 0.5 * GWH_K * p.S[idx] * (p.H[i * n + i] + p.H[j * n + j]);
+        // superposed atoms: the Hartree-Fock Fock matrix of the guess density, J and K built by the engine just before
+        // (atomic_guess_fock, mqc_libcint_rhf.f90:1382-1411: full exchange whatever the functional)
+        if (guess_kind == MQC_HIP_GUESS_SAD) v += p.J[idx] - 0.5 * p.K[idx];
         p.F[idx] = v;
     }
     __syncthreads();
@@ -648,16 +651,26 @@ __global__ void __launch_bounds__(NT) scf_step_uhf_kernel(BatchView bv)
     const size_t nn = (size_t)n * n;
     JacobiLds jl = carve_jacobi(lds, m, VLDS, nullptr);
 
+    // unrestricted Kohn-Sham: exchange scaled by the functional's fraction, the energy from the Fock matrices BEFORE
+    // the spin potentials are added, plus E_xc; V_s = A_s + A_s^T with A_b behind A_a (kern_xc.hip, xc_uks_kernel)
     double e = 0.0;
+    const double* Axa = bv.Vxc ? bv.Vxc + (size_t)f * nn : nullptr;
+    const double* Axb = bv.Vxc ? bv.Vxc + ((size_t)bv.nfrag + f) * nn : nullptr;
     for (int idx = tid; idx < n * n; idx += NT) {
         const double h = pa.H[idx];
         const double j = pa.J[idx] + pb.J[idx];
-        const double fa = h + j - bv.exx * pa.K[idx];
-        const double fb = h + j - bv.exx * pb.K[idx];
+        double fa = h + j - bv.exx * pa.K[idx];
+        double fb = h + j - bv.exx * pb.K[idx];
         e += pa.D[idx] * (h + fa) + pb.D[idx] * (h + fb);
+        if (Axa) {
+            const int i = idx / n, jj = idx - i * n;
+            fa += Axa[idx] + Axa[jj * n + i];
+            fb += Axb[idx] + Axb[jj * n + i];
+        }
         pa.F[idx] = fa; pb.F[idx] = fb;
     }
     e = 0.5 * block_sum(e, jl.red);
+    if (Axa) e += pa.scal[5];
     if (state == ST_FINAL) {
         if (tid == 0) { pa.scal[4] = e; pa.istate[0] = ST_DONE; }
         return;
@@ -800,6 +813,17 @@ static void apply_jacobi_env()
         return true;
     }();
     (void)done;
+}
+
+__global__ void broadcast_kernel(double* dst, const double* src, size_t count)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) dst[(size_t)blockIdx.y * count + i] = src[i];
+}
+
+void launch_broadcast(double* dst, const double* src, size_t count, int nfrag, hipStream_t s)
+{
+    hipLaunchKernelGGL(broadcast_kernel, dim3((unsigned)((count + 255) / 256), nfrag), dim3(256), 0, s, dst, src, count);
 }
 
 void launch_scf_step(const BatchView& bv, hipStream_t s)

@@ -168,6 +168,167 @@ __device__ __forceinline__ void eval_functional(const XcSpec& xc, double rho, do
     }
 }
 
+// ------------------------------------------------------------------ spin-polarised forms (unrestricted Kohn-Sham)
+// value + derivatives with respect to (rho_a, rho_b, sigma_aa, sigma_ab, sigma_bb): the layout of libxc's polarised
+// calls as xc_add_potential_uks feeds them (mqc_libcint_xc.F90:938-951).  Closed forms: the spin-scaling relations
+// of exchange, VWN's zeta interpolations, Miehlich's gradient-only LYP for two spin densities, PBE correlation with
+// phi(zeta) and the spin-polarised PW92 ("pw_mod") local part.
+struct D5 {
+    double v, d[5];
+};
+__device__ __forceinline__ D5 mk5(double v) { return {v, {0.0, 0.0, 0.0, 0.0, 0.0}}; }
+__device__ __forceinline__ D5 var5(double v, int i) { D5 r = mk5(v); r.d[i] = 1.0; return r; }
+__device__ __forceinline__ D5 operator+(D5 a, D5 b) { D5 r; r.v = a.v + b.v; for (int i = 0; i < 5; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+__device__ __forceinline__ D5 operator-(D5 a, D5 b) { D5 r; r.v = a.v - b.v; for (int i = 0; i < 5; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+__device__ __forceinline__ D5 operator-(D5 a) { D5 r; r.v = -a.v; for (int i = 0; i < 5; ++i) r.d[i] = -a.d[i]; return r; }
+__device__ __forceinline__ D5 operator*(D5 a, D5 b) { D5 r; r.v = a.v * b.v; for (int i = 0; i < 5; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+__device__ __forceinline__ D5 operator/(D5 a, D5 b)
+{
+    const double inv = xc_rcp(b.v), q = a.v * inv;
+    D5 r; r.v = q;
+    for (int i = 0; i < 5; ++i) r.d[i] = (a.d[i] - q * b.d[i]) * inv;
+    return r;
+}
+__device__ __forceinline__ D5 operator+(D5 a, double b) { a.v += b; return a; }
+__device__ __forceinline__ D5 operator+(double b, D5 a) { a.v += b; return a; }
+__device__ __forceinline__ D5 operator-(D5 a, double b) { a.v -= b; return a; }
+__device__ __forceinline__ D5 operator-(double b, D5 a) { return mk5(b) - a; }
+__device__ __forceinline__ D5 operator*(D5 a, double b) { a.v *= b; for (int i = 0; i < 5; ++i) a.d[i] *= b; return a; }
+__device__ __forceinline__ D5 operator*(double b, D5 a) { return a * b; }
+__device__ __forceinline__ D5 operator/(D5 a, double b) { return a * xc_rcp(b); }
+__device__ __forceinline__ D5 operator/(double b, D5 a) { return mk5(b) / a; }
+__device__ __forceinline__ D5 chain5(D5 x, double f, double df) { D5 r; r.v = f; for (int i = 0; i < 5; ++i) r.d[i] = df * x.d[i]; return r; }
+__device__ __forceinline__ D5 exp5(D5 x) { const double f = exp(x.v); return chain5(x, f, f); }
+__device__ __forceinline__ D5 log5(D5 x) { return chain5(x, log(x.v), xc_rcp(x.v)); }
+__device__ __forceinline__ D5 sqrt5(D5 x) { const double i = xc_rsqrt(x.v); return chain5(x, x.v * i, 0.5 * i); }
+__device__ __forceinline__ D5 atan5(D5 x) { return chain5(x, atan(x.v), xc_rcp(1.0 + x.v * x.v)); }
+__device__ __forceinline__ D5 asinh5(D5 x) { return chain5(x, asinh(x.v), xc_rsqrt(1.0 + x.v * x.v)); }
+__device__ __forceinline__ D5 pow5(D5 x, double p) { const double f = pow(x.v, p); return chain5(x, f, p * f * xc_rcp(x.v)); }
+__device__ __forceinline__ D5 cbrt5(D5 x) { const double f = cbrt(x.v); return chain5(x, f, f * xc_rcp(3.0 * x.v)); }
+
+__device__ __forceinline__ D5 zeta_f5(D5 opz13, D5 omz13, D5 z)
+{
+    // f(zeta) = [(1+z)^(4/3) + (1-z)^(4/3) - 2] / (2^(4/3) - 2), from the cube roots of 1 +- zeta
+    return ((1.0 + z) * opz13 + (1.0 - z) * omz13 - 2.0) * (1.0 / 0.5198420997897464);
+}
+__device__ __forceinline__ D5 vwn_aux5(D5 x /* sqrt(rs) */, double A, double x0, double b, double c)
+{
+    const D5 X = x * x + b * x + c;
+    const double X0 = x0 * x0 + b * x0 + c;
+    const double Q = sqrt(4.0 * c - b * b);
+    const D5 at = atan5(Q / (2.0 * x + b));
+    const D5 xm = x - x0;
+    return A * (log5(x * x / X) + (2.0 * b / Q) * at - (b * x0 / X0) * (log5(xm * xm / X) + (2.0 * (b + 2.0 * x0) / Q) * at));
+}
+__device__ __forceinline__ D5 b88_spin5(D5 r, D5 s)
+{
+    const double beta = 0.0042, cx = 0.9305257363491;
+    const D5 r43 = r * cbrt5(r);
+    const D5 x = sqrt5(s) / r43;
+    return -cx * r43 - beta * r43 * x * x / (1.0 + 6.0 * beta * x * asinh5(x));
+}
+__device__ __forceinline__ D5 pbe_x_unpol5(D5 rho, D5 sigma)
+{
+    const D5 r13 = cbrt5(rho);
+    const D5 kf = 3.0936677262801355 * r13;
+    const D5 s2 = sigma / (4.0 * kf * kf * rho * rho);
+    const D5 fx = (1.0 + PBE_KAPPA) - PBE_KAPPA / (1.0 + (PBE_MU / PBE_KAPPA) * s2);
+    return -0.7385587663820224 * (rho * r13) * fx;
+}
+__device__ __forceinline__ D5 pw_mod_g5(D5 rs, D5 srs, double A, double a1, double b1, double b2, double b3, double b4)
+{
+    const D5 q = 2.0 * A * (b1 * srs + b2 * rs + b3 * rs * srs + b4 * rs * rs);
+    return -2.0 * A * (1.0 + a1 * rs) * log5(1.0 + 1.0 / q);
+}
+
+constexpr double XC_SPIN_FLOOR = 1.0e-30;        // a spin density below this is held there: zeta stays inside (-1, 1)
+
+// f per volume and its five derivatives; zero where the TOTAL density is below the threshold
+__device__ __forceinline__ void eval_functional_pol(const XcSpec& xc, double ra_in, double rb_in, double saa, double sab, double sbb,
+                                                    double& f, double* dv)
+{
+    f = 0.0;
+    for (int i = 0; i < 5; ++i) dv[i] = 0.0;
+    if (!(ra_in + rb_in > XC_DENS_THRESHOLD)) return;
+    const D5 ra = var5(fmax(ra_in, XC_SPIN_FLOOR), 0), rb = var5(fmax(rb_in, XC_SPIN_FLOOR), 1);
+    const D5 Saa = var5(fmax(saa, 1.0e-40), 2), Sab = var5(sab, 3), Sbb = var5(fmax(sbb, 1.0e-40), 4);
+    const D5 rho = ra + rb;
+    const D5 r13 = cbrt5(rho);
+    const D5 z = (ra - rb) / rho;
+    const D5 opz13 = cbrt5(1.0 + z), omz13 = cbrt5(1.0 - z);
+    const D5 rs = 0.6203504908994001 / r13;
+    const D5 sig = Saa + 2.0 * Sab + Sbb;
+    for (int k = 0; k < xc.ncomp; ++k) {
+        D5 d;
+        switch (xc.id[k]) {
+            case XC_LDA_X:
+                d = -0.7385587663820224 * 1.2599210498948732 * (ra * cbrt5(ra) + rb * cbrt5(rb));
+                break;
+            case XC_LDA_C_VWN: {
+                const D5 x = sqrt5(rs);
+                const D5 eP = vwn_aux5(x, 0.0310907, -0.10498, 3.72744, 12.9352);
+                const D5 eF = vwn_aux5(x, 0.01554535, -0.32500, 7.06042, 18.0578);
+                const D5 aC = vwn_aux5(x, -0.016886863940389628 /* -1/(6 pi^2) */, -0.0047584, 1.13107, 13.0045);
+                const D5 fz = zeta_f5(opz13, omz13, z);
+                const D5 z2 = z * z, z4 = z2 * z2;
+                d = rho * (eP + aC * fz * (1.0 - z4) * (1.0 / 1.7099209341613653) + (eF - eP) * fz * z4);
+                break;
+            }
+            case XC_LDA_C_VWN_RPA: {
+                const D5 x = sqrt5(rs);
+                const D5 eP = vwn_aux5(x, 0.0310907, -0.409286, 13.0720, 42.7198);
+                const D5 eF = vwn_aux5(x, 0.01554535, -0.743294, 20.1231, 101.578);
+                const D5 fz = zeta_f5(opz13, omz13, z);
+                d = rho * (eP * (1.0 - fz) + eF * fz);
+                break;
+            }
+            case XC_GGA_X_B88: d = b88_spin5(ra, Saa) + b88_spin5(rb, Sbb); break;
+            case XC_GGA_C_LYP: {
+                const double a = 0.04918, b = 0.132, c = 0.2533, dd = 0.349, cf = 2.871234000188191;
+                const D5 rm13 = 1.0 / r13;
+                const D5 den = 1.0 + dd * rm13;
+                const D5 rm113 = rm13 * rm13 / (rho * rho * rho);              // rho^(-11/3)
+                const D5 omega = exp5(-c * rm13) / den * rm113;
+                const D5 delta = c * rm13 + dd * rm13 / den;
+                const D5 rab = ra * rb;
+                const D5 ra13 = cbrt5(ra), rb13 = cbrt5(rb);
+                const D5 ra83 = ra * ra * ra13 * ra13, rb83 = rb * rb * rb13 * rb13;
+                const D5 t1 = (12.699208415745595 * cf) * (ra83 + rb83);        // 2^(11/3) C_F (ra^(8/3) + rb^(8/3))
+                const D5 t2 = (47.0 / 18.0 - (7.0 / 18.0) * delta) * sig;
+                const D5 t3 = (2.5 - delta * (1.0 / 18.0)) * (Saa + Sbb);
+                const D5 t4 = (delta - 11.0) * (1.0 / 9.0) * (ra * Saa + rb * Sbb) / rho;
+                const D5 r2 = (2.0 / 3.0) * rho * rho;
+                const D5 br = rab * (t1 + t2 - t3 - t4) - r2 * sig + (r2 - ra * ra) * Sbb + (r2 - rb * rb) * Saa;
+                d = -4.0 * a / den * rab / rho - (a * b) * omega * br;
+                break;
+            }
+            case XC_GGA_X_PBE: d = 0.5 * (pbe_x_unpol5(2.0 * ra, 4.0 * Saa) + pbe_x_unpol5(2.0 * rb, 4.0 * Sbb)); break;
+            case XC_GGA_C_PBE: {
+                const D5 srs = sqrt5(rs);
+                const D5 g0 = pw_mod_g5(rs, srs, 0.0310907, 0.21370, 7.5957, 3.5876, 1.6382, 0.49294);
+                const D5 g1 = pw_mod_g5(rs, srs, 0.01554535, 0.20548, 14.1189, 6.1977, 3.3662, 0.62517);
+                const D5 g2 = pw_mod_g5(rs, srs, 0.0168869, 0.11125, 10.357, 3.6231, 0.88026, 0.49671);       // = -alpha_c
+                const D5 fz = zeta_f5(opz13, omz13, z);
+                const D5 z2 = z * z, z4 = z2 * z2;
+                const D5 ec = g0 - g2 * fz * (1.0 - z4) * (1.0 / 1.709920934161365617563962776245) + (g1 - g0) * fz * z4;
+                const D5 phi = 0.5 * (opz13 * opz13 + omz13 * omz13);
+                const D5 phi3 = phi * phi * phi;
+                const D5 kf = 3.0936677262801355 * r13;
+                const D5 ks2 = (4.0 / M_PI) * kf;
+                const D5 t2 = sig / (4.0 * phi * phi * ks2 * rho * rho);
+                const D5 Aa = (PBE_BETA / PBE_GAMMA) / (exp5(-ec / (PBE_GAMMA * phi3)) - 1.0);
+                const D5 at2 = Aa * t2;
+                const D5 H = PBE_GAMMA * phi3 * log5(1.0 + (PBE_BETA / PBE_GAMMA) * t2 * (1.0 + at2) / (1.0 + at2 + at2 * at2));
+                d = rho * (ec + H);
+                break;
+            }
+            default: d = mk5(0.0);
+        }
+        f += xc.w[k] * d.v;
+        for (int i = 0; i < 5; ++i) dv[i] += xc.w[k] * d.d[i];
+    }
+}
+
 // ------------------------------------------------------------------ Becke / Treutler partition weights
 __device__ __forceinline__ double becke_cutoff(double nu)
 {
@@ -1177,12 +1338,165 @@ static void xc_launch(const BatchView& bv, int oa, hipStream_t s)
     hipLaunchKernelGGL(kern, dim3(gx, bv.nfrag), dim3(XC_NT), lds, s, bv, oa);
 }
 
+// ------------------------------------------------------------------ unrestricted Kohn-Sham
+// xc_add_potential_uks (mqc_libcint_xc.F90:929-1119): one AO evaluation per tile, the two spin densities from
+// D_a = C_a C_a^T and D_b (not doubled), the polarised functional, and per spin
+//     V_s = A_s + A_s^T,  A_s = (w (v_rho_s / 2 chi + (2 v_ss grad rho_s + v_ab grad rho_s') . grad chi))^T chi.
+// One launch per spin (flag bit 1 = beta): the densities and the functional are formed in both, the n x n update of
+// ONE spin accumulates in registers -- two accumulator sets would not fit for n ~ 100.  E_xc and N_e come from the
+// alpha launch.  V_b lives behind V_a in bv.Vxc ([2][nfrag][n*n]).  VALU contractions: a parity-first kernel; the
+// restricted path is the tuned one.
+template <bool GGA, int PT, int NV>
+__global__ void __launch_bounds__(XC_NT) xc_uks_kernel(BatchView bv, int flags)
+{
+    extern __shared__ double lds[];
+    const int f = blockIdx.y;
+    const bool beta = (flags & 2) != 0;
+    if ((flags & 1) && bv.istate[4 * f] == ST_DONE) return;
+    const int n = bv.n, tid = threadIdx.x;
+    const TopologyDev& tp = bv.topo;
+    const GridDev& gd = bv.grid;
+    constexpr int PTP = PT + 1;
+    double* chi = lds;
+    double* gx = chi + (size_t)n * PTP;
+    double* gy = gx + (GGA ? (size_t)n * PTP : 0);
+    double* gz = gy + (GGA ? (size_t)n * PTP : 0);
+    double* Xa = gz + (GGA ? (size_t)n * PTP : 0);
+    double* Xb = Xa + (size_t)n * PTP;
+    double* A = Xb + (size_t)n * PTP;
+    double* pw = A + (size_t)n * PTP;                 // [PT] weights
+    double* pc = pw + PT;                             // [4][PT] this spin's v_rho w / 2 and gradient coefficient vector
+
+    const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
+    const double* __restrict__ Da = bv.D + (size_t)f * n * n;
+    const double* __restrict__ Db = bv.Db + (size_t)f * n * n;
+    const double* __restrict__ wts = gd.weights + (size_t)f * gd.npts;
+
+    double acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = 0.0;
+    double e_acc = 0.0, n_acc = 0.0;
+
+    const int ntiles = (gd.npts + PT - 1) / PT;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int g0 = tile * PT;
+        for (int idx = tid; idx < tp.ngroup * PT; idx += XC_NT) {
+            const int rg = idx / PT, p = idx - rg * PT;
+            const int g = g0 + p;
+            if (g < gd.npts) {
+                const int oa = gd.pt_atom[g], it = gd.pt_tmpl[g];
+                eval_group<GGA>(tp, xyz, rg, xyz[3 * oa] + gd.tmpl_xyz[3 * it], xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1],
+                                xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2], chi, gx, gy, gz, PTP, p, bv.c2s);
+            } else {
+                zero_group<GGA>(tp, rg, chi, gx, gy, gz, PTP, p);
+            }
+        }
+        if (tid < PT) pw[tid] = (g0 + tid < gd.npts) ? wts[g0 + tid] : 0.0;
+        __syncthreads();
+        for (int idx = tid; idx < n * PT; idx += XC_NT) {
+            const int mu = idx / PT, p = idx - mu * PT;
+            const double* __restrict__ ra = Da + (size_t)mu * n;
+            const double* __restrict__ rb = Db + (size_t)mu * n;
+            double sa = 0.0, sb = 0.0;
+            for (int nu = 0; nu < n; ++nu) { const double c = chi[nu * PTP + p]; sa += ra[nu] * c; sb += rb[nu] * c; }
+            Xa[mu * PTP + p] = sa; Xb[mu * PTP + p] = sb;
+        }
+        __syncthreads();
+        if (tid < PT) {
+            const int p = tid;
+            double ra = 0.0, rb = 0.0, ga[3] = {0.0, 0.0, 0.0}, gb[3] = {0.0, 0.0, 0.0};
+            for (int mu = 0; mu < n; ++mu) {
+                const double xa = Xa[mu * PTP + p], xb = Xb[mu * PTP + p], c = chi[mu * PTP + p];
+                ra += xa * c; rb += xb * c;
+                if (GGA) {
+                    const double dx = gx[mu * PTP + p], dy = gy[mu * PTP + p], dz = gz[mu * PTP + p];
+                    ga[0] += xa * dx; ga[1] += xa * dy; ga[2] += xa * dz;
+                    gb[0] += xb * dx; gb[1] += xb * dy; gb[2] += xb * dz;
+                }
+            }
+            for (int d = 0; d < 3; ++d) { ga[d] *= 2.0; gb[d] *= 2.0; }
+            const double saa = ga[0] * ga[0] + ga[1] * ga[1] + ga[2] * ga[2];
+            const double sab = ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2];
+            const double sbb = gb[0] * gb[0] + gb[1] * gb[1] + gb[2] * gb[2];
+            double fx, dv[5];
+            eval_functional_pol(bv.xc, ra, rb, saa, sab, sbb, fx, dv);
+            const double w = pw[p];
+            e_acc += w * fx;
+            n_acc += w * (ra + rb);
+            pc[p] = 0.5 * w * (beta ? dv[1] : dv[0]);
+            if (GGA) {
+                const double vss = beta ? dv[4] : dv[2], vab = dv[3];
+                for (int d = 0; d < 3; ++d) pc[(1 + d) * PT + p] = w * (2.0 * vss * (beta ? gb[d] : ga[d]) + vab * (beta ? ga[d] : gb[d]));
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < n * PT; idx += XC_NT) {
+            const int mu = idx / PT, p = idx - mu * PT;
+            double a = pc[p] * chi[mu * PTP + p];
+            if (GGA) a += pc[PT + p] * gx[mu * PTP + p] + pc[2 * PT + p] * gy[mu * PTP + p] + pc[3 * PT + p] * gz[mu * PTP + p];
+            A[mu * PTP + p] = a;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int idx = tid + XC_NT * k;
+            if (idx < n * n) {
+                const int mu = idx / n, nu = idx - mu * n;
+                const double* __restrict__ ar = A + mu * PTP;
+                const double* __restrict__ cr = chi + nu * PTP;
+                double sum = 0.0;
+#pragma unroll 8
+                for (int p = 0; p < PT; ++p) sum += ar[p] * cr[p];
+                acc[k] += sum;
+            }
+        }
+        __syncthreads();
+    }
+    double* Vx = bv.Vxc + ((size_t)(beta ? bv.nfrag : 0) + f) * n * n;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int idx = tid + XC_NT * k;
+        if (idx < n * n && acc[k] != 0.0) atomicAdd(&Vx[idx], acc[k]);
+    }
+    if (!beta) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { e_acc += __shfl_down(e_acc, off, 64); n_acc += __shfl_down(n_acc, off, 64); }
+        if (tid == 0) {
+            atomicAdd(&bv.scal[(size_t)f * 8 + 5], e_acc);
+            atomicAdd(&bv.scal[(size_t)f * 8 + 6], n_acc);
+        }
+    }
+}
+
+template <bool GGA, int PT, int NV>
+static void xc_uks_launch(const BatchView& bv, int oa, hipStream_t s)
+{
+    const int n = bv.n;
+    const size_t lds = sizeof(double) * ((size_t)(GGA ? 7 : 4) * n * (PT + 1) + 5 * PT + 16);
+    auto kern = xc_uks_kernel<GGA, PT, NV>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int ntiles = (bv.grid.npts + PT - 1) / PT;
+    int gx = (8192 + bv.nfrag - 1) / bv.nfrag;
+    if (gx > ntiles) gx = ntiles;
+    if (gx < 1) gx = 1;
+    for (int spin = 0; spin < 2; ++spin)
+        hipLaunchKernelGGL(kern, dim3(gx, bv.nfrag), dim3(XC_NT), lds, s, bv, oa | (spin << 1));
+}
+
 void launch_xc(const BatchView& bv, bool only_active, hipStream_t s)
 {
     const int n = bv.n, oa = only_active ? 1 : 0;
-    (void)hipMemsetAsync(bv.Vxc, 0, sizeof(double) * (size_t)bv.nfrag * n * n, s);
+    (void)hipMemsetAsync(bv.Vxc, 0, sizeof(double) * (size_t)bv.nfrag * n * n * (bv.uhf ? 2 : 1), s);
     hipLaunchKernelGGL(xc_reset_kernel, dim3((bv.nfrag + 255) / 256), dim3(256), 0, s, bv);
     const bool gga = bv.xc.gga != 0;
+    if (bv.uhf) {
+        // n <= 116 (the in-core path UHF runs on): 16-point tiles, GGA LDS 7 n 17 doubles <= 110 KB
+        const int nv = (n * n + XC_NT - 1) / XC_NT;
+        if (nv <= 10) { if (gga) xc_uks_launch<true, 16, 10>(bv, oa, s); else xc_uks_launch<false, 16, 10>(bv, oa, s); }
+        else if (nv <= 29) { if (gga) xc_uks_launch<true, 16, 29>(bv, oa, s); else xc_uks_launch<false, 16, 29>(bv, oa, s); }
+        else { if (gga) xc_uks_launch<true, 16, 54>(bv, oa, s); else xc_uks_launch<false, 16, 54>(bv, oa, s); }
+        return;
+    }
     static const bool probed = [] {
         if (const char* e = std::getenv("MQC_HIP_XC_PROBE")) { const int v = std::atoi(e); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_xc_probe), &v, sizeof(int)); }
         return true;

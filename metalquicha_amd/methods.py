@@ -129,7 +129,7 @@ class CalculationResult:
     n_beta: int = 0
 
 
-_GUESS = {"auto": capi.GUESS_AUTO, "gwh": capi.GUESS_GWH, "core": capi.GUESS_CORE}
+_GUESS = {"auto": capi.GUESS_AUTO, "gwh": capi.GUESS_GWH, "core": capi.GUESS_CORE, "sad": capi.GUESS_SAD, "sac": capi.GUESS_SAC}
 
 
 def hip_backend_available() -> bool:
@@ -155,7 +155,7 @@ def _options(settings: ScfSettings, want_gradient: bool) -> capi.ScfOptions:
     if g not in _GUESS:
         # the cuEST path refuses guesses it does not implement rather than running another one
         raise capi.HipBackendError(capi.ERR_UNSUPPORTED, "initial guess '%s' is not available on the HIP backend "
-                                                         "(core, gwh, auto)" % settings.guess)
+                                                         "(core, gwh, auto, sad, sac)" % settings.guess)
     o.guess = _GUESS[g]
     o.unrestricted = int(settings.unrestricted)
     o.want_gradient = int(want_gradient)

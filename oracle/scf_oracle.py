@@ -465,7 +465,7 @@ class UhfResult:
 
 
 def run_uhf(mol: OracleMol, nelec: int, multiplicity: int, max_iter=100, e_tol=1e-8, d_tol=1e-6, diis_vectors=8,
-            guess="gwh", diis_start=UHF_DIIS_START, eri=None) -> UhfResult:
+            guess="gwh", diis_start=UHF_DIIS_START, eri=None, xc=None) -> UhfResult:
     """Unrestricted Hartree-Fock with the reference CPU path's semantics (run_libcint_uhf,
     backends/libcint/mqc_libcint_rhf.f90:682-974): F_s = H + J[D_a + D_b] - K[D_s], one DIIS over both spins
     (Fock matrices and commutators laid end to end) from iteration `diis_start`, dE and the rms over BOTH density
@@ -486,13 +486,22 @@ def run_uhf(mol: OracleMol, nelec: int, multiplicity: int, max_iter=100, e_tol=1
     if na > m:
         raise ValueError("UHF: more alpha electrons than the basis supports")
 
+    exx = 1.0 if xc is None else xc.exx
+
     def assemble(Da, Db):
+        # unrestricted Kohn-Sham (run_libcint_uhf with an XC context): exchange scaled by the functional's fraction,
+        # the energy from the Fock matrices BEFORE the spin potentials are added, plus E_xc
         J = np.einsum("ijkl,kl->ij", eri, Da + Db, optimize=True)
-        Ka = np.einsum("ikjl,kl->ij", eri, Da, optimize=True)
-        Kb = np.einsum("ikjl,kl->ij", eri, Db, optimize=True)
-        Fa = H + J - Ka
-        Fb = H + J - Kb
+        Fa = H + J
+        Fb = H + J
+        if exx != 0.0:
+            Fa = Fa - exx * np.einsum("ikjl,kl->ij", eri, Da, optimize=True)
+            Fb = Fb - exx * np.einsum("ikjl,kl->ij", eri, Db, optimize=True)
         e = 0.5 * float(np.sum(Da * (H + Fa)) + np.sum(Db * (H + Fb)))
+        if xc is not None:
+            exc, Va, Vb = xc.potential_uks(Da, Db)
+            Fa = Fa + Va; Fb = Fb + Vb
+            e += exc
         return Fa, Fb, e
 
     F0 = H.copy() if guess == "core" else guess_fock_gwh(S, H)

@@ -188,6 +188,210 @@ def eval_functional(name: str, rho: np.ndarray, sigma: np.ndarray):
     return np.where(ok, f, z), np.where(ok, vr, z), np.where(ok, vs, z)
 
 
+# ------------------------------------------------------------------ spin-polarised forms (unrestricted Kohn-Sham)
+class DualN:
+    """value + derivatives with respect to k independent variables (here rho_a, rho_b, sigma_aa, sigma_ab,
+    sigma_bb), elementwise on arrays."""
+    __slots__ = ("v", "d")
+
+    def __init__(self, v, d):
+        self.v = v
+        self.d = d
+
+    @staticmethod
+    def var(v, i, k):
+        return DualN(v, [np.ones_like(v) if j == i else np.zeros_like(v) for j in range(k)])
+
+    def _lift(self, x):
+        return x if isinstance(x, DualN) else DualN(np.full_like(self.v, float(x)), [np.zeros_like(self.v) for _ in self.d])
+
+    def __add__(self, o):
+        o = self._lift(o); return DualN(self.v + o.v, [a + b for a, b in zip(self.d, o.d)])
+    __radd__ = __add__
+
+    def __neg__(self):
+        return DualN(-self.v, [-a for a in self.d])
+
+    def __sub__(self, o):
+        o = self._lift(o); return DualN(self.v - o.v, [a - b for a, b in zip(self.d, o.d)])
+
+    def __rsub__(self, o):
+        return self._lift(o) - self
+
+    def __mul__(self, o):
+        o = self._lift(o); return DualN(self.v * o.v, [a * o.v + self.v * b for a, b in zip(self.d, o.d)])
+    __rmul__ = __mul__
+
+    def __truediv__(self, o):
+        o = self._lift(o)
+        inv = 1.0 / o.v
+        q = self.v * inv
+        return DualN(q, [(a - q * b) * inv for a, b in zip(self.d, o.d)])
+
+    def __rtruediv__(self, o):
+        return self._lift(o) / self
+
+    def chain(self, f, df):
+        return DualN(f, [df * a for a in self.d])
+
+    def __pow__(self, p):
+        return self.chain(self.v ** p, p * self.v ** (p - 1.0))
+
+
+def nexp(x): f = np.exp(x.v); return x.chain(f, f)
+def nlog(x): return x.chain(np.log(x.v), 1.0 / x.v)
+def nsqrt(x): f = np.sqrt(x.v); return x.chain(f, 0.5 / f)
+def natan(x): return x.chain(np.arctan(x.v), 1.0 / (1.0 + x.v * x.v))
+def nasinh(x): return x.chain(np.arcsinh(x.v), 1.0 / np.sqrt(1.0 + x.v * x.v))
+
+
+def _zeta_f(z):
+    """f(zeta) = [(1+z)^(4/3) + (1-z)^(4/3) - 2] / (2^(4/3) - 2)"""
+    return ((1.0 + z) ** (4.0 / 3.0) + (1.0 - z) ** (4.0 / 3.0) - 2.0) / (2.0 ** (4.0 / 3.0) - 2.0)
+
+
+def _vwn_aux(rs, A, x0, b, c):
+    x = nsqrt(rs)
+    X = x * x + b * x + c
+    X0 = x0 * x0 + b * x0 + c
+    Q = math.sqrt(4.0 * c - b * b)
+    at = natan(Q / (2.0 * x + b))
+    return A * (nlog(x * x / X) + (2.0 * b / Q) * at
+                - (b * x0 / X0) * (nlog((x - x0) * (x - x0) / X) + (2.0 * (b + 2.0 * x0) / Q) * at))
+
+
+def lda_x_pol(ra, rb, saa, sab, sbb):
+    return -0.75 * (3.0 / math.pi) ** (1.0 / 3.0) * 2.0 ** (1.0 / 3.0) * (ra ** (4.0 / 3.0) + rb ** (4.0 / 3.0))
+
+
+def lda_c_vwn_pol(ra, rb, saa, sab, sbb):
+    """VWN5 with the spin stiffness: e_P + alpha_c f/f''(0) (1 - z^4) + (e_F - e_P) f z^4."""
+    rho = ra + rb
+    z = (ra - rb) / rho
+    rs = (3.0 / (4.0 * math.pi)) ** (1.0 / 3.0) * rho ** (-1.0 / 3.0)
+    eP = _vwn_aux(rs, 0.0310907, -0.10498, 3.72744, 12.9352)
+    eF = _vwn_aux(rs, 0.01554535, -0.32500, 7.06042, 18.0578)
+    aC = _vwn_aux(rs, -1.0 / (6.0 * math.pi ** 2), -0.0047584, 1.13107, 13.0045)
+    fpp = 4.0 / (9.0 * (2.0 ** (1.0 / 3.0) - 1.0))
+    f = _zeta_f(z)
+    z4 = z * z * z * z
+    return rho * (eP + aC * f * (1.0 - z4) / fpp + (eF - eP) * f * z4)
+
+
+def lda_c_vwn_rpa_pol(ra, rb, saa, sab, sbb):
+    """The RPA fit: plain f(zeta) interpolation between the paramagnetic and ferromagnetic fits."""
+    rho = ra + rb
+    z = (ra - rb) / rho
+    rs = (3.0 / (4.0 * math.pi)) ** (1.0 / 3.0) * rho ** (-1.0 / 3.0)
+    eP = _vwn_aux(rs, 0.0310907, -0.409286, 13.0720, 42.7198)
+    eF = _vwn_aux(rs, 0.01554535, -0.743294, 20.1231, 101.578)
+    f = _zeta_f(z)
+    return rho * (eP * (1.0 - f) + eF * f)
+
+
+def _b88_spin(r, s):
+    beta = 0.0042
+    cx = 1.5 * (3.0 / (4.0 * math.pi)) ** (1.0 / 3.0)
+    r43 = r ** (4.0 / 3.0)
+    x = nsqrt(s) / r43
+    return -cx * r43 - beta * r43 * x * x / (1.0 + 6.0 * beta * x * nasinh(x))
+
+
+def gga_x_b88_pol(ra, rb, saa, sab, sbb):
+    return _b88_spin(ra, saa) + _b88_spin(rb, sbb)
+
+
+def gga_c_lyp_pol(ra, rb, saa, sab, sbb):
+    """Lee-Yang-Parr in the gradient-only form of Miehlich et al. (CPL 157, 200) for two spin densities."""
+    a, b, c, d = 0.04918, 0.132, 0.2533, 0.349
+    cf = 0.3 * (3.0 * math.pi ** 2) ** (2.0 / 3.0)
+    rho = ra + rb
+    rm13 = rho ** (-1.0 / 3.0)
+    den = 1.0 + d * rm13
+    omega = nexp(-c * rm13) / den * rho ** (-11.0 / 3.0)
+    delta = c * rm13 + d * rm13 / den
+    sig = saa + 2.0 * sab + sbb
+    rab = ra * rb
+    t1 = 2.0 ** (11.0 / 3.0) * cf * (ra ** (8.0 / 3.0) + rb ** (8.0 / 3.0))
+    t2 = (47.0 / 18.0 - 7.0 * delta / 18.0) * sig
+    t3 = (2.5 - delta / 18.0) * (saa + sbb)
+    t4 = (delta - 11.0) / 9.0 * (ra * saa + rb * sbb) / rho
+    br = rab * (t1 + t2 - t3 - t4) - (2.0 / 3.0) * rho * rho * sig \
+        + ((2.0 / 3.0) * rho * rho - ra * ra) * sbb + ((2.0 / 3.0) * rho * rho - rb * rb) * saa
+    return -a * 4.0 / den * rab / rho - a * b * omega * br
+
+
+def _pbe_x_unpol(rho, sigma):
+    kf = (3.0 * math.pi ** 2) ** (1.0 / 3.0) * rho ** (1.0 / 3.0)
+    s2 = sigma / (4.0 * kf * kf * rho * rho)
+    fx = 1.0 + PBE_KAPPA - PBE_KAPPA / (1.0 + PBE_MU * s2 / PBE_KAPPA)
+    return -0.75 * (3.0 / math.pi) ** (1.0 / 3.0) * rho ** (4.0 / 3.0) * fx
+
+
+def gga_x_pbe_pol(ra, rb, saa, sab, sbb):
+    """Exchange spin scaling: E[ra, rb] = (E[2 ra] + E[2 rb]) / 2."""
+    return 0.5 * (_pbe_x_unpol(2.0 * ra, 4.0 * saa) + _pbe_x_unpol(2.0 * rb, 4.0 * sbb))
+
+
+def _pw_mod_g(rs, A, a1, b1, b2, b3, b4):
+    srs = nsqrt(rs)
+    q = 2.0 * A * (b1 * srs + b2 * rs + b3 * rs * srs + b4 * rs * rs)
+    return -2.0 * A * (1.0 + a1 * rs) * nlog(1.0 + 1.0 / q)
+
+
+PW_MOD_FZ20 = 1.709920934161365617563962776245
+
+
+def _pw_mod_pol(rs, z):
+    g0 = _pw_mod_g(rs, 0.0310907, 0.21370, 7.5957, 3.5876, 1.6382, 0.49294)
+    g1 = _pw_mod_g(rs, 0.01554535, 0.20548, 14.1189, 6.1977, 3.3662, 0.62517)
+    g2 = _pw_mod_g(rs, 0.0168869, 0.11125, 10.357, 3.6231, 0.88026, 0.49671)       # = -alpha_c
+    f = _zeta_f(z)
+    z4 = z * z * z * z
+    return g0 - g2 * f * (1.0 - z4) / PW_MOD_FZ20 + (g1 - g0) * f * z4
+
+
+def gga_c_pbe_pol(ra, rb, saa, sab, sbb):
+    rho = ra + rb
+    z = (ra - rb) / rho
+    rs = (3.0 / (4.0 * math.pi)) ** (1.0 / 3.0) * rho ** (-1.0 / 3.0)
+    ec = _pw_mod_pol(rs, z)
+    phi = 0.5 * ((1.0 + z) ** (2.0 / 3.0) + (1.0 - z) ** (2.0 / 3.0))
+    phi3 = phi * phi * phi
+    kf = (3.0 * math.pi ** 2) ** (1.0 / 3.0) * rho ** (1.0 / 3.0)
+    ks2 = 4.0 * kf / math.pi
+    sig = saa + 2.0 * sab + sbb
+    t2 = sig / (4.0 * phi * phi * ks2 * rho * rho)
+    A = (PBE_BETA / PBE_GAMMA) / (nexp(-ec / (PBE_GAMMA * phi3)) - 1.0)
+    at2 = A * t2
+    H = PBE_GAMMA * phi3 * nlog(1.0 + (PBE_BETA / PBE_GAMMA) * t2 * (1.0 + at2) / (1.0 + at2 + at2 * at2))
+    return rho * (ec + H)
+
+
+POLARISED = {lda_x: lda_x_pol, lda_c_vwn: lda_c_vwn_pol, lda_c_vwn_rpa: lda_c_vwn_rpa_pol, gga_x_b88: gga_x_b88_pol,
+             gga_c_lyp: gga_c_lyp_pol, gga_x_pbe: gga_x_pbe_pol, gga_c_pbe: gga_c_pbe_pol}
+SPIN_FLOOR = 1.0e-30         # a spin density below this is held there: zeta stays inside (-1, 1)
+
+
+def eval_functional_pol(name: str, ra, rb, saa, sab, sbb):
+    """-> f per volume and (v_rho_a, v_rho_b, v_sigma_aa, v_sigma_ab, v_sigma_bb); zero where the TOTAL density is
+    below the threshold (the layout of libxc's polarised calls, mqc_libcint_xc.F90:938-951)."""
+    comps, _, _ = FUNCTIONALS[name.lower()]
+    ok = (ra + rb) > DENS_THRESHOLD
+    a = np.where(ok, np.maximum(ra, SPIN_FLOOR), 0.5)
+    b = np.where(ok, np.maximum(rb, SPIN_FLOOR), 0.5)
+    xs = [a, b, np.where(ok, np.maximum(saa, 1.0e-40), 1.0e-40), np.where(ok, sab, 0.0), np.where(ok, np.maximum(sbb, 1.0e-40), 1.0e-40)]
+    V = [DualN.var(x, i, 5) for i, x in enumerate(xs)]
+    f = 0.0
+    dv = [0.0] * 5
+    for wgt, fn in comps:
+        d = POLARISED[fn](*V)
+        f = f + wgt * d.v
+        dv = [t + wgt * u for t, u in zip(dv, d.d)]
+    z = np.zeros_like(ra)
+    return np.where(ok, f, z), [np.where(ok, t, z) for t in dv]
+
+
 @dataclass
 class XCOracle:
     """`xc` object for scf_oracle.run_rhf: .exx and .potential(D) -> (E_xc, V_xc)."""
@@ -229,3 +433,35 @@ class XCOracle:
                 V += A + A.T
         self.n_electrons = nel
         return exc, V
+
+    def potential_uks(self, Da: np.ndarray, Db: np.ndarray):
+        """E_xc and the two spin potentials (xc_add_potential_uks, mqc_libcint_xc.F90:929-1119): one AO evaluation,
+        spin densities from C_s C_s^T (not doubled), dE/dgrad rho_a = 2 v_aa grad rho_a + v_ab grad rho_b."""
+        n = self.mol.nao
+        Va = np.zeros((n, n)); Vb = np.zeros((n, n))
+        exc = 0.0; nel = 0.0
+        for b0 in range(0, len(self.w), self.block):
+            p = self.pts[b0:b0 + self.block]; w = self.w[b0:b0 + self.block]
+            if self.gga:
+                ao, g = scf_oracle.eval_ao(self.mol, p, deriv=True)
+            else:
+                ao, g = scf_oracle.eval_ao(self.mol, p), None
+            Xa = ao @ Da; Xb = ao @ Db
+            ra = np.einsum("pi,pi->p", Xa, ao); rb = np.einsum("pi,pi->p", Xb, ao)
+            if self.gga:
+                ga = 2.0 * np.einsum("pi,dpi->dp", Xa, g); gb = 2.0 * np.einsum("pi,dpi->dp", Xb, g)
+                saa = np.einsum("dp,dp->p", ga, ga); sab = np.einsum("dp,dp->p", ga, gb); sbb = np.einsum("dp,dp->p", gb, gb)
+            else:
+                saa = sab = sbb = np.zeros_like(ra)
+            f, (vra, vrb, vaa, vab, vbb) = eval_functional_pol(self.name, ra, rb, saa, sab, sbb)
+            exc += float(np.dot(w, f)); nel += float(np.dot(w, ra + rb))
+            Va += (ao * (w * vra)[:, None]).T @ ao
+            Vb += (ao * (w * vrb)[:, None]).T @ ao
+            if self.gga:
+                ca = 2.0 * vaa * ga + vab * gb
+                cb = 2.0 * vbb * gb + vab * ga
+                A = np.einsum("p,dp,dpi->pi", w, ca, g).T @ ao
+                B = np.einsum("p,dp,dpi->pi", w, cb, g).T @ ao
+                Va += A + A.T; Vb += B + B.T
+        self.n_electrons = nel
+        return exc, Va, Vb

@@ -182,6 +182,40 @@ def test_manifest_kohn_sham(case):
     assert abs(xc.n_electrons - frag.nelec) < 1e-4
 
 
+_UKS = [c for c in _CASES if c["method"] == "dft" and c["functional"] in xc_oracle.FUNCTIONALS and c["unrestricted"]
+        and c["driver"] == "Energy" and not c["density_fitting"]]
+
+
+@pytest.mark.parametrize("case", _UKS, ids=[c["name"] for c in _UKS])
+def test_manifest_unrestricted_kohn_sham(case):
+    """UKS goldens (CH3 doublet SVWN / PBE / B3LYP, O2 triplet PBE), tolerance 1e-9: pins the spin-polarised forms --
+    lda_x spin scaling, VWN5 with the spin stiffness, VWN-RPA's f(zeta) interpolation, B88 per spin, LYP for two
+    spin densities, PBE exchange scaling and PBE correlation with phi(zeta) over polarised pw_mod -- and
+    xc_add_potential_uks' cross-spin gradient term."""
+    z = [SYMBOL_TO_Z[s.lower()] for s in case["symbols"]]
+    frag = fragment_bohr(z, np.array(case["xyz_angstrom"]) * ANGSTROM_TO_BOHR, multiplicity=case["multiplicity"])
+    mol = oracle_mol(case["basis"], frag)
+    xc = xc_oracle.XCOracle(mol, case["functional"], case["grid_level"])
+    r = so.run_uhf(mol, int(frag.nelec), case["multiplicity"], case["maxiter"], 1e-10, 1e-7, xc=xc)
+    assert r.converged
+    assert abs(r.energy - case["expected_energy"]) < 1e-9
+    assert abs(xc.n_electrons - frag.nelec) < 1e-4
+
+
+def test_polarised_functionals_reduce_to_the_restricted_forms():
+    """rho_a = rho_b: same energy density, v_rho_a = v_rho_b = v_rho, (v_aa + v_ab + v_bb) / 4 = v_sigma."""
+    rng = np.random.default_rng(1)
+    rho = 10.0 ** rng.uniform(-4, 1.0, 100)
+    sig = (rho ** (4.0 / 3.0) * 10.0 ** rng.uniform(-2, 1, size=100)) ** 2
+    for name in ("svwn", "pbe", "blyp", "b3lyp", "pbe0"):
+        f, vr, vs = xc_oracle.eval_functional(name, rho, sig)
+        fp, (vra, vrb, vaa, vab, vbb) = xc_oracle.eval_functional_pol(name, rho / 2, rho / 2, sig / 4, sig / 4, sig / 4)
+        assert np.max(np.abs(f - fp) / np.abs(f)) < 1e-13
+        assert np.max(np.abs(vr - vra) / np.abs(vr)) < 1e-12 and np.max(np.abs(vra - vrb)) == 0.0
+        if name != "svwn":
+            assert np.max(np.abs(vs - (vaa + vab + vbb) / 4.0) / (np.abs(vs) + 1e-300)) < 1e-10
+
+
 def test_functional_derivatives_by_finite_differences():
     rng = np.random.default_rng(4)
     rho = 10.0 ** rng.uniform(-4, 1.5, size=200)
