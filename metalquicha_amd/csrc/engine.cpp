@@ -248,7 +248,11 @@ static int validate_options(const mqc_hip_scf_options_t& o, const Topology& topo
         (void)direct;       // f classes are digested by the LDS kernel: the direct build covers them
         if (o.density_fitting) { msg = "orbital f shells with density fitting are not available in this build of the HIP backend (three-centre kernels cover s, p, d orbital shells)"; return MQC_HIP_ERR_UNSUPPORTED; }
     }
-    if (topo.nao > 140) { msg = "fragment too large for the LDS eigen-solver (n_ao <= 140)"; return MQC_HIP_ERR_UNSUPPORTED; }
+    // n_ao <= 140: the Fock matrix is diagonalised in LDS; up to 256 it is rotated in global memory (L2), exact-ERI
+    // direct path and the quadrature's z-split; density fitting keeps the 140 limit (its J/K kernels tile n in LDS)
+    if (topo.nao > 256) { msg = "fragment too large for the eigen-solver (n_ao <= 256)"; return MQC_HIP_ERR_UNSUPPORTED; }
+    if (topo.nao > 140 && o.density_fitting) { msg = "density fitting is available up to n_ao = 140; larger fragments run on the direct exact-ERI path"; return MQC_HIP_ERR_UNSUPPORTED; }
+    if (topo.nao > 140 && o.want_gradient) { msg = "analytic gradients are available up to n_ao = 140"; return MQC_HIP_ERR_UNSUPPORTED; }
     return MQC_HIP_OK;
 }
 
@@ -1257,7 +1261,7 @@ int mqc_hip_jk_incore(mqc_hip_context* ctx, const mqc_hip_molecule_t* mol, const
 int mqc_hip_syev(mqc_hip_context* ctx, int32_t n, const double* A, double* w, double* V)
 {
     if (!ctx || !A || !w || !V || n <= 0) return fail(MQC_HIP_ERR_VALIDATION, "bad arguments");
-    if (n > 140) return fail(MQC_HIP_ERR_UNSUPPORTED, "matrix too large for the LDS Jacobi solver (n <= 140)");
+    if (n > 256) return fail(MQC_HIP_ERR_UNSUPPORTED, "matrix too large for the Jacobi solver (n <= 256)");
     HIP_CHECK_RET(hipSetDevice(ctx->device));
     const size_t nn = (size_t)n * n;
     double* d = (double*)ctx->pool_main.ensure(sizeof(double) * (2 * nn + n) + 1024);

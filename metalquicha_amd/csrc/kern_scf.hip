@@ -154,10 +154,10 @@ struct JacobiLds {
 
 __host__ __device__ inline int even_up(int m) { return (m + 1) & ~1; }
 
-__host__ __device__ inline size_t jacobi_lds_doubles(int m, bool v_in_lds)
+__host__ __device__ inline size_t jacobi_lds_doubles(int m, bool v_in_lds, bool a_in_lds = true)
 {
     const int mp = even_up(m), lda = mp + 1;
-    size_t d = (size_t)mp * lda;             // A
+    size_t d = a_in_lds ? (size_t)mp * lda : 0;   // A
     if (v_in_lds) d += (size_t)mp * lda;     // V
     d += 2 * (mp / 2);                       // rc, rs
     d += mp / 2 + 1;                         // rp, rq as ints packed in doubles
@@ -165,12 +165,16 @@ __host__ __device__ inline size_t jacobi_lds_doubles(int m, bool v_in_lds)
     return d;
 }
 
-__device__ inline JacobiLds carve_jacobi(double* lds, int m, bool v_in_lds, double* v_global)
+// mode 2: A and V in LDS; 1: A in LDS, V in global memory; 0: both in global memory (a_global: (m+2)^2 doubles of the
+// fragment's workspace) -- matrices too wide for the CU's 160 KB, rotated in the L2 instead
+__device__ inline JacobiLds carve_jacobi(double* lds, int m, int mode, double* v_global, double* a_global = nullptr)
 {
     JacobiLds j;
     const int mp = even_up(m);
+    const bool v_in_lds = mode == 2;
     j.lda = mp + 1;
-    j.A = lds; lds += (size_t)mp * j.lda;
+    if (mode == 0) j.A = a_global;
+    else { j.A = lds; lds += (size_t)mp * j.lda; }
     if (v_in_lds) { j.V = lds; lds += (size_t)mp * j.lda; } else { j.V = v_global; }
     j.rc = lds; lds += mp / 2;
     j.rs = lds; lds += mp / 2;
@@ -183,9 +187,10 @@ __device__ inline JacobiLds carve_jacobi(double* lds, int m, bool v_in_lds, doub
 // Symmetric eigen-decomposition of the m x m matrix already stored in jl.A (padded to even mp
 // with a zero row/column).  On exit jl.A's diagonal holds the eigenvalues and V's columns the
 // eigenvectors (V addressed as V[row * ldv + col]).
-template <bool VLDS>
+template <int JM>
 __device__ void jacobi_eig(JacobiLds& jl, int m, int ldv, const double* __restrict__ v0 = nullptr, int ldv0 = 0)
 {
+    constexpr bool VLDS = JM == 2;      // JM: 2 = A and V in LDS, 1 = A in LDS and V in global memory, 0 = both global (n > 140)
     const int mp = even_up(m), lda = jl.lda, half = mp / 2;
     const int tid = threadIdx.x;
     double* A = jl.A;
@@ -322,20 +327,21 @@ __device__ __forceinline__ FragPtrs frag_ptrs(const BatchView& bv, int f)
 // ---------------------------------------------------------------------------------------
 // X = U s^{-1/2} over overlap eigenvalues > 1e-7, ascending (build_orthogonalizer,
 // src/scf/mqc_scf_common.f90:43-83).  nmo goes to istate[2].
-template <bool VLDS>
+template <int JM>
 __global__ void __launch_bounds__(NT) orthogonalizer_kernel(BatchView bv)
 {
+    constexpr bool VLDS = JM == 2;      // JM: 2 = A and V in LDS, 1 = A in LDS and V in global memory, 0 = both global (n > 140)
     extern __shared__ double lds[];
     const int f = blockIdx.x, n = bv.n, tid = threadIdx.x;
     FragPtrs p = frag_ptrs(bv, f);
-    JacobiLds jl = carve_jacobi(lds, n, VLDS, p.W);
+    JacobiLds jl = carve_jacobi(lds, n, JM, p.W, p.W + 4 * (size_t)n * n + n);
     const int mp = even_up(n), lda = jl.lda;
     const int ldv = VLDS ? lda : n;
     for (int idx = tid; idx < mp * lda; idx += NT) jl.A[idx] = 0.0;
     __syncthreads();
     for (int idx = tid; idx < n * n; idx += NT) jl.A[(idx / n) * lda + (idx % n)] = p.S[idx];
     __syncthreads();
-    jacobi_eig<VLDS>(jl, n, ldv);
+    jacobi_eig<JM>(jl, n, ldv);
     // count dropped modes
     int drop = 0;
     for (int i = 0; i < n; ++i) drop += (jl.A[i * lda + i] > OVERLAP_EIG_TOL) ? 0 : 1;
@@ -357,10 +363,11 @@ __global__ void __launch_bounds__(NT) orthogonalizer_kernel(BatchView bv)
 // that the Jacobi sweeps start from a nearly diagonal matrix; V then starts from Vp, so the final
 // V is the full eigenvector matrix and no extra product is needed.
 // vprev / nocc / dfac: spin channel of an unrestricted run (defaults: the closed-shell values)
-template <bool VLDS, bool WARM>
+template <int JM, bool WARM>
 __device__ void diagonalize_and_density(const BatchView& bv, FragPtrs& p, JacobiLds& jl, int m, double* vprev = nullptr, int nocc = -1,
                                         double dfac = 2.0)
 {
+    constexpr bool VLDS = JM == 2;      // JM: 2 = A and V in LDS, 1 = A in LDS and V in global memory, 0 = both global (n > 140)
     const int n = bv.n, tid = threadIdx.x;
     const size_t nn = (size_t)n * n;
     double* T = p.W + 2 * nn;       // F X  (n x m), then F' Vp (m x m)
@@ -390,7 +397,7 @@ __device__ void diagonalize_and_density(const BatchView& bv, FragPtrs& p, Jacobi
         }
     }
     __syncthreads();
-    jacobi_eig<VLDS>(jl, m, ldv, WARM ? Vp : nullptr, n);
+    jacobi_eig<JM>(jl, m, ldv, WARM ? Vp : nullptr, n);
     // keep the eigenvectors for the next iteration's warm start
     for (int idx = tid; idx < m * m; idx += NT) {
         const int i = idx / m, j = idx - i * m;
@@ -424,14 +431,15 @@ __device__ __forceinline__ FragPtrs frag_ptrs_beta(const BatchView& bv, int f)
 }
 
 // Starting Fock (core or GWH, guess_fock mqc_libcint_rhf.f90:1354-1380), then the first density.
-template <bool VLDS>
+template <int JM>
 __global__ void __launch_bounds__(NT) guess_kernel(BatchView bv, int guess_kind)
 {
+    constexpr bool VLDS = JM == 2;      // JM: 2 = A and V in LDS, 1 = A in LDS and V in global memory, 0 = both global (n > 140)
     extern __shared__ double lds[];
     const int f = blockIdx.x, n = bv.n, tid = threadIdx.x;
     FragPtrs p = frag_ptrs(bv, f);
     const int m = p.istate[2];
-    JacobiLds jl = carve_jacobi(lds, m, VLDS, nullptr);
+    JacobiLds jl = carve_jacobi(lds, m, JM, nullptr, (JM == 0) ? bv.W + ((size_t)blockIdx.x * 6 + 4) * n * n + n : nullptr);
     for (int idx = tid; idx < n * n; idx += NT) {
         const int i = idx / n, j = idx - i * n;
         double v = p.H[idx];
@@ -445,7 +453,7 @@ __global__ void __launch_bounds__(NT) guess_kernel(BatchView bv, int guess_kind)
     if (bv.uhf) {
         // symmetric guess: both spins get the orbitals of the same starting Fock, the occupations separate them
         // (run_libcint_uhf, mqc_libcint_rhf.f90:838-866)
-        diagonalize_and_density<VLDS, false>(bv, p, jl, m, nullptr, bv.nalpha, 1.0);
+        diagonalize_and_density<JM, false>(bv, p, jl, m, nullptr, bv.nalpha, 1.0);
         FragPtrs pb = frag_ptrs_beta(bv, f);
         const size_t nn = (size_t)n * n;
         double* Vpa = bv.Vprev + (size_t)f * nn; double* Vpb = bv.Vprevb + (size_t)f * nn;
@@ -455,7 +463,7 @@ __global__ void __launch_bounds__(NT) guess_kernel(BatchView bv, int guess_kind)
         double* const Dbg = pb.D; const double* Cbg = pb.C;
         wg_gemm_mfma<false, true>(n, n, bv.nbeta, Cbg, n, Cbg, n, [&](int i, int j, double v) { Dbg[i * n + j] = v; });
     } else {
-        diagonalize_and_density<VLDS, false>(bv, p, jl, m);
+        diagonalize_and_density<JM, false>(bv, p, jl, m);
     }
     if (tid == 0) {
         p.istate[0] = ST_ITER; p.istate[1] = 0; p.istate[3] = 0;
@@ -521,9 +529,10 @@ __host__ __device__ inline bool diis_solve(const double* overlap /* [maxv*maxv] 
     return true;
 }
 
-template <bool VLDS>
+template <int JM>
 __global__ void __launch_bounds__(NT) scf_step_kernel(BatchView bv)
 {
+    constexpr bool VLDS = JM == 2;      // JM: 2 = A and V in LDS, 1 = A in LDS and V in global memory, 0 = both global (n > 140)
     extern __shared__ double lds[];
     const int f = blockIdx.x, n = bv.n, tid = threadIdx.x;
     FragPtrs p = frag_ptrs(bv, f);
@@ -531,7 +540,7 @@ __global__ void __launch_bounds__(NT) scf_step_kernel(BatchView bv)
     if (state == ST_DONE) return;
     const int m = p.istate[2];
     const size_t nn = (size_t)n * n;
-    JacobiLds jl = carve_jacobi(lds, m, VLDS, nullptr);
+    JacobiLds jl = carve_jacobi(lds, m, JM, nullptr, (JM == 0) ? bv.W + ((size_t)blockIdx.x * 6 + 4) * n * n + n : nullptr);
 
     // ---- Fock assembly and energy (assemble_fock :985-990,1206-1228; electronic_energy :1691)
     // The energy is taken from the Fock matrix BEFORE V_xc is added, plus E_xc
@@ -613,7 +622,7 @@ __global__ void __launch_bounds__(NT) scf_step_kernel(BatchView bv)
     double* Dold = p.W + nn;    // W1 is free again
     for (int idx = tid; idx < n * n; idx += NT) Dold[idx] = p.D[idx];
     __syncthreads();
-    diagonalize_and_density<VLDS, true>(bv, p, jl, m);
+    diagonalize_and_density<JM, true>(bv, p, jl, m);
 
     double d2 = 0.0;
     for (int idx = tid; idx < n * n; idx += NT) { const double d = p.D[idx] - Dold[idx]; d2 += d * d; }
@@ -638,9 +647,10 @@ __global__ void __launch_bounds__(NT) scf_step_kernel(BatchView bv)
 // decide convergence; the final state rebuilds the energy from the converged densities.
 constexpr int UHF_DIIS_START = 4;
 
-template <bool VLDS>
+template <int JM>
 __global__ void __launch_bounds__(NT) scf_step_uhf_kernel(BatchView bv)
 {
+    constexpr bool VLDS = JM == 2;      // JM: 2 = A and V in LDS, 1 = A in LDS and V in global memory, 0 = both global (n > 140)
     extern __shared__ double lds[];
     const int f = blockIdx.x, n = bv.n, tid = threadIdx.x;
     FragPtrs pa = frag_ptrs(bv, f);
@@ -649,7 +659,7 @@ __global__ void __launch_bounds__(NT) scf_step_uhf_kernel(BatchView bv)
     if (state == ST_DONE) return;
     const int m = pa.istate[2];
     const size_t nn = (size_t)n * n;
-    JacobiLds jl = carve_jacobi(lds, m, VLDS, nullptr);
+    JacobiLds jl = carve_jacobi(lds, m, JM, nullptr, (JM == 0) ? bv.W + ((size_t)blockIdx.x * 6 + 4) * n * n + n : nullptr);
 
     // unrestricted Kohn-Sham: exchange scaled by the functional's fraction, the energy from the Fock matrices BEFORE
     // the spin potentials are added, plus E_xc; V_s = A_s + A_s^T with A_b behind A_a (kern_xc.hip, xc_uks_kernel)
@@ -740,9 +750,9 @@ __global__ void __launch_bounds__(NT) scf_step_uhf_kernel(BatchView bv)
     // old densities to W0 / W1, both spins diagonalised, new densities
     for (int idx = tid; idx < n * n; idx += NT) { W0[idx] = pa.D[idx]; W1[idx] = pb.D[idx]; }
     __syncthreads();
-    diagonalize_and_density<VLDS, true>(bv, pa, jl, m, bv.Vprev, bv.nalpha, 1.0);
+    diagonalize_and_density<JM, true>(bv, pa, jl, m, bv.Vprev, bv.nalpha, 1.0);
     __syncthreads();
-    diagonalize_and_density<VLDS, true>(bv, pb, jl, m, bv.Vprevb, bv.nbeta, 1.0);
+    diagonalize_and_density<JM, true>(bv, pb, jl, m, bv.Vprevb, bv.nbeta, 1.0);
 
     double d2 = 0.0;
     for (int idx = tid; idx < n * n; idx += NT) {
@@ -774,14 +784,26 @@ __global__ void count_active_kernel(BatchView bv)
 }
 
 // ---------------------------------------------------------------------------------------
-size_t scf_lds_bytes(int n)
+static int jacobi_mode(int n)
 {
-    size_t with_v = jacobi_lds_doubles(n, true) * sizeof(double);
-    if (with_v <= 150 * 1024) return with_v;
-    return jacobi_lds_doubles(n, false) * sizeof(double);
+    if (jacobi_lds_doubles(n, true) * sizeof(double) <= 150 * 1024) return 2;
+    if (jacobi_lds_doubles(n, false) * sizeof(double) <= 158 * 1024) return 1;      // n <= 140
+    return 0;
 }
 
-static bool v_in_lds(int n) { return jacobi_lds_doubles(n, true) * sizeof(double) <= 150 * 1024; }
+size_t scf_lds_bytes(int n)
+{
+    const int mode = jacobi_mode(n);
+    return jacobi_lds_doubles(n, mode == 2, mode != 0) * sizeof(double);
+}
+
+#define MQC_JACOBI_DISPATCH(KERNEL, N, ...)                                                   \
+    do {                                                                                      \
+        const int jm_ = jacobi_mode(N);                                                       \
+        if (jm_ == 2) launch_wg(KERNEL<2>, __VA_ARGS__);                                      \
+        else if (jm_ == 1) launch_wg(KERNEL<1>, __VA_ARGS__);                                 \
+        else launch_wg(KERNEL<0>, __VA_ARGS__);                                               \
+    } while (0)
 
 template <typename K, typename... Args>
 static void launch_wg(K kern, int nfrag, size_t lds, hipStream_t s, Args... args)
@@ -793,15 +815,13 @@ static void launch_wg(K kern, int nfrag, size_t lds, hipStream_t s, Args... args
 void launch_orthogonalizer(const BatchView& bv, hipStream_t s)
 {
     const size_t lds = scf_lds_bytes(bv.n);
-    if (v_in_lds(bv.n)) launch_wg(orthogonalizer_kernel<true>, bv.nfrag, lds, s, bv);
-    else launch_wg(orthogonalizer_kernel<false>, bv.nfrag, lds, s, bv);
+    MQC_JACOBI_DISPATCH(orthogonalizer_kernel, bv.n, bv.nfrag, lds, s, bv);
 }
 
 void launch_guess(const BatchView& bv, int guess_kind, hipStream_t s)
 {
     const size_t lds = scf_lds_bytes(bv.n);
-    if (v_in_lds(bv.n)) launch_wg(guess_kernel<true>, bv.nfrag, lds, s, bv, guess_kind);
-    else launch_wg(guess_kernel<false>, bv.nfrag, lds, s, bv, guess_kind);
+    MQC_JACOBI_DISPATCH(guess_kernel, bv.n, bv.nfrag, lds, s, bv, guess_kind);
 }
 
 static void apply_jacobi_env()
@@ -830,27 +850,25 @@ void launch_scf_step(const BatchView& bv, hipStream_t s)
 {
     apply_jacobi_env();
     const size_t lds = scf_lds_bytes(bv.n);
-    if (bv.uhf) {
-        if (v_in_lds(bv.n)) launch_wg(scf_step_uhf_kernel<true>, bv.nfrag, lds, s, bv);
-        else launch_wg(scf_step_uhf_kernel<false>, bv.nfrag, lds, s, bv);
-    } else if (v_in_lds(bv.n)) launch_wg(scf_step_kernel<true>, bv.nfrag, lds, s, bv);
-    else launch_wg(scf_step_kernel<false>, bv.nfrag, lds, s, bv);
+    if (bv.uhf) MQC_JACOBI_DISPATCH(scf_step_uhf_kernel, bv.n, bv.nfrag, lds, s, bv);
+    else MQC_JACOBI_DISPATCH(scf_step_kernel, bv.n, bv.nfrag, lds, s, bv);
     hipLaunchKernelGGL(count_active_kernel, dim3(1), dim3(256), 0, s, bv);
 }
 
 // ---- stage-level entry points ---------------------------------------------------------
-template <bool VLDS>
-__global__ void __launch_bounds__(NT) syev_kernel(int n, const double* A, double* w, double* V)
+template <int JM>
+__global__ void __launch_bounds__(NT) syev_kernel(int n, const double* A, double* w, double* V, double* Aglb)
 {
+    constexpr bool VLDS = JM == 2;      // JM: 2 = A and V in LDS, 1 = A in LDS and V in global memory, 0 = both global (n > 140)
     extern __shared__ double lds[];
     const int tid = threadIdx.x;
-    JacobiLds jl = carve_jacobi(lds, n, VLDS, V);
+    JacobiLds jl = carve_jacobi(lds, n, JM, V, Aglb);
     const int mp = even_up(n), lda = jl.lda, ldv = VLDS ? lda : n;
     for (int idx = tid; idx < mp * lda; idx += NT) jl.A[idx] = 0.0;
     __syncthreads();
     for (int idx = tid; idx < n * n; idx += NT) jl.A[(idx / n) * lda + (idx % n)] = A[idx];
     __syncthreads();
-    jacobi_eig<VLDS>(jl, n, ldv);
+    jacobi_eig<JM>(jl, n, ldv);
     __shared__ int rank_s[256];
     for (int i = tid; i < n; i += NT) { rank_s[i] = eig_rank(jl.A, lda, n, i); w[rank_s[i]] = jl.A[i * lda + i]; }
     __syncthreads();
@@ -874,12 +892,21 @@ __global__ void __launch_bounds__(NT) syev_kernel(int n, const double* A, double
 void launch_syev(int n, double* dA, double* dw, double* dV, hipStream_t s)
 {
     const size_t lds = scf_lds_bytes(n);
-    if (v_in_lds(n)) {
-        (void)hipFuncSetAttribute((const void*)syev_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(syev_kernel<true>, dim3(1), dim3(NT), lds, s, n, dA, dw, dV);
+    const int mode = jacobi_mode(n);
+    if (mode == 2) {
+        (void)hipFuncSetAttribute((const void*)syev_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(syev_kernel<2>, dim3(1), dim3(NT), lds, s, n, dA, dw, dV, (double*)nullptr);
+    } else if (mode == 1) {
+        (void)hipFuncSetAttribute((const void*)syev_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(syev_kernel<1>, dim3(1), dim3(NT), lds, s, n, dA, dw, dV, (double*)nullptr);
     } else {
-        (void)hipFuncSetAttribute((const void*)syev_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(syev_kernel<false>, dim3(1), dim3(NT), lds, s, n, dA, dw, dV);
+        // stage-level call on a matrix too wide for LDS: the padded working copy lives in a temporary
+        double* aw = nullptr;
+        if (hipMalloc(&aw, sizeof(double) * (size_t)(n + 2) * (n + 2)) != hipSuccess) return;
+        (void)hipFuncSetAttribute((const void*)syev_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(syev_kernel<0>, dim3(1), dim3(NT), lds, s, n, dA, dw, dV, aw);
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(aw);
     }
 }
 

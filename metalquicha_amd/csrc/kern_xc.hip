@@ -1062,6 +1062,9 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
     XC_ST_DECL
 
     const int probe = g_xc_probe;
+    // n > 144: the 16 x 16 output tiles are dealt to blockIdx.z groups of XV_NW * JMAX (the slab, the densities and the
+    // functional are formed in every group; the energy counts in group 0)
+    const int tz0 = (int)blockIdx.z * XV_NW * JMAX;
     auto ao_slab = [&](int g0) {
         if (probe & 1) return;
         // AO values (and gradients) of PT points: (radial group, point) items, point fastest
@@ -1227,7 +1230,7 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
             // A += a chi^T: this wave's tiles t = wave, wave + XV_NW, ...
 #pragma unroll
             for (int j = 0; j < JMAX; ++j) {
-                const int t = wave + XV_NW * j;
+                const int t = tz0 + wave + XV_NW * j;
                 if (t < NT16 * NT16 && !(probe & 8)) {
                     const int mt = t / NT16, nt = t - mt * NT16;
                     const double* __restrict__ ar = gx + (size_t)(16 * mt + lo) * RS + hi;
@@ -1252,7 +1255,7 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
     double* Vx = bv.Vxc + (size_t)f * n * n;
 #pragma unroll
     for (int j = 0; j < JMAX; ++j) {
-        const int t = wave + XV_NW * j;
+        const int t = tz0 + wave + XV_NW * j;
         if (t < NT16 * NT16) {
             const int mt = t / NT16, nt = t - mt * NT16;
 #pragma unroll
@@ -1266,7 +1269,7 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
     // E_xc and N_e: every thread holds partial sums
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { e_acc += __shfl_down(e_acc, off, 64); n_acc += __shfl_down(n_acc, off, 64); }
-    if (lane == 0) {
+    if (lane == 0 && blockIdx.z == 0) {
         atomicAdd(&bv.scal[(size_t)f * 8 + 5], e_acc);
         atomicAdd(&bv.scal[(size_t)f * 8 + 6], n_acc);
     }
@@ -1295,7 +1298,9 @@ static void xc_tile_launch(const BatchView& bv, int oa, hipStream_t s)
     int gx = (6144 + bv.nfrag - 1) / bv.nfrag;       // ~3 workgroups per CU x 8 in flight over the batch; many tiles each
     if (gx > ntiles) gx = ntiles;
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(kern, dim3(gx, bv.nfrag), dim3(64 * XV_NW), lds, s, bv, oa);
+    const int nt16 = (bv.n + 15) / 16;
+    const int nz = (nt16 * nt16 + XV_NW * JMAX - 1) / (XV_NW * JMAX);
+    hipLaunchKernelGGL(kern, dim3(gx, bv.nfrag, nz), dim3(64 * XV_NW), lds, s, bv, oa);
 }
 
 template <bool GGA>
@@ -1314,6 +1319,7 @@ static bool xc_tile_dispatch(const BatchView& bv, int oa, hipStream_t s)
     if (jobs <= 9) xc_tile_launch<GGA, 16, 9, 1, false, 0>(bv, oa, s);             // n <= 96
     else if (jobs <= 16) xc_tile_launch<GGA, 16, 16, 1, false, 0>(bv, oa, s);      // n <= 128
     else if (jobs <= 21) xc_tile_launch<GGA, 16, 21, 1, false, 0>(bv, oa, s);      // n <= 144
+    else if (bv.n <= 256) xc_tile_launch<GGA, 16, 16, 1, false, 0>(bv, oa, s);     // above: 64 output tiles per z group
     else return false;
     return true;
 }

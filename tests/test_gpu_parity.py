@@ -68,7 +68,7 @@ def test_jk_incore_matches_oracle(basis):
     assert np.max(np.abs(K - Ko)) < 1e-11
 
 
-@pytest.mark.parametrize("n", [2, 7, 24, 25, 48, 86, 114])
+@pytest.mark.parametrize("n", [2, 7, 24, 25, 48, 86, 114, 140, 141, 200, 256])
 def test_syev_matches_lapack(n):
     rng = np.random.default_rng(n)
     A = rng.normal(size=(n, n)); A = 0.5 * (A + A.T)
@@ -343,6 +343,28 @@ def test_sad_guess_in_a_batch_with_a_ghost_atom():
     g = methods.run_hip_scf(methods.ScfSettings(basis_set="cc-pvdz", guess="gwh", energy_tol=1e-10, density_tol=1e-8), gh)
     assert not a.has_error and not g.has_error, (a.error_message, g.error_message)
     assert abs(a.energy.scf - g.energy.scf) < 2e-9
+
+
+def test_fragments_above_140_functions_run_from_global_memory():
+    """n_ao = 147 ((H2O)21 in STO-3G: 63 atoms): the Fock matrix no longer fits the CU's LDS, the Jacobi rotations run
+    on a copy in global memory (L2), the two-electron part on the direct path, the quadrature deals its output tiles to
+    blockIdx.z groups.  RHF and B3LYP against the oracle, iteration counts included."""
+    rng = np.random.default_rng(7)
+    xs = [water_at(rng, np.array([5.6 * i, 5.6 * j, 5.6 * k])) for i in range(3) for j in range(3) for k in range(3)][:21]
+    frag = fragment_bohr([8, 1, 1] * 21, np.vstack(xs))
+    mol = oracle_mol("sto-3g", frag)
+    assert mol.nao == 147
+    eri = so.eri4(mol)
+    for fn in ("", "b3lyp"):
+        st = methods.ScfSettings(basis_set="sto-3g", functional=fn, grid_level=1, energy_tol=1e-9, density_tol=1e-7, guess="gwh")
+        r = methods.run_hip_scf(st, frag)
+        assert not r.has_error, r.error_message
+        xc = xc_oracle.XCOracle(mol, fn, 1) if fn else None       # the coarsest grid: the oracle's quadrature sets this test's time
+        o = so.run_rhf(mol, int(frag.nelec), 100, 1e-9, 1e-7, xc=xc, eri=eri)
+        assert abs(r.energy.scf - o.energy) < 2e-8, (fn, r.energy.scf, o.energy)
+        assert r.scf_iterations == o.iterations
+    r = methods.run_hip_scf(methods.ScfSettings(basis_set="sto-3g", density_fitting=True, aux_basis_set="mqc-even-tempered-jkfit"), frag)
+    assert r.has_error and "140" in r.error_message
 
 
 def test_refusals_match_reference_behaviour():
