@@ -20,7 +20,9 @@ for g in 15 18 6 12 4 13 5 14 10 2 11 3 9 19 1 8 0 7 16 17; do
   o=_obj/kern_eri_inst_$g.o
   if stale "$o" kern_eri_inst.hip; then run hipcc $FLAGS -DERI_GROUP=$g -x hip -c kern_eri_inst.hip -o "$o"; fi
 done
-for f in kern_int1e.hip kern_eri.hip kern_eri_general.hip kern_grad.hip kern_fock.hip kern_scf.hip kern_xc.hip kern_df.hip host_setup.cpp grid_host.cpp engine.cpp; do
+# kern_scf_wide.hip is kern_scf.hip compiled with 512 threads per fragment
+[ kern_scf.hip -nt kern_scf_wide.hip ] && touch kern_scf_wide.hip
+for f in kern_int1e.hip kern_eri.hip kern_eri_general.hip kern_grad.hip kern_fock.hip kern_scf.hip kern_scf_wide.hip kern_xc.hip kern_df.hip host_setup.cpp grid_host.cpp engine.cpp; do
   o=_obj/${f%.*}.o
   if stale "$o" "$f"; then run hipcc $FLAGS -x hip -c "$f" -o "$o"; fi
 done

@@ -17,9 +17,18 @@
 // with the matrix in its 160 KB LDS does n/2 independent rotations per step).
 #include "engine.hpp"
 
-namespace mqc {
+// This file is compiled twice: with 256 threads per fragment (the throughput build: eight or more fragments per CU) and,
+// from kern_scf_wide.hip, with 512 (the latency build for batches that leave CUs idle -- one rank's share of an 8-way
+// split, single-fragment calls -- where a rotation set's update loops are the critical path).  Everything device-side
+// has internal linkage so that the two builds do not meet at link time.
+#ifndef MQC_SCF_NT
+#define MQC_SCF_NT 256
+#endif
 
-constexpr int NT = 256;
+namespace mqc {
+namespace {
+
+constexpr int NT = MQC_SCF_NT;
 constexpr double OVERLAP_EIG_TOL = 1.0e-7;   // src/scf/mqc_scf_common.f90:33
 constexpr double GWH_K = 1.75;               // src/scf/mqc_scf_common.f90:39
 constexpr double PIVOT_FLOOR = 1.0e-14;      // src/methods/mqc_diis.f90:30
@@ -784,6 +793,8 @@ __global__ void count_active_kernel(BatchView bv)
 }
 
 // ---------------------------------------------------------------------------------------
+}  // anonymous namespace
+
 static int jacobi_mode(int n)
 {
     if (jacobi_lds_doubles(n, true) * sizeof(double) <= 150 * 1024) return 2;
@@ -791,11 +802,25 @@ static int jacobi_mode(int n)
     return 0;
 }
 
+#if MQC_SCF_NT == 256
 size_t scf_lds_bytes(int n)
 {
     const int mode = jacobi_mode(n);
     return jacobi_lds_doubles(n, mode == 2, mode != 0) * sizeof(double);
 }
+void launch_orthogonalizer_wide(const BatchView& bv, hipStream_t s);
+void launch_guess_wide(const BatchView& bv, int guess_kind, hipStream_t s);
+void launch_scf_step_wide(const BatchView& bv, hipStream_t s);
+// batches of at most this many fragments take the 512-thread build (MQC_HIP_SCF_WIDE_MAX; 0 turns it off)
+static int scf_wide_max()
+{
+    static const int v = [] { const char* e = std::getenv("MQC_HIP_SCF_WIDE_MAX"); return e ? std::atoi(e) : 640; }();
+    return v;
+}
+#define MQC_SCF_PUBLIC(name) name
+#else
+#define MQC_SCF_PUBLIC(name) name##_wide
+#endif
 
 #define MQC_JACOBI_DISPATCH(KERNEL, N, ...)                                                   \
     do {                                                                                      \
@@ -812,14 +837,20 @@ static void launch_wg(K kern, int nfrag, size_t lds, hipStream_t s, Args... args
     hipLaunchKernelGGL(kern, dim3(nfrag), dim3(NT), lds, s, args...);
 }
 
-void launch_orthogonalizer(const BatchView& bv, hipStream_t s)
+void MQC_SCF_PUBLIC(launch_orthogonalizer)(const BatchView& bv, hipStream_t s)
 {
+#if MQC_SCF_NT == 256
+    if (bv.nfrag <= scf_wide_max()) return launch_orthogonalizer_wide(bv, s);
+#endif
     const size_t lds = scf_lds_bytes(bv.n);
     MQC_JACOBI_DISPATCH(orthogonalizer_kernel, bv.n, bv.nfrag, lds, s, bv);
 }
 
-void launch_guess(const BatchView& bv, int guess_kind, hipStream_t s)
+void MQC_SCF_PUBLIC(launch_guess)(const BatchView& bv, int guess_kind, hipStream_t s)
 {
+#if MQC_SCF_NT == 256
+    if (bv.nfrag <= scf_wide_max()) return launch_guess_wide(bv, guess_kind, s);
+#endif
     const size_t lds = scf_lds_bytes(bv.n);
     MQC_JACOBI_DISPATCH(guess_kernel, bv.n, bv.nfrag, lds, s, bv, guess_kind);
 }
@@ -835,6 +866,7 @@ static void apply_jacobi_env()
     (void)done;
 }
 
+#if MQC_SCF_NT == 256
 __global__ void broadcast_kernel(double* dst, const double* src, size_t count)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -846,8 +878,13 @@ void launch_broadcast(double* dst, const double* src, size_t count, int nfrag, h
     hipLaunchKernelGGL(broadcast_kernel, dim3((unsigned)((count + 255) / 256), nfrag), dim3(256), 0, s, dst, src, count);
 }
 
-void launch_scf_step(const BatchView& bv, hipStream_t s)
+#endif
+
+void MQC_SCF_PUBLIC(launch_scf_step)(const BatchView& bv, hipStream_t s)
 {
+#if MQC_SCF_NT == 256
+    if (bv.nfrag <= scf_wide_max()) return launch_scf_step_wide(bv, s);
+#endif
     apply_jacobi_env();
     const size_t lds = scf_lds_bytes(bv.n);
     if (bv.uhf) MQC_JACOBI_DISPATCH(scf_step_uhf_kernel, bv.n, bv.nfrag, lds, s, bv);
@@ -855,6 +892,7 @@ void launch_scf_step(const BatchView& bv, hipStream_t s)
     hipLaunchKernelGGL(count_active_kernel, dim3(1), dim3(256), 0, s, bv);
 }
 
+#if MQC_SCF_NT == 256
 // ---- stage-level entry points ---------------------------------------------------------
 template <int JM>
 __global__ void __launch_bounds__(NT) syev_kernel(int n, const double* A, double* w, double* V, double* Aglb)
@@ -926,5 +964,7 @@ void launch_diis_coeff(int n_stored, const double* d_overlap, double* d_coef, in
 {
     hipLaunchKernelGGL(diis_coeff_kernel, dim3(1), dim3(64), 0, s, n_stored, d_overlap, d_coef, d_ok);
 }
+
+#endif      // MQC_SCF_NT == 256
 
 }  // namespace mqc
