@@ -113,7 +113,7 @@ static int upload_topology(mqc_hip_context* ctx, const Topology& topo, TopologyD
     td.gexps = (double*)take(sizeof(double) * gex.size()); td.gcoefs = (double*)take(sizeof(double) * gco.size());
     td.ngroup = ng;
     td.gprim_total = (int)gex.size(); td.gcoef_total = (int)gco.size();
-    td.nshell = ns; td.nao = topo.nao; td.npair = topo.npair; td.natoms = topo.natoms;
+    td.nshell = ns; td.nao = topo.nao; td.npair = topo.npair; td.natoms = topo.natoms; td.lmax = topo.lmax;
     hipStream_t s = stream ? stream : ctx->stream;
     HIP_CHECK_RET(hipMemcpyAsync(td.sh_l, l.data(), ib, hipMemcpyHostToDevice, s));
     HIP_CHECK_RET(hipMemcpyAsync(td.sh_nprim, np.data(), ib, hipMemcpyHostToDevice, s));

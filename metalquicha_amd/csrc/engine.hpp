@@ -110,6 +110,7 @@ struct TopologyDev {
     int *sh_l, *sh_nprim, *sh_poff, *sh_atom, *sh_aoff;
     double *exps, *coefs, *zeff;
     int nshell, nao, npair, natoms;
+    int lmax;                           // highest angular momentum among the shells
     // radial groups for the AO evaluation on the grid (kern_xc.hip): consecutive shells of one atom and one l whose
     // primitives all belong to the first shell's list (general contraction: cc-pVDZ oxygen 1s/2s/3s share nine
     // exponents) evaluate their exponentials once.  gcoefs holds grp_count rows of grp_nprim coefficients (zeros

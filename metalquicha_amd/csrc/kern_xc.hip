@@ -389,7 +389,7 @@ void launch_becke_weights(const BatchView& bv, hipStream_t s)
 constexpr int XC_NT = 256;
 
 // angular part of one shell at one point from its radial value and derivative factor
-template <bool GGA>
+template <bool GGA, bool LF = true>
 __device__ __forceinline__ void emit_shell(int l, int ao, double dx, double dy, double dz, double rad, double drad,
                                            double* __restrict__ chi, double* __restrict__ gx, double* __restrict__ gy,
                                            double* __restrict__ gz, int ptp, int p, const double* __restrict__ c2s)
@@ -404,7 +404,7 @@ __device__ __forceinline__ void emit_shell(int l, int ao, double dx, double dy, 
             gx[(ao + 1) * ptp + p] = dy * dx * drad; gy[(ao + 1) * ptp + p] = rad + dy * dy * drad; gz[(ao + 1) * ptp + p] = dy * dz * drad;
             gx[(ao + 2) * ptp + p] = dz * dx * drad; gy[(ao + 2) * ptp + p] = dz * dy * drad; gz[(ao + 2) * ptp + p] = rad + dz * dz * drad;
         }
-    } else if (l >= 3) {
+    } else if (LF && l >= 3) {
         // l = 3, 4: Cartesian monomials x^a y^b z^c in libcint order, transformed with the packed c2s table
         const int nc = ncart(l), nsp = nsph(l);
         auto ipow = [](double x, int k) { double r = 1.0; for (int i = 0; i < k; ++i) r *= x; return r; };   // k <= 4, no arrays (no scratch)
@@ -948,7 +948,7 @@ __device__ unsigned long long g_xc_stamps[16];
 #define XC_ST(k)
 #endif
 
-template <bool GGA, int PT, int JMAX, int OCC, bool DREG, int NTC>
+template <bool GGA, int PT, int JMAX, int OCC, bool DREG, int NTC, bool FAST = false>
 __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, int only_active)
 {
     // One tile = PT points: AO slab -> X = D chi, rho / grad rho -> functional (one lane per point) -> a -> A += a chi^T.
@@ -957,7 +957,13 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
     // the full-width functional saves: measured 2.09 s against 1.99 s per evaluation.  Kept for the record, off.)
     extern __shared__ double lds[];
     const int f = blockIdx.y;
-    const bool rad_in_lds = (only_active & 2) != 0;           // bit 1 of the flag word: radial tile staged in LDS
+    // FAST: the lean build of the slab phase for the common case -- radial tile in LDS, no f shells: one item per
+    // (SHELL, point) with a single copy of the angular code.  The general slab (radial groups with up to three
+    // contracted shells each, cached / uncached paths, f and g shells) is ~4 500 instructions, the whole tile loop
+    // ~80 KB of code against a 64 KB instruction cache shared by two CUs: the eight waves of a CU, each in its own
+    // phase, were waiting on instruction fetches (making MORE waves run different code at once -- the functional's
+    // components dealt to four waves -- made the kernel slower, twice).
+    const bool rad_in_lds = FAST || (only_active & 2) != 0;   // bit 1 of the flag word: radial tile staged in LDS
     if ((only_active & 1) && bv.istate[4 * f] == ST_DONE) return;
     constexpr int RS = PT + 1, PT16 = PT / 16, NTHR = 64 * XV_NW, SUPER = XC_TWO_PASS ? NTHR : PT, NSUB = SUPER / PT;
     const int n = bv.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -981,7 +987,8 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
     int* tdesc = (int*)tab;
     double* texps = tab + 3 * ng;
     double* tcoefs = texps + ngp;
-    double* radl = tab + (((size_t)(3 * ng + ngp + ngc + 8) + 1) & ~(size_t)1);      // [nshell][2][PT] radial tile (16-byte aligned)
+    int* sdesc = (int*)(tab + 3 * ng + ngp + ngc + 8);        // [nshell] ao | l << 12 | atom << 16 (FAST slab)
+    double* radl = tab + (((size_t)(3 * ng + ngp + ngc + 8 + (tp.nshell + 1) / 2) + 1) & ~(size_t)1);      // [nshell][2][PT] radial tile (16-byte aligned)
     const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
     const double* __restrict__ D = bv.D + (size_t)f * n * n;
     const double* __restrict__ wts = gd.weights + (size_t)f * gd.npts;
@@ -997,6 +1004,7 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
         tdesc[6 * g + 4] = sh0;
         tdesc[6 * g + 5] = 0;
     }
+    if (FAST) for (int sh = tid; sh < tp.nshell; sh += NTHR) sdesc[sh] = tp.sh_aoff[sh] | (tp.sh_l[sh] << 12) | (tp.sh_atom[sh] << 16);
     for (int idx = tid; idx < ngp; idx += NTHR) texps[idx] = tp.gexps[idx];
     for (int idx = tid; idx < ngc; idx += NTHR) tcoefs[idx] = tp.gcoefs[idx];
     const GroupTables gt{tdesc, texps, tcoefs};
@@ -1067,6 +1075,20 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
     const int tz0 = (int)blockIdx.z * XV_NW * JMAX;
     auto ao_slab = [&](int g0) {
         if (probe & 1) return;
+        if constexpr (FAST) {
+            // (shell, point) items, point fastest; beyond the grid's end the radial values are zero and so is the shell
+            for (int idx = tid; idx < tp.nshell * PT; idx += NTHR) {
+                const int sh = idx / PT, p = idx - sh * PT;
+                const int sd = sdesc[sh];
+                const int ao = sd & 0xfff, l = (sd >> 12) & 0xf, at = sd >> 16;
+                const double* pp = pxyz + 3 * (pbuf * PT + p);
+                const double dx = pp[0] - axyz[3 * at], dy = pp[1] - axyz[3 * at + 1], dz = pp[2] - axyz[3 * at + 2];
+                const bool in = g0 + p < gd.npts;
+                const double* r0 = radl + (size_t)sh * 2 * PT + p;
+                emit_shell<GGA, false>(l, ao, dx, dy, dz, in ? r0[0] : 0.0, in ? r0[PT] : 0.0, chi, gx, gy, gz, RS, p, bv.c2s);
+            }
+            return;
+        }
         // AO values (and gradients) of PT points: (radial group, point) items, point fastest
         for (int idx = tid; idx < tp.ngroup * PT; idx += NTHR) {
             const int rg = idx / PT, p = idx - rg * PT;
@@ -1281,7 +1303,7 @@ static void xc_tile_launch(const BatchView& bv, int oa, hipStream_t s)
     const int np = ((bv.n + 15) / 16) * 16;
     // + radial-group tables: 2 doubles of descriptor per group, the exponents and up to XC_GROUP_MAX coefficient rows;
     // groups <= shells <= n, primitives per group <= 63 (descriptor field); bounded by the topology's own totals
-    const size_t tab = 3 * (size_t)bv.topo.ngroup + (size_t)bv.topo.gprim_total + (size_t)bv.topo.gcoef_total + 8;
+    const size_t tab = 3 * (size_t)bv.topo.ngroup + (size_t)bv.topo.gprim_total + (size_t)bv.topo.gcoef_total + 8 + ((size_t)bv.topo.nshell + 1) / 2;
     size_t lds = sizeof(double) * ((size_t)(GGA ? 4 : 2) * np * (PT + 1) + 8 * (XC_TWO_PASS ? 64 * XV_NW : PT) + 3 * 64 + 6 * PT + ((tab + 1) & ~(size_t)1));
     // the radial tile rides in LDS when that does not cost a resident workgroup (OCC of them share 160 KB)
     const size_t rad_lds = sizeof(double) * (size_t)bv.topo.nshell * 2 * PT;
@@ -1291,7 +1313,11 @@ static void xc_tile_launch(const BatchView& bv, int oa, hipStream_t s)
         lds += rad_lds;
         oa |= 2;
     }
-    auto kern = xc_tile_kernel<GGA, PT, JMAX, OCC, DREG, NTC>;
+    auto kern = xc_tile_kernel<GGA, PT, JMAX, OCC, DREG, NTC, false>;
+    if constexpr (DREG) {
+        static const bool fast_on = [] { const char* e = std::getenv("MQC_HIP_XC_FAST_SLAB"); return !(e && e[0] == '0'); }();
+        if (fast_on && (oa & 2) && bv.topo.lmax <= 2) kern = xc_tile_kernel<GGA, PT, JMAX, OCC, DREG, NTC, true>;
+    }
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int tile_pts = XC_TWO_PASS ? 64 * XV_NW : PT;
     const int ntiles = (bv.grid.npts + tile_pts - 1) / tile_pts;
