@@ -281,6 +281,32 @@ def main():
             secondary["single_call"] = {"scf_iterations_per_s": its / dt, "fragments": len(frags), "seconds": dt,
                                         "ms_per_fragment": 1e3 * dt / len(frags),
                                         "note": "one fragment per mqc_hip_scf_run (unchanged do_fragment_work): a batch of one"}
+            # BASELINE.json configs[1]: ONE benzene, B3LYP/cc-pVDZ, density-fitted J/K (n = 114, grid level 3); a fresh
+            # rotation per repeat so that nothing is served from a geometry-keyed cache
+            import numpy as _np
+            rcc, rch = 1.397, 1.084
+            sym = ["C"] * 6 + ["H"] * 6
+            xyz0 = _np.array([[rcc * _np.cos(_np.pi / 3 * k), rcc * _np.sin(_np.pi / 3 * k), 0.0] for k in range(6)] +
+                             [[(rcc + rch) * _np.cos(_np.pi / 3 * k), (rcc + rch) * _np.sin(_np.pi / 3 * k), 0.0] for k in range(6)])
+            bst = methods.ScfSettings(basis_set="cc-pvdz", functional="b3lyp", density_fitting=True, aux_basis_set="mqc-even-tempered-jkfit",
+                                      energy_tol=args.energy_tol, density_tol=args.density_tol, guess="gwh")
+            rngb = _np.random.default_rng(5)
+            times, iters, e_b = [], 0, None
+            for rep in range(3):
+                q, _ = _np.linalg.qr(rngb.normal(size=(3, 3)))
+                frag_b = methods.PhysicalFragment.from_angstrom(sym, (xyz0 @ q.T).tolist())
+                t1 = time.perf_counter()
+                rb = methods.run_hip_scf(bst, frag_b)
+                dtb = time.perf_counter() - t1
+                if rb.has_error:
+                    raise RuntimeError("benzene secondary failed: " + rb.error_message)
+                if rep > 0:
+                    times.append(dtb); iters += rb.scf_iterations
+                e_b = rb.energy.scf
+            secondary["benzene_b3lyp_df_single_fragment"] = {
+                "seconds_per_scf": sum(times) / len(times), "scf_iterations_per_s": iters / sum(times), "scf_iterations": iters // len(times),
+                "energy_hartree": e_b, "n_ao": 114,
+                "note": "BASELINE configs[1]; auxiliary set mqc-even-tempered-jkfit; one fragment = a batch of one (latency-bound stages)"}
 
     if rank == 0:
         n_steps = max(args.steps, 1)
