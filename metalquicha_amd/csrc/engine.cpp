@@ -222,7 +222,6 @@ static int validate_options(const mqc_hip_scf_options_t& o, const Topology& topo
     if (o.want_gradient) {
         XcSpec tg; std::string eg;
         parse_functional(o.functional, tg, eg);
-        if (tg.ncomp > 0) { msg = "analytic gradients are available for Hartree-Fock (restricted and unrestricted); the Kohn-Sham exchange-correlation term is not built yet"; return MQC_HIP_ERR_UNSUPPORTED; }
         if (o.density_fitting) { msg = "analytic gradients are available on the exact-ERI path; the density-fitted two-electron derivative is not built yet"; return MQC_HIP_ERR_UNSUPPORTED; }
         if (topo.lmax > 2) { msg = "analytic gradients cover s, p and d shells"; return MQC_HIP_ERR_UNSUPPORTED; }
     }

@@ -617,6 +617,8 @@ static Grad2eLayout grad2e_layout(int la, int lb, int lc, int ld)
 
 // Gradient of the whole batch into d_grad [nfrag][natoms][3] (zeroed here); Dtot = D (restricted) or D_a + D_b.
 // work: device scratch of at least 2 * nfrag * n * n doubles (energy-weighted density, total density of a UHF run).
+bool launch_xc_gradient(const BatchView& bv, double* d_grad, hipStream_t s, std::string& err);      // kern_xc.hip
+
 bool launch_gradient(const BatchView& bv, const Topology& topo, double* d_grad, double* work, int* d_lists, size_t list_capacity_ints,
                      hipStream_t s, std::string& err)
 {
@@ -670,6 +672,8 @@ bool launch_gradient(const BatchView& bv, const Topology& topo, double* d_grad, 
                            d_lists + off, (int)(cl.quartets.size() / 4), Dtot, bv.uhf ? bv.Db : (const double*)nullptr, d_grad);
         off += cl.quartets.size();
     }
+    // ---- exchange-correlation (Kohn-Sham): moving functions, moving points, moving partition
+    if (bv.xc.ncomp > 0 && !launch_xc_gradient(bv, d_grad, s, err)) return false;
     return true;
 }
 

@@ -18,6 +18,7 @@
 #include "engine.hpp"
 #include "md_integrals.hpp"
 #include <cstdlib>
+#include <string>
 
 namespace mqc {
 
@@ -1563,6 +1564,320 @@ void launch_xc(const BatchView& bv, bool only_active, hipStream_t s)
     } else {
         if (gga) xc_launch<true, 16, 77>(bv, oa, s); else xc_launch<false, 16, 77>(bv, oa, s);
     }
+}
+
+
+// ------------------------------------------------------------------ exchange-correlation gradient
+// xc_gradient (backends/libcint/mqc_libcint_gradient.f90:331-549), per point g with quadrature weight q, partition
+// P and w = q P, channel density D (total when restricted, one spin otherwise), Xc = D chi, Xg_j = D d_j chi:
+//     S_k(A) = sum_{mu in A} [ w v_rho d_k chi_mu Xc_mu + sum_j w c_j (d_k d_j chi_mu Xc_mu + d_k chi_mu Xg_j,mu) ]
+//     grad[A] -= 2 S(A)                 the functions of A move with A
+//     grad[own(g)] += 2 sum_A S(A)      the point moves with the atom that owns it
+//     grad[A] += q f dP/dR_A,  grad[own] -= q f sum_A dP/dR_A      the partition weights move (becke_xc_grad_kernel)
+// with c = dE/d(grad rho) = 2 v_sigma grad rho (restricted) or 2 v_ss grad rho_s + v_ab grad rho_s' (unrestricted).
+// Parity-first kernels on the vector units: a gradient is one evaluation per geometry step, not per SCF iteration.
+constexpr int XG_PT = 8, XG_NT = 256;
+
+// value, gradient and packed Hessian (xx, xy, xz, yy, yz, zz) of P(x, y, z) R(r^2) from the polynomial's own
+// derivatives and R0 = R, R1 = R'/r, R2 = (R'/r)'/r:  d_i d_j (P R) = P_ij R0 + (P_i x_j + P_j x_i) R1 + P (R2 x_i x_j + R1 d_ij)
+template <bool GGA>
+__device__ __forceinline__ void put_function(double P, const double* Pi, const double* Pij, const double* x, double R0, double R1, double R2,
+                                             double* __restrict__ base, size_t S, int o)
+{
+    base[o] = P * R0;
+    for (int i = 0; i < 3; ++i) base[(1 + i) * S + o] = Pi[i] * R0 + P * R1 * x[i];
+    if (GGA) {
+        int m = 0;
+        for (int i = 0; i < 3; ++i)
+            for (int j = i; j < 3; ++j, ++m)
+                base[(4 + m) * S + o] = Pij[m] * R0 + (Pi[i] * x[j] + Pi[j] * x[i]) * R1 + P * (R2 * x[i] * x[j] + (i == j ? R1 : 0.0));
+    }
+}
+
+template <bool GGA>
+__device__ void emit_shell_d2(int l, int ao, double dx, double dy, double dz, double R0, double R1, double R2,
+                              double* __restrict__ base, size_t S, int ptp, int p)
+{
+    const double x[3] = {dx, dy, dz};
+    if (l == 0) {
+        const double Pi[3] = {0.0, 0.0, 0.0}, Pij[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        put_function<GGA>(1.0, Pi, Pij, x, R0, R1, R2, base, S, ao * ptp + p);
+    } else if (l == 1) {
+        for (int k = 0; k < 3; ++k) {
+            double Pi[3] = {0.0, 0.0, 0.0};
+            const double Pij[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            Pi[k] = 1.0;
+            put_function<GGA>(x[k], Pi, Pij, x, R0, R1, R2, base, S, (ao + k) * ptp + p);
+        }
+    } else {
+        // l = 2: the five real solid harmonics as combinations of xx, xy, xz, yy, yz, zz (libcint order xy, yz, z2, xz, x2-y2)
+        const int ca[6] = {0, 0, 0, 1, 1, 2}, cb[6] = {0, 1, 2, 1, 2, 2};
+        for (int m = 0; m < 5; ++m) {
+            double P = 0.0, Pi[3] = {0.0, 0.0, 0.0}, Pij[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            for (int c = 0; c < 6; ++c) {
+                const double w = c2s_coef<2>(nullptr, m, c);
+                if (w == 0.0) continue;
+                const int a = ca[c], b = cb[c];
+                P += w * x[a] * x[b];
+                Pi[a] += w * x[b]; Pi[b] += w * x[a];
+                // packed index of (a, b), a <= b: xx 0, xy 1, xz 2, yy 3, yz 4, zz 5 -- the same order as the Cartesian list
+                Pij[c] += (a == b) ? 2.0 * w : w;
+            }
+            put_function<GGA>(P, Pi, Pij, x, R0, R1, R2, base, S, (ao + m) * ptp + p);
+        }
+    }
+}
+
+template <bool GGA, bool UKS>
+__global__ void __launch_bounds__(XG_NT) xc_grad_kernel(BatchView bv, double* __restrict__ d_grad, double* __restrict__ fbuf)
+{
+    extern __shared__ double lds[];
+    const int f = blockIdx.y, tid = threadIdx.x, n = bv.n;
+    const TopologyDev& tp = bv.topo;
+    const GridDev& gd = bv.grid;
+    constexpr int PT = XG_PT, PTP = PT + 1, NA = GGA ? 10 : 4, NXS = GGA ? 4 : 1, NSP = UKS ? 2 : 1;
+    const size_t S = (size_t)n * PTP;
+    double* ao = lds;                                   // [NA][n][PTP]: chi, d chi (3), d d chi (6)
+    double* X = ao + NA * S;                            // [NSP][NXS][n][PTP]: D chi, D d_j chi
+    double* pwv = X + (size_t)NSP * NXS * S;            // [NSP][4][PT]: w v_rho, w c_j
+    double* gacc = pwv + NSP * 4 * PT;                  // [natoms][3]
+    int* aoff = (int*)(gacc + 3 * tp.natoms);           // [natoms + 1] first function of every atom
+    int* own = aoff + tp.natoms + 1;                    // [PT]
+    const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
+    const double* Dm[2] = {bv.D + (size_t)f * n * n, UKS ? bv.Db + (size_t)f * n * n : nullptr};
+    const double* wts = gd.weights + (size_t)f * gd.npts;
+
+    for (int i = tid; i < 3 * tp.natoms; i += XG_NT) gacc[i] = 0.0;
+    if (tid == 0) {
+        // shells are ordered by atom: the first function of every atom
+        for (int a = 0; a <= tp.natoms; ++a) aoff[a] = n;
+        for (int sh = tp.nshell - 1; sh >= 0; --sh) aoff[tp.sh_atom[sh]] = tp.sh_aoff[sh];
+        for (int a = tp.natoms - 1; a >= 0; --a) if (aoff[a] > aoff[a + 1]) aoff[a] = aoff[a + 1];       // atoms without functions
+    }
+    __syncthreads();
+    const int ntiles = (gd.npts + PT - 1) / PT;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int g0 = tile * PT;
+        // 1. functions, first and second derivatives: (shell, point) items
+        for (int idx = tid; idx < tp.nshell * PT; idx += XG_NT) {
+            const int sh = idx / PT, p = idx - sh * PT, g = g0 + p;
+            const int l = tp.sh_l[sh], at = tp.sh_atom[sh];
+            double dx = 0.0, dy = 0.0, dz = 0.0, R0 = 0.0, R1 = 0.0, R2 = 0.0;
+            if (g < gd.npts) {
+                const int oa = gd.pt_atom[g], it = gd.pt_tmpl[g];
+                dx = xyz[3 * oa] + gd.tmpl_xyz[3 * it] - xyz[3 * at];
+                dy = xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1] - xyz[3 * at + 1];
+                dz = xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2] - xyz[3 * at + 2];
+                const double r2 = dx * dx + dy * dy + dz * dz;
+                const double* e = tp.exps + tp.sh_poff[sh];
+                const double* c = tp.coefs + tp.sh_poff[sh];
+                for (int k = 0; k < tp.sh_nprim[sh]; ++k) {
+                    const double a = e[k], ar2 = a * r2;
+                    if (ar2 < XC_EXP_CUTOFF) {
+                        const double t = c[k] * exp(-ar2);
+                        R0 += t; R1 -= 2.0 * a * t; R2 += 4.0 * a * a * t;
+                    }
+                }
+            }
+            emit_shell_d2<GGA>(l, tp.sh_aoff[sh], dx, dy, dz, R0, R1, R2, ao, S, PTP, p);
+        }
+        if (tid < PT) own[tid] = (g0 + tid < gd.npts) ? gd.pt_atom[g0 + tid] : 0;
+        __syncthreads();
+        // 2. X = D chi and, for a gradient-corrected functional, D d_j chi, per spin
+        for (int idx = tid; idx < n * PT; idx += XG_NT) {
+            const int mu = idx / PT, p = idx - mu * PT;
+            for (int sp = 0; sp < NSP; ++sp) {
+                const double* __restrict__ dr = Dm[sp] + (size_t)mu * n;
+                double acc[NXS];
+                for (int k = 0; k < NXS; ++k) acc[k] = 0.0;
+                for (int nu = 0; nu < n; ++nu) {
+                    const double d = dr[nu];
+                    for (int k = 0; k < NXS; ++k) acc[k] += d * ao[k * S + nu * PTP + p];
+                }
+                for (int k = 0; k < NXS; ++k) X[((size_t)sp * NXS + k) * S + mu * PTP + p] = acc[k];
+            }
+        }
+        __syncthreads();
+        // 3. densities, the functional, the per-point weights; the energy density goes to fbuf for the partition term
+        if (tid < PT) {
+            const int p = tid, g = g0 + p;
+            double rho[2] = {0.0, 0.0}, gr[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+            for (int sp = 0; sp < NSP; ++sp)
+                for (int mu = 0; mu < n; ++mu) {
+                    const double xc_ = X[(size_t)sp * NXS * S + mu * PTP + p];
+                    rho[sp] += xc_ * ao[mu * PTP + p];
+                    if (GGA) for (int j = 0; j < 3; ++j) gr[sp][j] += 2.0 * xc_ * ao[(1 + j) * S + mu * PTP + p];
+                }
+            const double w = (g < gd.npts) ? wts[g] : 0.0;
+            double fx = 0.0;
+            if (!UKS) {
+                const double sigma = GGA ? gr[0][0] * gr[0][0] + gr[0][1] * gr[0][1] + gr[0][2] * gr[0][2] : 0.0;
+                double vr, vs;
+                eval_functional(bv.xc, rho[0], sigma, fx, vr, vs);
+                pwv[p] = w * vr;
+                for (int j = 0; j < 3; ++j) pwv[(1 + j) * PT + p] = GGA ? w * 2.0 * vs * gr[0][j] : 0.0;
+            } else {
+                double saa = 0.0, sab = 0.0, sbb = 0.0, dv[5];
+                for (int j = 0; j < 3; ++j) { saa += gr[0][j] * gr[0][j]; sab += gr[0][j] * gr[1][j]; sbb += gr[1][j] * gr[1][j]; }
+                eval_functional_pol(bv.xc, rho[0], rho[1], saa, sab, sbb, fx, dv);
+                pwv[p] = w * dv[0]; pwv[4 * PT + p] = w * dv[1];
+                for (int j = 0; j < 3; ++j) {
+                    pwv[(1 + j) * PT + p] = GGA ? w * (2.0 * dv[2] * gr[0][j] + dv[3] * gr[1][j]) : 0.0;
+                    pwv[(5 + j) * PT + p] = GGA ? w * (2.0 * dv[4] * gr[1][j] + dv[3] * gr[0][j]) : 0.0;
+                }
+            }
+            if (g < gd.npts) fbuf[(size_t)f * gd.npts + g] = fx;
+        }
+        __syncthreads();
+        // 4. block sums per (point, atom): the functions of the atom move with it, the point with its owner
+        for (int idx = tid; idx < PT * tp.natoms; idx += XG_NT) {
+            const int A = idx / PT, p = idx - A * PT;
+            double Sk[3] = {0.0, 0.0, 0.0};
+            for (int sp = 0; sp < NSP; ++sp) {
+                const double wv = pwv[(sp * 4) * PT + p];
+                const double c0 = pwv[(sp * 4 + 1) * PT + p], c1 = pwv[(sp * 4 + 2) * PT + p], c2 = pwv[(sp * 4 + 3) * PT + p];
+                const double* Xs = X + (size_t)sp * NXS * S;
+                for (int mu = aoff[A]; mu < aoff[A + 1]; ++mu) {
+                    const int o = mu * PTP + p;
+                    const double xc_ = Xs[o];
+                    const double g0_ = ao[S + o], g1_ = ao[2 * S + o], g2_ = ao[3 * S + o];
+                    Sk[0] += wv * g0_ * xc_; Sk[1] += wv * g1_ * xc_; Sk[2] += wv * g2_ * xc_;
+                    if (GGA) {
+                        const double hxx = ao[4 * S + o], hxy = ao[5 * S + o], hxz = ao[6 * S + o], hyy = ao[7 * S + o], hyz = ao[8 * S + o], hzz = ao[9 * S + o];
+                        const double xg = c0 * Xs[S + o] + c1 * Xs[2 * S + o] + c2 * Xs[3 * S + o];        // sum_j c_j (D d_j chi)_mu
+                        Sk[0] += (c0 * hxx + c1 * hxy + c2 * hxz) * xc_ + g0_ * xg;
+                        Sk[1] += (c0 * hxy + c1 * hyy + c2 * hyz) * xc_ + g1_ * xg;
+                        Sk[2] += (c0 * hxz + c1 * hyz + c2 * hzz) * xc_ + g2_ * xg;
+                    }
+                }
+            }
+            const int o = own[p];
+            for (int k = 0; k < 3; ++k) {
+                if (Sk[k] != 0.0) { atomicAdd(&gacc[3 * A + k], -2.0 * Sk[k]); atomicAdd(&gacc[3 * o + k], 2.0 * Sk[k]); }
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < 3 * tp.natoms; i += XG_NT)
+        if (gacc[i] != 0.0) atomicAdd(&d_grad[(size_t)f * tp.natoms * 3 + i], gacc[i]);
+}
+
+// d(f3(f2(f1(nu))))/d nu of Becke's cell function s = (1 - f3) / 2, f(x) = x (3 - x^2) / 2
+__device__ __forceinline__ void becke_cutoff_d(double nu, double& s, double& ds)
+{
+    const double f1 = 0.5 * nu * (3.0 - nu * nu), f2 = 0.5 * f1 * (3.0 - f1 * f1), f3 = 0.5 * f2 * (3.0 - f2 * f2);
+    s = 0.5 * (1.0 - f3);
+    ds = -0.5 * (1.5 * (1.0 - f2 * f2)) * (1.5 * (1.0 - f1 * f1)) * (1.5 * (1.0 - nu * nu));
+}
+
+// The partition term: P_O = cell_O / sum_C cell_C with cell_C = prod_{B != C} s(nu_CB); point held fixed,
+//     dP_O/dR_A = P_O sum_C (delta_CO - P_C) d ln cell_C / dR_A,
+// and the pair (i < j) touches d ln cell_i and d ln cell_j with respect to R_i and R_j only.
+__global__ void __launch_bounds__(256) becke_xc_grad_kernel(BatchView bv, const double* __restrict__ fbuf, double* __restrict__ d_grad)
+{
+    __shared__ double gblk[3 * BECKE_MAX_ATOMS];
+    const int f = blockIdx.y;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const GridDev& gd = bv.grid;
+    const int na = bv.topo.natoms;
+    for (int i = threadIdx.x; i < 3 * na; i += blockDim.x) gblk[i] = 0.0;
+    __syncthreads();
+    if (g < gd.npts && na > 1) {
+        const double* xyz = bv.xyz + (size_t)f * na * 3;
+        const int owner = gd.pt_atom[g], it = gd.pt_tmpl[g];
+        const double px = xyz[3 * owner] + gd.tmpl_xyz[3 * it], py = xyz[3 * owner + 1] + gd.tmpl_xyz[3 * it + 1],
+                     pz = xyz[3 * owner + 2] + gd.tmpl_xyz[3 * it + 2];
+        const double qf = gd.tmpl_w[it] * fbuf[(size_t)f * gd.npts + g];
+        if (qf != 0.0) {
+            double dist[BECKE_MAX_ATOMS], cell[BECKE_MAX_ATOMS], G[3 * BECKE_MAX_ATOMS];
+            for (int i = 0; i < na; ++i) {
+                const double dx = px - xyz[3 * i], dy = py - xyz[3 * i + 1], dz = pz - xyz[3 * i + 2];
+                dist[i] = sqrt(dx * dx + dy * dy + dz * dz);
+                cell[i] = 1.0;
+                G[3 * i] = 0.0; G[3 * i + 1] = 0.0; G[3 * i + 2] = 0.0;
+            }
+            for (int i = 0; i < na; ++i)
+                for (int j = i + 1; j < na; ++j) {
+                    const double dx = xyz[3 * i] - xyz[3 * j], dy = xyz[3 * i + 1] - xyz[3 * j + 1], dz = xyz[3 * i + 2] - xyz[3 * j + 2];
+                    const double mu = (dist[i] - dist[j]) / sqrt(dx * dx + dy * dy + dz * dz);
+                    const double chi = gd.sqrt_bragg[i] / gd.sqrt_bragg[j];
+                    double a = 0.25 * (1.0 / chi - chi);
+                    a = fmax(-0.5, fmin(0.5, a));
+                    const double s = becke_cutoff(mu + a * (1.0 - mu * mu));
+                    cell[i] *= s;
+                    cell[j] *= (1.0 - s);
+                }
+            double tot = 0.0;
+            for (int i = 0; i < na; ++i) tot += cell[i];
+            if (tot > 0.0 && cell[owner] > 0.0) {
+                const double itot = 1.0 / tot, PO = cell[owner] * itot;
+                for (int i = 0; i < na; ++i)
+                    for (int j = i + 1; j < na; ++j) {
+                        const double rx = xyz[3 * i] - xyz[3 * j], ry = xyz[3 * i + 1] - xyz[3 * j + 1], rz = xyz[3 * i + 2] - xyz[3 * j + 2];
+                        const double Rij = sqrt(rx * rx + ry * ry + rz * rz), iR = 1.0 / Rij;
+                        const double mu = (dist[i] - dist[j]) * iR;
+                        const double chi = gd.sqrt_bragg[i] / gd.sqrt_bragg[j];
+                        double a = 0.25 * (1.0 / chi - chi);
+                        a = fmax(-0.5, fmin(0.5, a));
+                        double s, ds;
+                        becke_cutoff_d(mu + a * (1.0 - mu * mu), s, ds);
+                        const double c = ds * (1.0 - 2.0 * a * mu);                 // d s / d mu
+                        // K = (delta_iO - P_i) c / s - (delta_jO - P_j) c / (1 - s); a vanished factor means a vanished cell
+                        double K = 0.0;
+                        if (s > 1.0e-300) K += ((i == owner ? 1.0 : 0.0) - cell[i] * itot) * c / s;
+                        if (1.0 - s > 1.0e-300) K -= ((j == owner ? 1.0 : 0.0) - cell[j] * itot) * c / (1.0 - s);
+                        if (K == 0.0) continue;
+                        // d mu / dR_i = -u_i / R_ij - mu (R_i - R_j) / R_ij^2,  d mu / dR_j = u_j / R_ij + mu (R_i - R_j) / R_ij^2
+                        const double ui[3] = {(px - xyz[3 * i]) / fmax(dist[i], 1.0e-300), (py - xyz[3 * i + 1]) / fmax(dist[i], 1.0e-300), (pz - xyz[3 * i + 2]) / fmax(dist[i], 1.0e-300)};
+                        const double uj[3] = {(px - xyz[3 * j]) / fmax(dist[j], 1.0e-300), (py - xyz[3 * j + 1]) / fmax(dist[j], 1.0e-300), (pz - xyz[3 * j + 2]) / fmax(dist[j], 1.0e-300)};
+                        const double rv[3] = {rx, ry, rz};
+                        for (int k = 0; k < 3; ++k) {
+                            const double t = mu * rv[k] * iR * iR;
+                            G[3 * i + k] += K * (-ui[k] * iR - t);
+                            G[3 * j + k] += K * (uj[k] * iR + t);
+                        }
+                    }
+                double sum[3] = {0.0, 0.0, 0.0};
+                for (int i = 0; i < na; ++i)
+                    for (int k = 0; k < 3; ++k) {
+                        const double v = qf * PO * G[3 * i + k];
+                        if (v != 0.0) atomicAdd(&gblk[3 * i + k], v);
+                        sum[k] += v;
+                    }
+                for (int k = 0; k < 3; ++k) if (sum[k] != 0.0) atomicAdd(&gblk[3 * owner + k], -sum[k]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * na; i += blockDim.x)
+        if (gblk[i] != 0.0) atomicAdd(&d_grad[(size_t)f * na * 3 + i], gblk[i]);
+}
+
+static DevicePool g_xcgrad_pool[2];
+
+bool launch_xc_gradient(const BatchView& bv, double* d_grad, hipStream_t s, std::string& err)
+{
+    const int n = bv.n;
+    const bool gga = bv.xc.gga != 0, uks = bv.uhf != 0;
+    double* fbuf = (double*)g_xcgrad_pool[bv.slot & 1].ensure(sizeof(double) * (size_t)bv.nfrag * bv.grid.npts + 256);
+    if (!fbuf) { err = "out of device memory (XC gradient)"; return false; }
+    const int NA = gga ? 10 : 4, NX = (gga ? 4 : 1) * (uks ? 2 : 1);
+    const size_t lds = sizeof(double) * ((size_t)(NA + NX) * n * (XG_PT + 1) + 8 * XG_PT + 3 * bv.topo.natoms + 8) + sizeof(int) * (bv.topo.natoms + 2 + XG_PT);
+    if (lds > 160 * 1024) { err = "XC gradient: fragment too large for the LDS slab"; return false; }
+    const int ntiles = (bv.grid.npts + XG_PT - 1) / XG_PT;
+    int gx = (8192 + bv.nfrag - 1) / bv.nfrag;
+    if (gx > ntiles) gx = ntiles;
+    if (gx < 1) gx = 1;
+#define XG_LAUNCH(G, U)                                                                                     \
+    do {                                                                                                    \
+        (void)hipFuncSetAttribute((const void*)xc_grad_kernel<G, U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((xc_grad_kernel<G, U>), dim3(gx, bv.nfrag), dim3(XG_NT), lds, s, bv, d_grad, fbuf); \
+    } while (0)
+    if (gga) { if (uks) XG_LAUNCH(true, true); else XG_LAUNCH(true, false); }
+    else { if (uks) XG_LAUNCH(false, true); else XG_LAUNCH(false, false); }
+#undef XG_LAUNCH
+    hipLaunchKernelGGL(becke_xc_grad_kernel, dim3((bv.grid.npts + 255) / 256, bv.nfrag), dim3(256), 0, s, bv, fbuf, d_grad);
+    return true;
 }
 
 }  // namespace mqc

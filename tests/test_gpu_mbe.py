@@ -170,6 +170,54 @@ def test_manifest_hf_gradient_goldens(case):
     assert np.max(np.abs(r.gradient.sum(axis=1))) < 1e-9
 
 
+from oracle import xc_oracle as _xco
+
+_KSGRAD = [c for c in _CASES if c.get("expected_gradient") and c["method"] == "dft" and not c["density_fitting"]
+           and c["functional"] in _xco.FUNCTIONALS and "*" not in c["basis"] and "mbe_level" not in c]
+
+
+@pytest.mark.parametrize("case", _KSGRAD, ids=[c["name"] for c in _KSGRAD])
+def test_manifest_kohn_sham_gradient_goldens(case):
+    """validation_tests_cpu.json gradient/ rows for Kohn-Sham (SVWN, PBE, B3LYP on H2O cc-pVDZ; unrestricted PBE on
+    CH3): the exchange-correlation gradient with moving functions (second derivatives of the basis for the GGAs),
+    moving grid points and the Becke / Treutler partition derivatives, as xc_gradient builds it
+    (mqc_libcint_gradient.f90:331-549).  Energy to 1e-9, components to the manifest's tolerance."""
+    z = [SYMBOL_TO_Z[s.lower()] for s in case["symbols"]]
+    frag = fragment_bohr(z, np.array(case["xyz_angstrom"]) * ANGSTROM_TO_BOHR, multiplicity=case["multiplicity"])
+    st = methods.ScfSettings(basis_set=case["basis"], functional=case["functional"], grid_level=case["grid_level"],
+                             energy_tol=1e-12, density_tol=1e-10, guess="gwh", max_iter=200)
+    r = methods.HFMethod(st).calc_gradient(frag)
+    assert not r.has_error, r.error_message
+    assert r.has_gradient and r.gradient.shape == (3, len(z))
+    assert abs(r.energy.scf - case["expected_energy"]) < 1e-9
+    ref = np.array(case["expected_gradient"]).T
+    assert np.max(np.abs(r.gradient - ref)) < max(case["gradient_tolerance"], 5e-8), (np.max(np.abs(r.gradient - ref)), r.gradient, ref)
+    assert np.max(np.abs(r.gradient.sum(axis=1))) < 1e-7
+
+
+def test_kohn_sham_gradient_matches_finite_differences():
+    """Central differences of the engine's own B3LYP energy (the grid moves with the atoms, so the differences carry the
+    full grid response) on a bent, asymmetric water."""
+    xyz = np.array([[0.03, -0.02, -0.13], [0.10, 1.45, 1.05], [-0.05, -1.38, 1.12]])
+    st = methods.ScfSettings(basis_set="cc-pvdz", functional="b3lyp", energy_tol=1e-12, density_tol=1e-10, guess="gwh", max_iter=200)
+    r = methods.HFMethod(st).calc_gradient(fragment_bohr([8, 1, 1], xyz))
+    assert not r.has_error, r.error_message
+    h = 2e-3
+    frags = []
+    for a in range(3):
+        for c in range(3):
+            for sgn in (+1, -1):
+                x = xyz.copy(); x[a, c] += sgn * h
+                frags.append(fragment_bohr([8, 1, 1], x))
+    e = [q.energy.scf for q in methods.run_hip_scf_batch(st, frags)]
+    fd = np.zeros((3, 3))
+    k = 0
+    for a in range(3):
+        for c in range(3):
+            fd[c, a] = (e[k] - e[k + 1]) / (2 * h); k += 2
+    assert np.max(np.abs(r.gradient - fd)) < 5e-6, (np.max(np.abs(r.gradient - fd)), r.gradient, fd)
+
+
 def test_gradient_matches_finite_differences_of_the_oracle_energy():
     """check_gradient's procedure (validation/check_gradient.f90: central differences, bound 3.5e-8 Eh/a0) with the
     oracle as the energy function: a bent, asymmetric water in cc-pVDZ (d shells, every class of the gradient kernel)."""
