@@ -252,3 +252,28 @@ def test_mbe2_water_dimer_gradient_golden():
     ref = np.array(case["expected_gradient"])
     assert run.gradient is not None and run.gradient.shape == ref.shape
     assert np.max(np.abs(run.gradient - ref)) < case["gradient_tolerance"], np.max(np.abs(run.gradient - ref))
+
+
+# ---- GMBE caller mirror ---------------------------------------------------------------------------------------------
+def test_gmbe_over_overlapping_water_fragments():
+    """GMBE(1) over two overlapping base fragments of a water trimer, E = E(w0 w1) + E(w1 w2) - E(w1), against the
+    three SCFs run one by one; GMBE(2) over NON-overlapping monomers reproduces the MBE(2) total and gradient."""
+    from metalquicha_amd import gmbe
+    rng = np.random.default_rng(5)
+    ws = [water_at(rng, c) for c in ([0, 0, 0], [5.4, 0.3, 0.1], [10.9, -0.2, 0.4])]
+    xyz = np.vstack(ws)
+    z = np.array([8, 1, 1] * 3, dtype=np.int32)
+    st = methods.ScfSettings(basis_set="cc-pvdz", energy_tol=1e-10, density_tol=1e-8, guess="gwh")
+    ov = mbe.FragmentedSystem(z, xyz.T.copy(), [np.arange(0, 6), np.arange(3, 9)])
+    run = gmbe.run_gmbe(ov, st, level=1)
+    assert not run.errors, run.errors
+    assert sorted(zip(map(len, run.atom_sets), run.coefficients.tolist())) == [(3, -1), (6, 1), (6, 1)]
+    e = [methods.run_hip_scf(st, fragment_bohr(z[a], xyz[a])).energy.scf for a in (slice(0, 6), slice(3, 9), slice(3, 6))]
+    assert abs(run.total - (e[0] + e[1] - e[2])) < 1e-9
+    plain = mbe.FragmentedSystem(z, xyz.T.copy(), [np.arange(0, 3), np.arange(3, 6), np.arange(6, 9)])
+    g2 = gmbe.run_gmbe(plain, st, level=2, want_gradient=True)
+    m2 = mbe.run_mbe(plain, st, level=2, want_gradient=True)
+    total, _, _ = mbe.compute_mbe(m2.terms, m2.energies)
+    assert not g2.errors and abs(g2.total - total) < 1e-9
+    assert np.max(np.abs(g2.gradient - m2.gradient)) < 1e-9
+

@@ -298,3 +298,43 @@ def test_result_record_view_matches_the_ctypes_struct():
     rec = np.frombuffer(arr, dtype=dt)
     assert rec["e_total"][1] == -1.5 and rec["iterations"][1] == 7
     assert rec["has_error"][2] == 1 and bytes(rec["message"][2]).split(b"\0", 1)[0] == b"boom"
+
+
+# ---- GMBE caller mirror (src/fragmentation/gmbe/mqc_gmbe_utils.f90) ----------------------------------------------
+def test_gmbe_pie_terms_reduce_to_mbe_and_count_every_atom_once():
+    from metalquicha_amd import gmbe
+    # non-overlapping monomers, level 2: dimers +1, monomers -(M - 2): the MBE(2) formula
+    mono = [(0, 1, 2), (3, 4, 5), (6, 7, 8), (9, 10, 11)]
+    prim = [tuple(sorted(mono[i] + mono[j])) for i in range(4) for j in range(i + 1, 4)]
+    sets, coef = gmbe.enumerate_pie_terms(prim)
+    table = dict(zip(sets, coef))
+    assert all(table[p] == 1 for p in prim)
+    assert all(table[m] == -2 for m in mono)
+    assert len([c for c in coef if c != 0]) == 10
+    # an overlapping chain at level 1
+    sets, coef = gmbe.enumerate_pie_terms([(0, 1, 2, 3, 4, 5), (3, 4, 5, 6, 7, 8)])
+    assert dict(zip(sets, coef)) == {(0, 1, 2, 3, 4, 5): 1, (3, 4, 5, 6, 7, 8): 1, (3, 4, 5): -1}
+    # inclusion-exclusion: every atom of the union is counted exactly once, whatever the overlaps
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        prim = [tuple(sorted(rng.choice(12, size=rng.integers(2, 7), replace=False).tolist())) for _ in range(rng.integers(2, 7))]
+        prim = list(dict.fromkeys(prim))
+        sets, coef = gmbe.enumerate_pie_terms(prim)
+        union = set(a for p_ in prim for a in p_)
+        for a in union:
+            assert sum(int(c) for s_, c in zip(sets, coef) if a in s_) == 1
+    # depth limit: pairs only
+    sets, coef = gmbe.enumerate_pie_terms([(0, 1), (0, 2), (0, 3)], max_k_level=2)
+    assert dict(zip(sets, coef))[(0,)] == -3
+
+
+def test_gmbe_primaries_and_polymer_atoms():
+    from metalquicha_amd import gmbe, mbe
+    system = mbe.water_cluster(2)
+    assert gmbe.generate_primaries(system, 1) == [(i,) for i in range(8)]
+    assert len(gmbe.generate_primaries(system, 2)) == 28
+    assert len(gmbe.generate_primaries(system, 2, {2: 4.0})) < 28
+    # overlapping base fragments: shared atoms appear once
+    ov = mbe.FragmentedSystem(system.element_numbers, system.coordinates, [np.arange(0, 6), np.arange(3, 9)])
+    assert gmbe.polymer_atoms(ov, (0, 1)) == tuple(range(9))
+
