@@ -235,7 +235,11 @@ static int validate_options(const mqc_hip_scf_options_t& o, const Topology& topo
         if (nb < 0 || na < 0) { msg = "UHF: multiplicity asks for more unpaired electrons than the system has"; return MQC_HIP_ERR_VALIDATION; }
         if (na < 1) { msg = "UHF: no electrons to place"; return MQC_HIP_ERR_VALIDATION; }
         if (o.density_fitting) { msg = "UHF with density fitting is not available (the CPU reference refuses it too, mqc_libcint_bridge.f90:605-612)"; return MQC_HIP_ERR_UNSUPPORTED; }
-        if (o.eri_mode == MQC_HIP_ERI_DIRECT || !incore_supported(topo.nao)) { msg = "UHF runs on the in-core exact-ERI path (n_ao <= 116)"; return MQC_HIP_ERR_UNSUPPORTED; }
+        {
+            XcSpec tu; std::string eu;
+            parse_functional(o.functional, tu, eu);
+            if (tu.ncomp > 0 && topo.nao > 140) { msg = "unrestricted Kohn-Sham is available up to n_ao = 140"; return MQC_HIP_ERR_UNSUPPORTED; }
+        }
     } else if (topo.nelec < 2) { msg = "RHF: no electrons to place"; return MQC_HIP_ERR_VALIDATION; }
     if (o.guess < MQC_HIP_GUESS_AUTO || o.guess > MQC_HIP_GUESS_SAC) { msg = "unknown initial guess"; return MQC_HIP_ERR_VALIDATION; }
     if (o.guess == MQC_HIP_GUESS_SAC && uhf) { msg = "the SAC guess (free atoms' own spin densities) is available for restricted runs; unrestricted runs take sad, gwh or core"; return MQC_HIP_ERR_UNSUPPORTED; }
@@ -537,8 +541,15 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         while (remaining > 0 && guard < opts.max_iter + 2) {
             HIP_CHECK_RET(hipEventRecord(sl.e0, s));
             if (use_df) launch_df_jk(bv, true, s);
-            else if (use_direct) launch_jk_direct(bv, topo, direct_tol, true, s);
-            else {
+            else if (use_direct) {
+                launch_jk_direct(bv, topo, direct_tol, true, s);
+                if (uhf) {
+                    // the integrals are formed again for the beta density: J[D_b], K[D_b] (twice the direct work)
+                    BatchView vb = bv;
+                    vb.D = bv.Db; vb.J = bv.Jb; vb.K = bv.Kb;
+                    launch_jk_direct(vb, topo, direct_tol, true, s);
+                }
+            } else {
                 launch_jk_incore(bv, true, s);
                 if (uhf) {
                     // the same stream over the tensor with the beta density: J[D_b], K[D_b]

@@ -1527,7 +1527,8 @@ void launch_xc(const BatchView& bv, bool only_active, hipStream_t s)
         const int nv = (n * n + XC_NT - 1) / XC_NT;
         if (nv <= 10) { if (gga) xc_uks_launch<true, 16, 10>(bv, oa, s); else xc_uks_launch<false, 16, 10>(bv, oa, s); }
         else if (nv <= 29) { if (gga) xc_uks_launch<true, 16, 29>(bv, oa, s); else xc_uks_launch<false, 16, 29>(bv, oa, s); }
-        else { if (gga) xc_uks_launch<true, 16, 54>(bv, oa, s); else xc_uks_launch<false, 16, 54>(bv, oa, s); }
+        else if (nv <= 54) { if (gga) xc_uks_launch<true, 16, 54>(bv, oa, s); else xc_uks_launch<false, 16, 54>(bv, oa, s); }
+        else { if (gga) xc_uks_launch<true, 16, 77>(bv, oa, s); else xc_uks_launch<false, 16, 77>(bv, oa, s); }      // n <= 140
         return;
     }
     static const bool probed = [] {

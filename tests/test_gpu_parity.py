@@ -267,6 +267,21 @@ def test_manifest_uks_goldens(case):
     assert abs(r.s_squared - o.s_squared) < 1e-6
 
 
+def test_unrestricted_runs_on_the_direct_path():
+    """UHF and UKS with the integrals formed on the fly (eri_mode = direct: what fragments above 116 functions take), the
+    integrals formed once per spin density: the manifest's OH UHF and CH3 UKS-PBE energies to 1e-9."""
+    oh = [c for c in _uhf_cases() if c["basis"] == "cc-pvdz" and c["symbols"] == ["O", "H"]][0]
+    ch3 = [c for c in _uks_cases() if c["symbols"][0] == "C" and c["functional"] == "pbe"][0]
+    for case in (oh, ch3):
+        z = [SYMBOL_TO_Z[s_.lower()] for s_ in case["symbols"]]
+        frag = fragment_bohr(z, np.array(case["xyz_angstrom"]) * ANGSTROM_TO_BOHR, multiplicity=case["multiplicity"])
+        st = methods.ScfSettings(basis_set=case["basis"], functional=case["functional"], eri_mode="direct", energy_tol=1e-10,
+                                 density_tol=1e-7, guess="gwh", max_iter=case["maxiter"])
+        r = methods.run_hip_scf(st, frag)
+        assert not r.has_error, r.error_message
+        assert abs(r.energy.scf - case["expected_energy"]) < 1e-9, (case["name"], r.energy.scf)
+
+
 def test_uks_closed_shell_limit_and_batch():
     """A closed-shell molecule run unrestricted lands on the restricted Kohn-Sham energy (the reference's own guard
     against a wrong spin stride, mqc_libcint_xc.F90:944-946); a batch of OH radicals in one call against the oracle."""
