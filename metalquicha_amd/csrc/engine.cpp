@@ -22,6 +22,7 @@ const std::string& last_error_string();
 void eri_plan_lists(const BatchView& bv, const Topology& topo, hipStream_t s, const double* host_xyz);   // kern_eri.hip
 bool launch_gradient(const BatchView& bv, const Topology& topo, double* d_grad, double* work, int* d_lists, size_t list_capacity_ints,
                      hipStream_t s, std::string& err);                                                      // kern_grad.hip
+void launch_jk_direct_incremental(const BatchView& bv, const Topology& topo, double thresh, bool only_active, hipStream_t s);   // kern_eri.hip
 static DevicePool g_grad_pool[2];
 
 static int stage_check(const char* stage)
@@ -542,7 +543,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
             HIP_CHECK_RET(hipEventRecord(sl.e0, s));
             if (use_df) launch_df_jk(bv, true, s);
             else if (use_direct) {
-                launch_jk_direct(bv, topo, direct_tol, true, s);
+                launch_jk_direct_incremental(bv, topo, direct_tol, true, s);        // restricted: G_ref += G(D - D_ref)
                 if (uhf) {
                     // the integrals are formed again for the beta density: J[D_b], K[D_b] (twice the direct work)
                     BatchView vb = bv;
