@@ -127,7 +127,13 @@ class CalculationResult:
     orbital_energies_beta: Optional[np.ndarray] = None
     n_alpha: int = 0
     n_beta: int = 0
+    hessian: Optional[np.ndarray] = None               # (3 n_atoms, 3 n_atoms) Hartree/Bohr^2, atom-major like result%hessian
+    has_hessian: bool = False
+    dipole_derivatives: Optional[np.ndarray] = None    # (3, 3 n_atoms) d mu / d R
+    has_dipole_derivatives: bool = False
 
+
+DEFAULT_DISPLACEMENT = 0.005         # Bohr, src/core/mqc_calculation_defaults.f90:13
 
 _GUESS = {"auto": capi.GUESS_AUTO, "gwh": capi.GUESS_GWH, "core": capi.GUESS_CORE, "sad": capi.GUESS_SAD, "sac": capi.GUESS_SAC}
 
@@ -468,9 +474,48 @@ class HFMethod:
         return run_hip_scf(self.settings, fragment, result, want_gradient=True)
 
     def calc_hessian(self, fragment, result=None):
+        """hf_calc_hessian -> finite_difference_hessian (src/methods/mqc_method_hf.F90:228-257,
+        src/methods/mqc_semi_numerical_hessian.f90): central differences of analytic gradients at +-0.005 Bohr,
+        H[i, j] = (g_j(x_i + h) - g_j(x_i - h)) / 2h, symmetrised (finite_diff_hessian_from_gradients,
+        src/utils/mqc_finite_differences.f90); the dipoles of the same displacements give d mu / d R; the undisplaced
+        point supplies energy, gradient and dipole.  The reference walks the 6 N + 1 geometries one SCF at a time; here
+        they are ONE batch of the engine (one topology group)."""
+        h = DEFAULT_DISPLACEMENT
+        na = len(fragment.element_numbers)
+        base = np.asarray(fragment.coordinates, dtype=float)              # (3, n_atoms)
+        coords = [base.T.copy()]
+        for a in range(na):
+            for c in range(3):
+                for sgn in (+1.0, -1.0):
+                    x = base.T.copy(); x[a, c] += sgn * h
+                    coords.append(x)
+        m = len(coords)
+        group = FragmentGroup(fragment.element_numbers, np.stack(coords), np.full(m, fragment.charge, dtype=np.int32),
+                              np.full(m, fragment.multiplicity, dtype=np.int32), fragment.ghost, np.full(m, fragment.nelec, dtype=np.int32))
+        grads: list = []
+        rec = run_hip_scf_groups(self.settings, [group], want_gradient=True, gradients_out=grads)[0]
         r = result or CalculationResult()
-        r.has_error = True
-        r.error_message = "Hessians are not available in this build of the HIP backend"
+        bad = [k for k in range(m) if rec["has_error"][k] or not rec["has_gradient"][k]]
+        if bad:
+            k = bad[0]
+            r.has_error = True
+            r.error_message = ("Hessian: the gradient at displaced geometry %d failed: " % k) + \
+                bytes(rec["message"][k]).split(b"\0", 1)[0].decode(errors="replace")
+            return r
+        _fill_record(r, rec[0])
+        g = grads[0]                                                        # (m, n_atoms, 3)
+        r.gradient = g[0].T.copy(); r.has_gradient = True
+        hess = np.zeros((3 * na, 3 * na))
+        dmu = np.zeros((3, 3 * na))
+        have_dip = all(bool(rec["has_dipole"][k]) for k in range(m))
+        for i in range(3 * na):
+            fwd, bwd = 1 + 2 * i, 2 + 2 * i
+            hess[i, :] = (g[fwd] - g[bwd]).reshape(-1) / (2.0 * h)
+            if have_dip:
+                dmu[:, i] = (np.array(rec["dipole"][fwd]) - np.array(rec["dipole"][bwd])) / (2.0 * h)
+        r.hessian = 0.5 * (hess + hess.T); r.has_hessian = True
+        if have_dip:
+            r.dipole_derivatives = dmu; r.has_dipole_derivatives = True
         return r
 
 

@@ -277,3 +277,28 @@ def test_gmbe_over_overlapping_water_fragments():
     assert not g2.errors and abs(g2.total - total) < 1e-9
     assert np.max(np.abs(g2.gradient - m2.gradient)) < 1e-9
 
+
+def test_finite_difference_hessian_through_one_batch():
+    """calc_hessian = the reference's finite_difference_hessian (central differences of analytic gradients, 0.005 Bohr,
+    symmetrised) with the 6 N + 1 geometries as one engine batch: symmetric, translationally invariant, six zero modes,
+    and its projection on an arbitrary displacement equals the second difference of the ORACLE's energy."""
+    xyz = np.array([[0.02, -0.01, -0.13], [0.05, 1.44, 1.06], [-0.03, -1.40, 1.10]])
+    frag = fragment_bohr([8, 1, 1], xyz)
+    st = methods.ScfSettings(basis_set="sto-3g", energy_tol=1e-12, density_tol=1e-10, guess="gwh", max_iter=200)
+    r = methods.HFMethod(st).calc_hessian(frag)
+    assert not r.has_error, r.error_message
+    assert r.has_hessian and r.hessian.shape == (9, 9) and r.has_gradient and r.has_energy and r.has_dipole_derivatives
+    H = r.hessian
+    assert np.max(np.abs(H - H.T)) == 0.0
+    assert np.max(np.abs(H.reshape(9, 3, 3).sum(axis=1))) < 2e-5            # sum over atoms B of H[., B] = 0
+    w = np.linalg.eigvalsh(H)
+    assert np.sum(np.abs(w) < 1e-10) == 3 and np.sum(np.abs(w) < 1e-2) == 6 and np.sum(w > 0.05) == 3           # translations + rotations (non-stationary point: small), 3 vibrations
+    rng = np.random.default_rng(2)
+    d = rng.normal(size=(3, 3)); d /= np.linalg.norm(d)
+    h = 0.01
+    e = [so.run_rhf(oracle_mol("sto-3g", fragment_bohr([8, 1, 1], xyz + s_ * h * d)), 10, 200, 1e-12, 1e-10).energy for s_ in (+1, 0, -1)]
+    second = (e[0] - 2 * e[1] + e[2]) / h ** 2
+    assert abs(d.reshape(-1) @ H @ d.reshape(-1) - second) < 2e-4, (d.reshape(-1) @ H @ d.reshape(-1), second)
+    # the charge sum rule of the dipole derivatives: sum over atoms of d mu_k / d R_A,k' = charge * delta = 0
+    assert np.max(np.abs(r.dipole_derivatives.reshape(3, 3, 3).sum(axis=1))) < 1e-4
+
