@@ -250,7 +250,7 @@ void launch_diis_coeff(int n_stored, const double* d_overlap, double* d_coef, in
 void launch_becke_weights(const BatchView& bv, hipStream_t s);
 void launch_xc_radial_cache(const BatchView& bv, hipStream_t s);
 // points per tile of the quadrature kernel for n basis functions (kern_xc.hip) = granularity of the radial cache
-inline int xc_tile_points(int n) { return ((n + 15) / 16 <= 4) ? 32 : 16; }
+inline int xc_tile_points(int n) { return ((n + 15) / 16 <= 6) ? 32 : 16; }     // n <= 96: 32-point tiles (kern_xc.hip, xc_tile_dispatch)
 void launch_df_build(const BatchView& bv, const Topology& topo, const Topology& aux, hipStream_t s);
 void launch_df_jk(const BatchView& bv, bool only_active, hipStream_t s);
 void launch_xc(const BatchView& bv, bool only_active, hipStream_t s);

@@ -1343,6 +1343,15 @@ static bool xc_tile_dispatch(const BatchView& bv, int oa, hipStream_t s)
         else xc_tile_launch<GGA, 32, 4, 2, true, 4>(bv, oa, s);
         return true;
     }
+    // 64 < n <= 96 (def2-TZVP water dimer, n = 86): still 32-point tiles with the density fragments in registers, ONE
+    // workgroup per CU (101 KB of slab) and the whole register file for its four waves -- against 16-point tiles the
+    // functional runs on twice the lanes and the density is not re-read from L2 per tile (MQC_HIP_XC_WIDE_TILE=0: off)
+    static const bool wide_tile = [] { const char* e = std::getenv("MQC_HIP_XC_WIDE_TILE"); return !(e && e[0] == '0'); }();
+    if (wide_tile && nt <= 6) {
+        if (nt == 5) xc_tile_launch<GGA, 32, 7, 1, true, 5>(bv, oa, s);
+        else xc_tile_launch<GGA, 32, 9, 1, true, 6>(bv, oa, s);
+        return true;
+    }
     if (jobs <= 9) xc_tile_launch<GGA, 16, 9, 1, false, 0>(bv, oa, s);             // n <= 96
     else if (jobs <= 16) xc_tile_launch<GGA, 16, 16, 1, false, 0>(bv, oa, s);      // n <= 128
     else if (jobs <= 21) xc_tile_launch<GGA, 16, 21, 1, false, 0>(bv, oa, s);      // n <= 144
