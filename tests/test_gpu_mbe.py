@@ -14,7 +14,7 @@ from metalquicha_amd import mbe, methods
 from metalquicha_amd.basis import ANGSTROM_TO_BOHR, SYMBOL_TO_Z
 from oracle import scf_oracle as so
 from oracle import xc_oracle
-from tests.helpers import fragment_bohr, oracle_mol, water_at
+from tests.helpers import fragment_bohr, oracle_mol, water_at, recorded_oracle, scf_record
 
 pytestmark = pytest.mark.gpu
 
@@ -116,11 +116,13 @@ def test_benzene_b3lyp_ccpvdz_df_matches_oracle():
     r = methods.run_hip_scf(st, frag)
     assert not r.has_error, r.error_message
     assert r.scf_status == methods.SCF_CONVERGED
-    mol = oracle_mol("cc-pvdz", frag); aux = oracle_mol(AUX, frag)
-    assert mol.nao == 114
-    o = so.run_rhf(mol, 42, 100, 1e-10, 1e-8, aux=aux, xc=xc_oracle.XCOracle(mol, "b3lyp", 3))
-    assert abs(r.energy.scf - o.energy) < 1e-8, (r.energy.scf, o.energy)
-    assert r.scf_iterations == o.iterations
+    def oracle():
+        mol = oracle_mol("cc-pvdz", frag); aux = oracle_mol(AUX, frag)
+        assert mol.nao == 114
+        return scf_record(so.run_rhf(mol, 42, 100, 1e-10, 1e-8, aux=aux, xc=xc_oracle.XCOracle(mol, "b3lyp", 3)))
+    o = recorded_oracle("benzene_b3lyp_df", frag, "cc-pvdz|b3lyp|df:%s|grid3|1e-10|1e-8|gwh" % AUX, oracle)      # ~75 s live
+    assert abs(r.energy.scf - o["energy"]) < 1e-8, (r.energy.scf, o["energy"])
+    assert r.scf_iterations == o["iterations"]
     assert -232.4 < r.energy.scf < -232.1          # B3LYP/cc-pVDZ benzene, literature -232.26
 
 

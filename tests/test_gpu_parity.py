@@ -15,7 +15,7 @@ from metalquicha_amd.basis import ANGSTROM_TO_BOHR, SYMBOL_TO_Z
 from tests import stages
 from oracle import scf_oracle as so
 from oracle import xc_oracle
-from tests.helpers import fragment_bohr, oracle_mol, water_at, synthetic_density
+from tests.helpers import fragment_bohr, oracle_mol, water_at, synthetic_density, recorded_oracle, scf_record
 
 pytestmark = pytest.mark.gpu
 
@@ -187,11 +187,12 @@ def test_def2_tzvp_water_dimer_batch_matches_oracle():
         res = methods.run_hip_scf_batch(st, frags)
         for f, r in zip(frags[1:], res[1:]):
             assert not r.has_error, r.error_message
-            mol = oracle_mol("def2-tzvp", f)
-            xc = xc_oracle.XCOracle(mol, fn, 3) if fn else None
-            o = so.run_rhf(mol, int(f.nelec), 100, 1e-9, 1e-7, xc=xc)
-            assert abs(r.energy.scf - o.energy) < 1e-8, (fn, r.energy.scf, o.energy)
-            assert r.scf_iterations == o.iterations
+            def oracle(f=f, fn=fn):
+                mol = oracle_mol("def2-tzvp", f)
+                return scf_record(so.run_rhf(mol, int(f.nelec), 100, 1e-9, 1e-7, xc=xc_oracle.XCOracle(mol, fn, 3) if fn else None))
+            o = recorded_oracle("def2tzvp_water", f, "def2-tzvp|%s|grid3|1e-9|1e-7|gwh" % fn, oracle)
+            assert abs(r.energy.scf - o["energy"]) < 1e-8, (fn, r.energy.scf, o["energy"])
+            assert r.scf_iterations == o["iterations"]
 
 
 # ---- unrestricted Hartree-Fock ---------------------------------------------------------------------------------
@@ -303,10 +304,12 @@ def test_uks_closed_shell_limit_and_batch():
     st = methods.ScfSettings(basis_set="cc-pvdz", functional="pbe", energy_tol=1e-10, density_tol=1e-8, guess="gwh")
     for f, r in zip(frags, methods.run_hip_scf_batch(st, frags)):
         assert not r.has_error, r.error_message
-        mol = oracle_mol("cc-pvdz", f)
-        o = so.run_uhf(mol, 9, 2, 100, 1e-10, 1e-8, xc=xc_oracle.XCOracle(mol, "pbe", 3))
-        assert abs(r.energy.scf - o.energy) < 1e-8, (r.energy.scf, o.energy)
-        assert r.scf_iterations == o.iterations
+        def oracle(f=f):
+            mol = oracle_mol("cc-pvdz", f)
+            return scf_record(so.run_uhf(mol, 9, 2, 100, 1e-10, 1e-8, xc=xc_oracle.XCOracle(mol, "pbe", 3)))
+        o = recorded_oracle("uks_pbe_methyl_batch", f, "cc-pvdz|pbe|uks|grid3|1e-10|1e-8|gwh", oracle)
+        assert abs(r.energy.scf - o["energy"]) < 1e-8, (r.energy.scf, o["energy"])
+        assert r.scf_iterations == o["iterations"]
 
 
 # ---- superposed-atom guesses ------------------------------------------------------------------------------------
@@ -369,15 +372,21 @@ def test_fragments_above_140_functions_run_from_global_memory():
     frag = fragment_bohr([8, 1, 1] * 21, np.vstack(xs))
     mol = oracle_mol("sto-3g", frag)
     assert mol.nao == 147
-    eri = so.eri4(mol)
+    eri_box = []
+
+    def oracle(fn):
+        if not eri_box:
+            eri_box.append(so.eri4(mol))
+        xc = xc_oracle.XCOracle(mol, fn, 1) if fn else None       # the coarsest grid: the oracle's quadrature sets the time
+        return scf_record(so.run_rhf(mol, int(frag.nelec), 100, 1e-9, 1e-7, xc=xc, eri=eri_box[0]))
+
     for fn in ("", "b3lyp"):
         st = methods.ScfSettings(basis_set="sto-3g", functional=fn, grid_level=1, energy_tol=1e-9, density_tol=1e-7, guess="gwh")
         r = methods.run_hip_scf(st, frag)
         assert not r.has_error, r.error_message
-        xc = xc_oracle.XCOracle(mol, fn, 1) if fn else None       # the coarsest grid: the oracle's quadrature sets this test's time
-        o = so.run_rhf(mol, int(frag.nelec), 100, 1e-9, 1e-7, xc=xc, eri=eri)
-        assert abs(r.energy.scf - o.energy) < 2e-8, (fn, r.energy.scf, o.energy)
-        assert r.scf_iterations == o.iterations
+        o = recorded_oracle("h2o21_sto3g", frag, "sto-3g|%s|grid1|1e-9|1e-7|gwh" % fn, lambda: oracle(fn))      # ~2 min live
+        assert abs(r.energy.scf - o["energy"]) < 2e-8, (fn, r.energy.scf, o["energy"])
+        assert r.scf_iterations == o["iterations"]
     r = methods.run_hip_scf(methods.ScfSettings(basis_set="sto-3g", density_fitting=True, aux_basis_set="mqc-even-tempered-jkfit"), frag)
     assert r.has_error and "140" in r.error_message
 
@@ -480,9 +489,11 @@ def test_b3lyp_water_dimer_batch_matches_oracle():
     res = methods.run_hip_scf_batch(st, frags)
     for f, r in zip(frags, res):
         assert not r.has_error, r.error_message
-        mol = oracle_mol("cc-pvdz", f)
-        o = so.run_rhf(mol, int(f.nelec), 100, 1e-9, 1e-7, xc=xc_oracle.XCOracle(mol, "b3lyp", 3))
-        assert abs(r.energy.scf - o.energy) < 1e-8, (r.energy.scf, o.energy)
+        def oracle(f=f):
+            mol = oracle_mol("cc-pvdz", f)
+            return scf_record(so.run_rhf(mol, int(f.nelec), 100, 1e-9, 1e-7, xc=xc_oracle.XCOracle(mol, "b3lyp", 3)))
+        o = recorded_oracle("b3lyp_water_batch", f, "cc-pvdz|b3lyp|grid3|1e-9|1e-7|gwh", oracle)
+        assert abs(r.energy.scf - o["energy"]) < 1e-8, (r.energy.scf, o["energy"])
 
 
 _XC_CHILD = r"""
@@ -562,8 +573,9 @@ def test_df_b3lyp_batch_matches_oracle():
     res = methods.run_hip_scf_batch(st, frags)
     for f, r in zip(frags, res):
         assert not r.has_error, r.error_message
-        o = _oracle_df(f, "cc-pvdz", "b3lyp")
-        assert abs(r.energy.scf - o.energy) < 1e-8, (r.energy.scf, o.energy)
+        o = recorded_oracle("df_b3lyp_water_batch", f, "cc-pvdz|b3lyp|df:%s|grid3|1e-9|1e-7|gwh" % AUX,
+                            lambda f=f: scf_record(_oracle_df(f, "cc-pvdz", "b3lyp")))
+        assert abs(r.energy.scf - o["energy"]) < 1e-8, (r.energy.scf, o["energy"])
 
 
 def test_df_rhf_with_the_orbital_basis_as_auxiliary_basis_matches_pinned_oracle():
