@@ -405,8 +405,40 @@ __device__ __forceinline__ void emit_shell(int l, int ao, double dx, double dy, 
             gx[(ao + 1) * ptp + p] = dy * dx * drad; gy[(ao + 1) * ptp + p] = rad + dy * dy * drad; gz[(ao + 1) * ptp + p] = dy * dz * drad;
             gx[(ao + 2) * ptp + p] = dz * dx * drad; gy[(ao + 2) * ptp + p] = dz * dy * drad; gz[(ao + 2) * ptp + p] = rad + dz * dz * drad;
         }
-    } else if (LF && l >= 3) {
-        // l = 3, 4: Cartesian monomials x^a y^b z^c in libcint order, transformed with the packed c2s table
+    } else if (LF && l == 3) {
+        // f shell, the seven real solid harmonics written out: value and gradient of the ten cubic monomials (libcint
+        // order xxx, xxy, xxz, xyy, xyz, xzz, yyy, yyz, yzz, zzz), combined with the l = 3 rows of the c2s table
+        // (host_setup.cpp: build_c2s_tables; zeros drop out at compile time).  The table-driven loop below takes
+        // ~2 000 instructions and 70 global loads per item and was the longest part of a def2-TZVP slab.
+        constexpr double T3[7][10] = {
+            {0, 1.7701307697799307, 0, 0, 0, 0, -0.59004358992664352, 0, 0, 0},
+            {0, 0, 0, 0, 2.8906114426405543, 0, 0, 0, 0, 0},
+            {0, -0.45704579946446572, 0, 0, 0, 0, -0.45704579946446572, 0, 1.8281831978578629, 0},
+            {0, 0, -1.1195289977703462, 0, 0, 0, 0, -1.1195289977703462, 0, 0.7463526651802308},
+            {-0.45704579946446572, 0, 0, -0.45704579946446572, 0, 1.8281831978578629, 0, 0, 0, 0},
+            {0, 0, 1.4453057213202771, 0, 0, 0, 0, -1.4453057213202771, 0, 0},
+            {0.59004358992664352, 0, 0, -1.7701307697799307, 0, 0, 0, 0, 0, 0}};
+        const double x2 = dx * dx, y2 = dy * dy, z2 = dz * dz, xy = dx * dy, xz = dx * dz, yz = dy * dz;
+        const double cv[10] = {x2 * dx, x2 * dy, x2 * dz, dx * y2, xy * dz, dx * z2, y2 * dy, y2 * dz, dy * z2, z2 * dz};
+        const double cgx[10] = {3.0 * x2, 2.0 * xy, 2.0 * xz, y2, yz, z2, 0.0, 0.0, 0.0, 0.0};
+        const double cgy[10] = {0.0, x2, 0.0, 2.0 * xy, xz, 0.0, 3.0 * y2, 2.0 * yz, z2, 0.0};
+        const double cgz[10] = {0.0, 0.0, x2, 0.0, xy, 2.0 * xz, 0.0, y2, 2.0 * yz, 3.0 * z2};
+#pragma unroll
+        for (int m = 0; m < 7; ++m) {
+            double v = 0.0, ax = 0.0, ay = 0.0, az = 0.0;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                if (T3[m][k] != 0.0) { v += T3[m][k] * cv[k]; ax += T3[m][k] * cgx[k]; ay += T3[m][k] * cgy[k]; az += T3[m][k] * cgz[k]; }
+            }
+            chi[(ao + m) * ptp + p] = v * rad;
+            if (GGA) {
+                gx[(ao + m) * ptp + p] = ax * rad + v * dx * drad;
+                gy[(ao + m) * ptp + p] = ay * rad + v * dy * drad;
+                gz[(ao + m) * ptp + p] = az * rad + v * dz * drad;
+            }
+        }
+    } else if (LF && l >= 4) {
+        // l = 4: Cartesian monomials x^a y^b z^c in libcint order, transformed with the packed c2s table
         const int nc = ncart(l), nsp = nsph(l);
         auto ipow = [](double x, int k) { double r = 1.0; for (int i = 0; i < k; ++i) r *= x; return r; };   // k <= 4, no arrays (no scratch)
         const double* tab = c2s + c2s_table_offset(l);
@@ -949,8 +981,8 @@ __device__ unsigned long long g_xc_stamps[16];
 #define XC_ST(k)
 #endif
 
-template <bool GGA, int PT, int JMAX, int OCC, bool DREG, int NTC, bool FAST = false>
-__global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, int only_active)
+template <bool GGA, int PT, int JMAX, int OCC, bool DREG, int NTC, bool FAST = false, int NWV = XV_NW>
+__global__ void __launch_bounds__(64 * NWV, OCC) xc_tile_kernel(BatchView bv, int only_active)
 {
     // One tile = PT points: AO slab -> X = D chi, rho / grad rho -> functional (one lane per point) -> a -> A += a chi^T.
     // (XC_TWO_PASS builds a 256-point super-tile in two passes so that the functional runs at full width; timing probes
@@ -966,7 +998,7 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
     // components dealt to four waves -- made the kernel slower, twice).
     const bool rad_in_lds = FAST || (only_active & 2) != 0;   // bit 1 of the flag word: radial tile staged in LDS
     if ((only_active & 1) && bv.istate[4 * f] == ST_DONE) return;
-    constexpr int RS = PT + 1, PT16 = PT / 16, NTHR = 64 * XV_NW, SUPER = XC_TWO_PASS ? NTHR : PT, NSUB = SUPER / PT;
+    constexpr int RS = PT + 1, PT16 = PT / 16, NTHR = 64 * NWV, SUPER = XC_TWO_PASS ? NTHR : PT, NSUB = SUPER / PT;
     const int n = bv.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lo = lane & 15, hi = lane >> 4;
     // NTC > 0: the number of 16-function tiles is a template constant (n <= 64), so that every k-loop and tile test
@@ -1036,7 +1068,7 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
     auto stage_radial = [&](int tile) {
         if (!rad_in_lds || tile * PT >= gd.npts) return;
         const char* src = (const char*)(radf + (size_t)tile * tp.nshell * 2 * PT);
-        for (int c = wave; c * 1024 < rad_bytes; c += XV_NW) {
+        for (int c = wave; c * 1024 < rad_bytes; c += NWV) {
             const int off = c * 1024 + lane * 16;
             if (off < rad_bytes)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off),
@@ -1049,12 +1081,12 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
     // keeps its density fragments in registers for the whole kernel -- reading them from L2 per tile made the phase a
     // chain of load latencies (probes: 30 % of the kernel for 10 % of its MFMA work)
     static_assert(!DREG || NTC > 0, "register-resident density fragments need a compile-time tile count");
-    constexpr int DJ = DREG ? (NTC * PT16 + XV_NW - 1) / XV_NW : 1, DK = DREG ? 4 * NTC : 1;      // X jobs per wave, k-steps per job
+    constexpr int DJ = DREG ? (NTC * PT16 + NWV - 1) / NWV : 1, DK = DREG ? 4 * NTC : 1;      // X jobs per wave, k-steps per job
     double dfrag[DJ][DK];
     if (DREG) {
 #pragma unroll
         for (int j = 0; j < DJ; ++j) {
-            const int job = wave + XV_NW * j;
+            const int job = wave + NWV * j;
             const int mt = job / PT16;
 #pragma unroll
             for (int ks = 0; ks < DK; ++ks) {
@@ -1071,9 +1103,9 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
     XC_ST_DECL
 
     const int probe = g_xc_probe;
-    // n > 144: the 16 x 16 output tiles are dealt to blockIdx.z groups of XV_NW * JMAX (the slab, the densities and the
+    // n > 144: the 16 x 16 output tiles are dealt to blockIdx.z groups of NWV * JMAX (the slab, the densities and the
     // functional are formed in every group; the energy counts in group 0)
-    const int tz0 = (int)blockIdx.z * XV_NW * JMAX;
+    const int tz0 = (int)blockIdx.z * NWV * JMAX;
     auto ao_slab = [&](int g0) {
         if (probe & 1) return;
         if constexpr (FAST) {
@@ -1132,7 +1164,7 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
             // X = D chi, job = (row tile mt, point tile pt); rho and grad rho from the accumulator rows
 #pragma unroll 2
             for (int jj = 0; jj < (DREG ? DJ : 64); ++jj) {       // DREG: DJ <= 2, unrolled
-                const int job = wave + XV_NW * jj;
+                const int job = wave + NWV * jj;
                 if (job >= NT16 * PT16 || (probe & 2)) break;
                 const int mt = job / PT16, pt = job - mt * PT16;
                 v4f64 xacc = (v4f64){0.0, 0.0, 0.0, 0.0};
@@ -1190,7 +1222,7 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
         // a fixed wave the functional phases of a CU's workgroups all queued on one SIMD while three idled.  (Dealing
         // the functional's components to the four waves was measured slower: 1.39 s against 1.30 s per evaluation.)
         if (!XC_TWO_PASS) {
-            if (wave == ((iter + (int)blockIdx.x) & (XV_NW - 1)) && lane < PT) {
+            if (wave == ((iter + (int)blockIdx.x) & (NWV - 1)) && lane < PT) {
                 const int p = lane;
                 double* rp = red + 4 * p;
                 const double rho = rp[0], rx = 2.0 * rp[1], ry = 2.0 * rp[2], rz = 2.0 * rp[3];
@@ -1250,10 +1282,10 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
             XC_ST(6)
             __syncthreads();
             XC_ST(7)
-            // A += a chi^T: this wave's tiles t = wave, wave + XV_NW, ...
+            // A += a chi^T: this wave's tiles t = wave, wave + NWV, ...
 #pragma unroll
             for (int j = 0; j < JMAX; ++j) {
-                const int t = tz0 + wave + XV_NW * j;
+                const int t = tz0 + wave + NWV * j;
                 if (t < NT16 * NT16 && !(probe & 8)) {
                     const int mt = t / NT16, nt = t - mt * NT16;
                     const double* __restrict__ ar = gx + (size_t)(16 * mt + lo) * RS + hi;
@@ -1278,7 +1310,7 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
     double* Vx = bv.Vxc + (size_t)f * n * n;
 #pragma unroll
     for (int j = 0; j < JMAX; ++j) {
-        const int t = tz0 + wave + XV_NW * j;
+        const int t = tz0 + wave + NWV * j;
         if (t < NT16 * NT16) {
             const int mt = t / NT16, nt = t - mt * NT16;
 #pragma unroll
@@ -1298,14 +1330,14 @@ __global__ void __launch_bounds__(64 * XV_NW, OCC) xc_tile_kernel(BatchView bv, 
     }
 }
 
-template <bool GGA, int PT, int JMAX, int OCC, bool DREG, int NTC>
+template <bool GGA, int PT, int JMAX, int OCC, bool DREG, int NTC, int NWV = XV_NW>
 static void xc_tile_launch(const BatchView& bv, int oa, hipStream_t s)
 {
     const int np = ((bv.n + 15) / 16) * 16;
     // + radial-group tables: 2 doubles of descriptor per group, the exponents and up to XC_GROUP_MAX coefficient rows;
     // groups <= shells <= n, primitives per group <= 63 (descriptor field); bounded by the topology's own totals
     const size_t tab = 3 * (size_t)bv.topo.ngroup + (size_t)bv.topo.gprim_total + (size_t)bv.topo.gcoef_total + 8 + ((size_t)bv.topo.nshell + 1) / 2;
-    size_t lds = sizeof(double) * ((size_t)(GGA ? 4 : 2) * np * (PT + 1) + 8 * (XC_TWO_PASS ? 64 * XV_NW : PT) + 3 * 64 + 6 * PT + ((tab + 1) & ~(size_t)1));
+    size_t lds = sizeof(double) * ((size_t)(GGA ? 4 : 2) * np * (PT + 1) + 8 * (XC_TWO_PASS ? 64 * NWV : PT) + 3 * 64 + 6 * PT + ((tab + 1) & ~(size_t)1));
     // the radial tile rides in LDS when that does not cost a resident workgroup (OCC of them share 160 KB)
     const size_t rad_lds = sizeof(double) * (size_t)bv.topo.nshell * 2 * PT;
     static const bool rad_lds_on = [] { const char* e = std::getenv("MQC_HIP_XC_RADIAL_LDS"); return !(e && e[0] == '0'); }();
@@ -1314,20 +1346,20 @@ static void xc_tile_launch(const BatchView& bv, int oa, hipStream_t s)
         lds += rad_lds;
         oa |= 2;
     }
-    auto kern = xc_tile_kernel<GGA, PT, JMAX, OCC, DREG, NTC, false>;
+    auto kern = xc_tile_kernel<GGA, PT, JMAX, OCC, DREG, NTC, false, NWV>;
     if constexpr (DREG) {
         static const bool fast_on = [] { const char* e = std::getenv("MQC_HIP_XC_FAST_SLAB"); return !(e && e[0] == '0'); }();
-        if (fast_on && (oa & 2) && bv.topo.lmax <= 2) kern = xc_tile_kernel<GGA, PT, JMAX, OCC, DREG, NTC, true>;
+        if (fast_on && (oa & 2) && bv.topo.lmax <= 2) kern = xc_tile_kernel<GGA, PT, JMAX, OCC, DREG, NTC, true, NWV>;
     }
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int tile_pts = XC_TWO_PASS ? 64 * XV_NW : PT;
+    const int tile_pts = XC_TWO_PASS ? 64 * NWV : PT;
     const int ntiles = (bv.grid.npts + tile_pts - 1) / tile_pts;
     int gx = (6144 + bv.nfrag - 1) / bv.nfrag;       // ~3 workgroups per CU x 8 in flight over the batch; many tiles each
     if (gx > ntiles) gx = ntiles;
     if (gx < 1) gx = 1;
     const int nt16 = (bv.n + 15) / 16;
-    const int nz = (nt16 * nt16 + XV_NW * JMAX - 1) / (XV_NW * JMAX);
-    hipLaunchKernelGGL(kern, dim3(gx, bv.nfrag, nz), dim3(64 * XV_NW), lds, s, bv, oa);
+    const int nz = (nt16 * nt16 + NWV * JMAX - 1) / (NWV * JMAX);
+    hipLaunchKernelGGL(kern, dim3(gx, bv.nfrag, nz), dim3(64 * NWV), lds, s, bv, oa);
 }
 
 template <bool GGA>
@@ -1348,6 +1380,7 @@ static bool xc_tile_dispatch(const BatchView& bv, int oa, hipStream_t s)
     // functional runs on twice the lanes and the density is not re-read from L2 per tile (MQC_HIP_XC_WIDE_TILE=0: off)
     static const bool wide_tile = [] { const char* e = std::getenv("MQC_HIP_XC_WIDE_TILE"); return !(e && e[0] == '0'); }();
     if (wide_tile && nt <= 6) {
+        // (eight waves per workgroup -- half the accumulators per wave -- measured the same: 3.94 against 3.92 s)
         if (nt == 5) xc_tile_launch<GGA, 32, 7, 1, true, 5>(bv, oa, s);
         else xc_tile_launch<GGA, 32, 9, 1, true, 6>(bv, oa, s);
         return true;
