@@ -289,6 +289,127 @@ __global__ void __launch_bounds__(64 * NW) jk_incore_kernel(BatchView bv, int on
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Long rows (64 < n <= ~88: def2-TZVP water dimer, n = 86, rows of 30 KB): a wave-private row buffer per wave no longer
+// fits more than four waves per CU and the stream starves (32 KB in flight per CU, ~1 TB/s).  Here the WHOLE workgroup
+// (eight waves) owns one row at a time: every thread keeps its slice of the next three rows in flight in registers
+// (90 KB per CU), the current row sits in one of two LDS buffers, J is a block reduction, and the exchange mat-vecs
+// split the l range over the waves (blocks of eight l, wave w takes blocks w, w + 8, ...) with lane <-> k and LDS
+// atomics into the workgroup's K accumulator.  One barrier per row.
+constexpr int JKC_NW = 8, JKC_NT = 64 * JKC_NW;
+
+template <int KCH, int RPT>       // RPT = doubles per thread per row = ceil(np / 512)
+__global__ void __launch_bounds__(JKC_NT) jk_rowcoop_kernel(BatchView bv, int only_active)
+{
+    extern __shared__ double lds[];
+    const int f = blockIdx.y;
+    if ((only_active & 1) && bv.istate[4 * f] == ST_DONE) return;
+    const int n = bv.n, np = bv.npair;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NPAD = RPT * JKC_NT;
+    const double* __restrict__ Dg = bv.D + (size_t)f * n * n;
+    double* __restrict__ Jg = bv.J + (size_t)f * n * n;
+    double* __restrict__ Kg = bv.K + (size_t)f * n * n;
+    const double* __restrict__ M = bv.eri + (size_t)f * np * np;
+    double* rowbuf = lds;                       // [2][NPAD]
+    double* Dp = rowbuf + 2 * NPAD;             // packed (2 - delta) D, padded with zeros to NPAD
+    double* Kl = Dp + NPAD;                     // n * n
+    double* jred = Kl + (size_t)n * n;          // [2][JKC_NW]
+    for (int idx = tid; idx < NPAD; idx += JKC_NT) {
+        double d = 0.0;
+        if (idx < np) { int k, l; unpack_pair(idx, k, l); d = Dg[k * n + l]; if (k != l) d *= 2.0; }
+        Dp[idx] = d;
+    }
+    for (int idx = tid; idx < n * n; idx += JKC_NT) Kl[idx] = 0.0;
+    __syncthreads();
+    double dp[RPT];
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) dp[u] = Dp[tid + JKC_NT * u];
+
+    const int stride = gridDim.x;
+    int row = blockIdx.x;
+    double va[RPT], vb[RPT], vc[RPT];
+    auto load_row = [&](int r, double* v) {
+        const double* __restrict__ src = M + (size_t)r * np;
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) { const int idx = tid + JKC_NT * u; v[u] = (r < np && idx < np) ? src[idx] : 0.0; }
+    };
+    load_row(row, va);
+    load_row(row + stride, vb);
+    load_row(row + 2 * stride, vc);
+    int t = 0, prev_i = 0, prev_j = 0;
+    bool have_prev = false;
+    while (row < np) {
+        double* buf = rowbuf + (t & 1) * NPAD;
+        double accj = 0.0;
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) { buf[tid + JKC_NT * u] = va[u]; accj += va[u] * dp[u]; }
+        // rotate the register ring and put the row after next in flight
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) { va[u] = vb[u]; vb[u] = vc[u]; }
+        load_row(row + 3 * stride, vc);
+        accj = wave_sum(accj);
+        if (lane == 0) jred[(t & 1) * JKC_NW + wave] = accj;
+        __syncthreads();
+        int i, j;
+        unpack_pair(row, i, j);
+        if (tid == 0) {
+            // this row's J from the partial sums just published; the barrier above ordered them
+            double sj = 0.0;
+#pragma unroll
+            for (int w = 0; w < JKC_NW; ++w) sj += jred[(t & 1) * JKC_NW + w];
+            Jg[i * n + j] = sj; Jg[j * n + i] = sj;
+        }
+        (void)have_prev; (void)prev_i; (void)prev_j;
+        if (!(only_active & 2)) {
+            const int iu = __builtin_amdgcn_readfirstlane(i), ju = __builtin_amdgcn_readfirstlane(j);
+            const double* __restrict__ Di = Dg + (size_t)iu * n;
+            const double* __restrict__ Dj = Dg + (size_t)ju * n;
+            double acc_i[KCH], acc_j[KCH];
+            int kk[KCH], tri[KCH];
+#pragma unroll
+            for (int c = 0; c < KCH; ++c) {
+                acc_i[c] = 0.0; acc_j[c] = 0.0;
+                const int k = lane + 64 * c;
+                kk[c] = k < n ? k : n - 1;
+                tri[c] = kk[c] * (kk[c] + 1) / 2;
+            }
+            typedef const double __attribute__((address_space(4))) * scalar_ptr;
+            for (int l0 = 8 * wave; l0 < n; l0 += 8 * JKC_NW) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool live = l0 + u < n;                  // uniform
+                    const int l = live ? l0 + u : n - 1;
+                    const int lbase = l * (l + 1) / 2;
+                    const double dil = live ? ((scalar_ptr)Di)[l] : 0.0, djl = live ? ((scalar_ptr)Dj)[l] : 0.0;
+#pragma unroll
+                    for (int c = 0; c < KCH; ++c) {
+                        const double v = buf[kk[c] >= l ? tri[c] + l : lbase + kk[c]];
+                        acc_i[c] += v * djl;
+                        acc_j[c] += v * dil;
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < KCH; ++c) {
+                const int k = lane + 64 * c;
+                if (k < n) {
+                    atomicAdd(&Kl[i * n + k], acc_i[c]);
+                    if (i != j) atomicAdd(&Kl[j * n + k], acc_j[c]);
+                }
+            }
+        }
+        row += stride;
+        ++t;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < n * n; idx += JKC_NT) {
+        const double kv = Kl[idx];
+        if (kv != 0.0) atomicAdd(&Kg[idx], kv);
+    }
+}
+
 static int jk_grid_x(const BatchView& bv, int nw)
 {
     // enough workgroups to cover 256 CUs several times over, but few enough that the per-workgroup
@@ -307,6 +428,12 @@ static void jk_launch(const BatchView& bv, int oa, size_t lds, hipStream_t s)
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid(jk_grid_x(bv, NW), bv.nfrag), block(64 * NW);
     hipLaunchKernelGGL(kern, grid, block, lds, s, bv, oa);
+}
+
+static bool jk_rowcoop_on()
+{
+    static const bool on = [] { const char* e = std::getenv("MQC_HIP_JK_ROWCOOP"); return !(e && e[0] == '0'); }();
+    return on;
 }
 
 void launch_jk_incore(const BatchView& bv, bool only_active, hipStream_t s)
@@ -337,6 +464,15 @@ void launch_jk_incore(const BatchView& bv, bool only_active, hipStream_t s)
         else jk_launch<1, true, 4, 0, true>(bv, oa, lds_reg, s);
     } else if (lds4k <= LDS_MAX && kch <= 2) {
         jk_launch<2, true, 4, 0, false>(bv, oa, lds4k, s);
+    } else if (kch == 2 && np <= 8 * JKC_NT && sizeof(double) * ((size_t)3 * 8 * JKC_NT + (size_t)n * n + 2 * JKC_NW) <= LDS_MAX && jk_rowcoop_on()) {
+        // 64 < n <= 89: rows up to 32 KB, the workgroup-cooperative kernel
+        const size_t lds = sizeof(double) * ((size_t)3 * 8 * JKC_NT + (size_t)n * n + 2 * JKC_NW);
+        auto kern = jk_rowcoop_kernel<2, 8>;
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int gx = (2048 + bv.nfrag - 1) / bv.nfrag;
+        if (gx < 1) gx = 1;
+        if (gx > np) gx = np;
+        hipLaunchKernelGGL(kern, dim3(gx, bv.nfrag), dim3(JKC_NT), lds, s, bv, oa);
     } else if (lds4 <= LDS_MAX) {
         if (kch <= 2) jk_launch<2, false, 4, 0, false>(bv, oa, lds4, s);
         else if (kch == 3) jk_launch<3, false, 4, 0, false>(bv, oa, lds4, s);
