@@ -106,8 +106,8 @@ typedef struct {
     int32_t use_diis;
     int32_t diis_size;               /* default 8 */
     int32_t guess;                   /* MQC_HIP_GUESS_* */
-    int32_t unrestricted;            /* refused for now (MQC_HIP_ERR_UNSUPPORTED) */
-    int32_t want_gradient;           /* refused for now */
+    int32_t unrestricted;            /* force UHF / UKS (open shells take it by themselves, mqc_cuest_driver.f90:127) */
+    int32_t want_gradient;           /* analytic gradient into result->gradient: HF and Kohn-Sham, exact ERIs, s-d shells */
     int32_t allow_crap_scf;
     int32_t verbose;
     int32_t eri_mode;                /* MQC_HIP_ERI_* */
