@@ -65,13 +65,26 @@ __device__ __forceinline__ Dual operator*(double b, Dual a) { return {a.v * b, a
 __device__ __forceinline__ Dual operator/(Dual a, double b) { const double i = xc_rcp(b); return {a.v * i, a.r * i, a.s * i}; }
 __device__ __forceinline__ Dual operator/(double b, Dual a) { return mk(b) / a; }
 __device__ __forceinline__ Dual chain(Dual x, double f, double df) { return {f, df * x.r, df * x.s}; }
-__device__ __forceinline__ Dual dexp(Dual x) { const double f = exp(x.v); return chain(x, f, f); }
-__device__ __forceinline__ Dual dlog(Dual x) { return chain(x, log(x.v), xc_rcp(x.v)); }
+#if defined(XC_MATH_PROBE)      /* measurement only: single-precision transcendentals, wrong results */
+#define XC_EXP(x) ((double)__expf((float)(x)))
+#define XC_LOG(x) ((double)__logf((float)(x)))
+#define XC_ATAN(x) ((double)atanf((float)(x)))
+#define XC_ASINH(x) ((double)__logf((float)(x) + sqrtf((float)(x) * (float)(x) + 1.0f)))
+#define XC_CBRT(x) ((double)__powf((float)(x), 0.33333334f))
+#else
+#define XC_EXP(x) exp(x)
+#define XC_LOG(x) log(x)
+#define XC_ATAN(x) atan(x)
+#define XC_ASINH(x) asinh(x)
+#define XC_CBRT(x) cbrt(x)
+#endif
+__device__ __forceinline__ Dual dexp(Dual x) { const double f = XC_EXP(x.v); return chain(x, f, f); }
+__device__ __forceinline__ Dual dlog(Dual x) { return chain(x, XC_LOG(x.v), xc_rcp(x.v)); }
 __device__ __forceinline__ Dual dsqrt(Dual x) { const double i = xc_rsqrt(x.v); return chain(x, x.v * i, 0.5 * i); }
-__device__ __forceinline__ Dual datan(Dual x) { return chain(x, atan(x.v), xc_rcp(1.0 + x.v * x.v)); }
-__device__ __forceinline__ Dual dasinh(Dual x) { return chain(x, asinh(x.v), xc_rsqrt(1.0 + x.v * x.v)); }
+__device__ __forceinline__ Dual datan(Dual x) { return chain(x, XC_ATAN(x.v), xc_rcp(1.0 + x.v * x.v)); }
+__device__ __forceinline__ Dual dasinh(Dual x) { return chain(x, XC_ASINH(x.v), xc_rsqrt(1.0 + x.v * x.v)); }
 __device__ __forceinline__ Dual dpow(Dual x, double p) { const double f = pow(x.v, p); return chain(x, f, p * f / x.v); }
-__device__ __forceinline__ Dual dcbrt(Dual x) { const double f = cbrt(x.v); return chain(x, f, f * xc_rcp(3.0 * x.v)); }
+__device__ __forceinline__ Dual dcbrt(Dual x) { const double f = XC_CBRT(x.v); return chain(x, f, f * xc_rcp(3.0 * x.v)); }
 
 // ------------------------------------------------------------------ functionals: energy per volume
 __device__ __forceinline__ Dual f_lda_x(Dual rho, Dual r13)
