@@ -976,7 +976,6 @@ static void xc_mfma_launch(const BatchView& bv, int oa, hipStream_t s)
 // (lane = point on wave 0 while the other workgroups of the CU compute), and n up to 144 uses the matrix cores
 // (benzene/cc-pVDZ n = 114, def2-TZVP water dimer n = 86).  Same arithmetic as mqc_libcint_xc.F90:796-927.
 constexpr int XV_NW = 4;
-constexpr bool XC_TWO_PASS = false;
 // MQC_HIP_XC_PROBE (timing experiments only, results are then meaningless): bit 0 skips the AO slab evaluation, bit 1 the
 // X = D chi jobs, bit 2 the functional (constants instead), bit 3 the accumulation A += a chi^T
 __device__ int g_xc_probe = 0;
@@ -998,9 +997,8 @@ template <bool GGA, int PT, int JMAX, int OCC, bool DREG, int NTC, bool FAST = f
 __global__ void __launch_bounds__(64 * NWV, OCC) xc_tile_kernel(BatchView bv, int only_active)
 {
     // One tile = PT points: AO slab -> X = D chi, rho / grad rho -> functional (one lane per point) -> a -> A += a chi^T.
-    // (XC_TWO_PASS builds a 256-point super-tile in two passes so that the functional runs at full width; timing probes
-    // showed the functional to be ~0 % of the kernel and the AO slab 57 %, so rebuilding the slab costs far more than
-    // the full-width functional saves: measured 2.09 s against 1.99 s per evaluation.  Kept for the record, off.)
+    // (A 256-point super-tile in two passes -- so that all 256 threads evaluate the functional -- rebuilt the slab and was
+    // slower, 2.09 s against 1.99 s per evaluation at the time; removed)
     extern __shared__ double lds[];
     const int f = blockIdx.y;
     // FAST: the lean build of the slab phase for the common case -- radial tile in LDS, no f shells: one item per
@@ -1011,7 +1009,7 @@ __global__ void __launch_bounds__(64 * NWV, OCC) xc_tile_kernel(BatchView bv, in
     // components dealt to four waves -- made the kernel slower, twice).
     const bool rad_in_lds = FAST || (only_active & 2) != 0;   // bit 1 of the flag word: radial tile staged in LDS
     if ((only_active & 1) && bv.istate[4 * f] == ST_DONE) return;
-    constexpr int RS = PT + 1, PT16 = PT / 16, NTHR = 64 * NWV, SUPER = XC_TWO_PASS ? NTHR : PT, NSUB = SUPER / PT;
+    constexpr int RS = PT + 1, PT16 = PT / 16, NTHR = 64 * NWV;
     const int n = bv.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lo = lane & 15, hi = lane >> 4;
     // NTC > 0: the number of 16-function tiles is a template constant (n <= 64), so that every k-loop and tile test
@@ -1024,9 +1022,9 @@ __global__ void __launch_bounds__(64 * NWV, OCC) xc_tile_kernel(BatchView bv, in
     double* gx = chi + (size_t)NP * RS;                       // GGA: grad chi, x then overwritten by a;  LDA: a
     double* gy = gx + (size_t)NP * RS;
     double* gz = gy + (GGA ? (size_t)NP * RS : 0);
-    double* red = gz + (GGA ? (size_t)NP * RS : 0);           // [SUPER][4] rho, grad rho sums of the super-tile
-    double* coef = red + 4 * SUPER;                           // [SUPER][4] w v_rho / 2, 2 w v_sigma grad rho
-    double* axyz = coef + 4 * SUPER;                          // [64][3] this fragment's atoms
+    double* red = gz + (GGA ? (size_t)NP * RS : 0);           // [PT][4] rho, grad rho sums of the tile
+    double* coef = red + 4 * PT;                              // [PT][4] w v_rho / 2, 2 w v_sigma grad rho
+    double* axyz = coef + 4 * PT;                             // [64][3] this fragment's atoms
     double* pxyz = axyz + 3 * 64;                             // [2][PT][3] grid points of the current / next tile
     double* tab = pxyz + 6 * PT;                              // radial-group tables: desc ints, exponents, coefficients
     const int ng = tp.ngroup, ngp = tp.gprim_total, ngc = tp.gcoef_total;
@@ -1040,7 +1038,7 @@ __global__ void __launch_bounds__(64 * NWV, OCC) xc_tile_kernel(BatchView bv, in
     const double* __restrict__ wts = gd.weights + (size_t)f * gd.npts;
 
     // rows n..NP-1 stay zero for the whole kernel; the sums start at zero
-    for (int idx = tid; idx < (GGA ? 4 : 2) * NP * RS + 8 * SUPER; idx += NTHR) lds[idx] = 0.0;
+    for (int idx = tid; idx < (GGA ? 4 : 2) * NP * RS + 8 * PT; idx += NTHR) lds[idx] = 0.0;
     for (int g = tid; g < ng; g += NTHR) {
         const int sh0 = tp.grp_first[g], nc = tp.grp_count[g], npg = tp.grp_nprim[g];
         tdesc[6 * g] = tp.sh_aoff[sh0] | (tp.sh_l[sh0] << 12) | (tp.sh_atom[sh0] << 16) | (nc << 24) | (npg << 26);
@@ -1068,7 +1066,7 @@ __global__ void __launch_bounds__(64 * NWV, OCC) xc_tile_kernel(BatchView bv, in
         double* pp = pxyz + 3 * (b * PT + q);
         pp[0] = x; pp[1] = y; pp[2] = z;
     };
-    if (!XC_TWO_PASS && tid < PT) load_points(blockIdx.x * PT, 0, tid);
+    if (tid < PT) load_points(blockIdx.x * PT, 0, tid);
     int pbuf = 0;
     // radial cache of this fragment (tiles of PT points), when the engine filled one with this tile size
     const double* __restrict__ radf = (gd.rad && gd.rad_pt == PT)
@@ -1088,7 +1086,7 @@ __global__ void __launch_bounds__(64 * NWV, OCC) xc_tile_kernel(BatchView bv, in
                                                  (__attribute__((address_space(3))) void*)((char*)radl + c * 1024), 16, 0, 0);
         }
     };
-    if (!XC_TWO_PASS) stage_radial(blockIdx.x);
+    stage_radial(blockIdx.x);
     int iter = 0;
     // DREG (n <= 64): the X = D chi jobs of a wave are the same (row tile, point tile) pairs in every tile, so the wave
     // keeps its density fragments in registers for the whole kernel -- reading them from L2 per tile made the phase a
@@ -1140,14 +1138,8 @@ __global__ void __launch_bounds__(64 * NWV, OCC) xc_tile_kernel(BatchView bv, in
             const int rg = idx / PT, p = idx - rg * PT;
             const int g = g0 + p;
             if (g < gd.npts) {
-                double ptx, pty, ptz;
-                if (XC_TWO_PASS) {
-                    const int oa = gd.pt_atom[g], it = gd.pt_tmpl[g];
-                    ptx = xyz[3 * oa] + gd.tmpl_xyz[3 * it]; pty = xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1]; ptz = xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2];
-                } else {
-                    const double* pp = pxyz + 3 * (pbuf * PT + p);
-                    ptx = pp[0]; pty = pp[1]; ptz = pp[2];
-                }
+                const double* pp = pxyz + 3 * (pbuf * PT + p);
+                const double ptx = pp[0], pty = pp[1], ptz = pp[2];
                 if (rad_in_lds)
                     eval_group_cached<GGA>(gt, axyz, rg, ptx, pty, ptz, radl, PT, chi, gx, gy, gz, RS, p, bv.c2s);
                 else if (radf)
@@ -1161,19 +1153,17 @@ __global__ void __launch_bounds__(64 * NWV, OCC) xc_tile_kernel(BatchView bv, in
         }
     };
 
-    const int nsuper = (gd.npts + SUPER - 1) / SUPER;
-    for (int st = blockIdx.x; st < nsuper; st += gridDim.x) {
-        const int s0 = st * SUPER;
-        // ---- pass 1: densities of the 256 points
-        for (int sub = 0; sub < NSUB; ++sub) {
-            const int g0 = s0 + sub * PT;
-            if (g0 >= gd.npts) break;
+    const int ntile = (gd.npts + PT - 1) / PT;
+    for (int st = blockIdx.x; st < ntile; st += gridDim.x) {
+        const int s0 = st * PT, g0 = s0;
+        // ---- the slab and the densities of the tile's points
+        {
             XC_ST(11)
             ao_slab(g0);
             XC_ST(0)
             __syncthreads();
             XC_ST(1)
-            if (!XC_TWO_PASS) stage_radial(st + (int)gridDim.x);      // lands under the MFMA phase below
+            stage_radial(st + (int)gridDim.x);      // lands under the MFMA phase below
             // X = D chi, job = (row tile mt, point tile pt); rho and grad rho from the accumulator rows
 #pragma unroll 2
             for (int jj = 0; jj < (DREG ? DJ : 64); ++jj) {       // DREG: DJ <= 2, unrolled
@@ -1221,7 +1211,7 @@ __global__ void __launch_bounds__(64 * NWV, OCC) xc_tile_kernel(BatchView bv, in
                     rz += __shfl_xor(rz, 16, 64); rz += __shfl_xor(rz, 32, 64);
                 }
                 if (hi == 0) {
-                    double* rp = red + 4 * (sub * PT + 16 * pt + lo);
+                    double* rp = red + 4 * (16 * pt + lo);
                     atomicAdd(&rp[0], rho);
                     if (GGA) { atomicAdd(&rp[1], rx); atomicAdd(&rp[2], ry); atomicAdd(&rp[3], rz); }
                 }
@@ -1234,7 +1224,7 @@ __global__ void __launch_bounds__(64 * NWV, OCC) xc_tile_kernel(BatchView bv, in
         // FP64 pipe busy by itself.  The wave ROTATES over the tiles: wave w of every workgroup sits on SIMD w, so with
         // a fixed wave the functional phases of a CU's workgroups all queued on one SIMD while three idled.  (Dealing
         // the functional's components to the four waves was measured slower: 1.39 s against 1.30 s per evaluation.)
-        if (!XC_TWO_PASS) {
+        {
             if (wave == ((iter + (int)blockIdx.x) & (NWV - 1)) && lane < PT) {
                 const int p = lane;
                 double* rp = red + 4 * p;
@@ -1252,37 +1242,18 @@ __global__ void __launch_bounds__(64 * NWV, OCC) xc_tile_kernel(BatchView bv, in
                 const double t2 = 2.0 * w * vs;
                 cp[1] = t2 * rx; cp[2] = t2 * ry; cp[3] = t2 * rz;
             }
-        } else if (tid < SUPER) {
-            const int p = tid;
-            double* rp = red + 4 * p;
-            const double rho = rp[0], rx = 2.0 * rp[1], ry = 2.0 * rp[2], rz = 2.0 * rp[3];
-            rp[0] = 0.0; rp[1] = 0.0; rp[2] = 0.0; rp[3] = 0.0;
-            const double sigma = GGA ? rx * rx + ry * ry + rz * rz : 0.0;
-            double fx, vr, vs;
-            if (probe & 4) { fx = -rho; vr = -1.0; vs = 0.0; }
-            else eval_functional(bv.xc, rho, sigma, fx, vr, vs);
-            const double w = (s0 + p < gd.npts) ? wts[s0 + p] : 0.0;
-            e_acc += w * fx;
-            n_acc += w * rho;
-            double* cp = coef + 4 * p;
-            cp[0] = 0.5 * w * vr;
-            const double t2 = 2.0 * w * vs;
-            cp[1] = t2 * rx; cp[2] = t2 * ry; cp[3] = t2 * rz;
         }
-        // ---- pass 2: a and the accumulation
-        for (int sub = 0; sub < NSUB; ++sub) {
-            const int g0 = s0 + sub * PT;
-            if (g0 >= gd.npts) break;
+        // ---- a and the accumulation (the slab is still in LDS)
+        {
             XC_ST(4)
-            __syncthreads();          // coef written / the previous sub-tile's MFMA reads are done
+            __syncthreads();          // coef written
             XC_ST(5)
-            if (NSUB > 1) { ao_slab(g0); __syncthreads(); }       // single pass: the slab of pass 1 is still in LDS
             // the next tile's grid points, a tile ahead (last PT threads)
-            if (!XC_TWO_PASS && tid >= NTHR - PT) load_points((st + (int)gridDim.x) * PT, pbuf ^ 1, tid - (NTHR - PT));
+            if (tid >= NTHR - PT) load_points((st + (int)gridDim.x) * PT, pbuf ^ 1, tid - (NTHR - PT));
             // a[mu][p] = w v_rho / 2 chi + 2 w v_sigma grad rho . grad chi, written over gx
             {       // a thread's point is the same for all its elements (NTHR is a multiple of PT): its four weights once
                 const int p = tid % PT;
-                const double* cp = coef + 4 * (sub * PT + p);
+                const double* cp = coef + 4 * p;
                 const double c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
 #pragma unroll 3
                 for (int mu = tid / PT; mu < n; mu += NTHR / PT) {
@@ -1350,12 +1321,12 @@ static void xc_tile_launch(const BatchView& bv, int oa, hipStream_t s)
     // + radial-group tables: 2 doubles of descriptor per group, the exponents and up to XC_GROUP_MAX coefficient rows;
     // groups <= shells <= n, primitives per group <= 63 (descriptor field); bounded by the topology's own totals
     const size_t tab = 3 * (size_t)bv.topo.ngroup + (size_t)bv.topo.gprim_total + (size_t)bv.topo.gcoef_total + 8 + ((size_t)bv.topo.nshell + 1) / 2;
-    size_t lds = sizeof(double) * ((size_t)(GGA ? 4 : 2) * np * (PT + 1) + 8 * (XC_TWO_PASS ? 64 * NWV : PT) + 3 * 64 + 6 * PT + ((tab + 1) & ~(size_t)1));
+    size_t lds = sizeof(double) * ((size_t)(GGA ? 4 : 2) * np * (PT + 1) + 8 * PT + 3 * 64 + 6 * PT + ((tab + 1) & ~(size_t)1));
     // the radial tile rides in LDS when that does not cost a resident workgroup (OCC of them share 160 KB)
     const size_t rad_lds = sizeof(double) * (size_t)bv.topo.nshell * 2 * PT;
     static const bool rad_lds_on = [] { const char* e = std::getenv("MQC_HIP_XC_RADIAL_LDS"); return !(e && e[0] == '0'); }();
     const size_t lds_cap = (size_t)160 * 1024 / (OCC < 1 ? 1 : OCC) - 512;
-    if (!XC_TWO_PASS && rad_lds_on && bv.grid.rad && bv.grid.rad_pt == PT && (lds + rad_lds <= lds_cap || (lds > lds_cap && lds + rad_lds <= 156 * 1024))) {
+    if (rad_lds_on && bv.grid.rad && bv.grid.rad_pt == PT && (lds + rad_lds <= lds_cap || (lds > lds_cap && lds + rad_lds <= 156 * 1024))) {
         lds += rad_lds;
         oa |= 2;
     }
@@ -1365,7 +1336,7 @@ static void xc_tile_launch(const BatchView& bv, int oa, hipStream_t s)
         if (fast_on && (oa & 2) && bv.topo.lmax <= 2) kern = xc_tile_kernel<GGA, PT, JMAX, OCC, DREG, NTC, true, NWV>;
     }
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int tile_pts = XC_TWO_PASS ? 64 * NWV : PT;
+    const int tile_pts = PT;
     const int ntiles = (bv.grid.npts + tile_pts - 1) / tile_pts;
     int gx = (6144 + bv.nfrag - 1) / bv.nfrag;       // ~3 workgroups per CU x 8 in flight over the batch; many tiles each
     if (gx > ntiles) gx = ntiles;
