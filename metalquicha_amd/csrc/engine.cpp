@@ -22,6 +22,7 @@ const std::string& last_error_string();
 void eri_plan_lists(const BatchView& bv, const Topology& topo, hipStream_t s, const double* host_xyz);   // kern_eri.hip
 bool launch_gradient(const BatchView& bv, const Topology& topo, double* d_grad, double* work, int* d_lists, size_t list_capacity_ints,
                      hipStream_t s, std::string& err);                                                      // kern_grad.hip
+void launch_scale(double* p, size_t count, double f, hipStream_t s);      // kern_df.hip
 void launch_jk_direct_incremental(const BatchView& bv, const Topology& topo, double thresh, bool only_active, hipStream_t s);   // kern_eri.hip
 static DevicePool g_grad_pool[2];
 
@@ -235,7 +236,6 @@ static int validate_options(const mqc_hip_scf_options_t& o, const Topology& topo
         const int na = (topo.nelec + topo.multiplicity - 1) / 2, nb = topo.nelec - na;
         if (nb < 0 || na < 0) { msg = "UHF: multiplicity asks for more unpaired electrons than the system has"; return MQC_HIP_ERR_VALIDATION; }
         if (na < 1) { msg = "UHF: no electrons to place"; return MQC_HIP_ERR_VALIDATION; }
-        if (o.density_fitting) { msg = "UHF with density fitting is not available (the CPU reference refuses it too, mqc_libcint_bridge.f90:605-612)"; return MQC_HIP_ERR_UNSUPPORTED; }
         {
             XcSpec tu; std::string eu;
             parse_functional(o.functional, tu, eu);
@@ -541,8 +541,24 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         int guard = 0;
         while (remaining > 0 && guard < opts.max_iter + 2) {
             HIP_CHECK_RET(hipEventRecord(sl.e0, s));
-            if (use_df) launch_df_jk(bv, true, s);
-            else if (use_direct) {
+            if (use_df) {
+                launch_df_jk(bv, true, s);
+                if (uhf) {
+                    // unrestricted density fitting, as run_uks_scf of the cuEST path (mqc_cuest_scf.f90:637-1009): J from each
+                    // spin density, K_s = sum_P (B_P C_s)(B_P C_s)^T; the kernels return the closed-shell 2 W W^T
+                    const size_t tot = (size_t)nf * n * n;
+                    launch_scale(bv.K, tot, 0.5, s);
+                    if (nbeta > 0) {
+                        BatchView vb = bv;
+                        vb.D = bv.Db; vb.J = bv.Jb; vb.K = bv.Kb; vb.C = bv.Cb; vb.nocc = nbeta;
+                        launch_df_jk(vb, true, s);
+                        launch_scale(bv.Kb, tot, 0.5, s);
+                    } else {
+                        HIP_CHECK_RET(hipMemsetAsync(bv.Jb, 0, sizeof(double) * tot, s));
+                        HIP_CHECK_RET(hipMemsetAsync(bv.Kb, 0, sizeof(double) * tot, s));
+                    }
+                }
+            } else if (use_direct) {
                 launch_jk_direct_incremental(bv, topo, direct_tol, true, s);        // restricted: G_ref += G(D - D_ref)
                 if (uhf) {
                     // the integrals are formed again for the beta density: J[D_b], K[D_b] (twice the direct work)

@@ -891,4 +891,17 @@ void launch_df_jk(const BatchView& bv, bool only_active, hipStream_t s)
 #undef DFK
 }
 
+
+__global__ void scale_kernel(double* __restrict__ p, size_t count, double f)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) p[i] *= f;
+}
+
+// p[0 .. count) *= f   (unrestricted density fitting: the exchange kernels return 2 W W^T, the closed-shell convention)
+void launch_scale(double* p, size_t count, double f, hipStream_t s)
+{
+    if (count) hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, p, count, f);
+}
+
 }  // namespace mqc

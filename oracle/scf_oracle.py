@@ -465,7 +465,7 @@ class UhfResult:
 
 
 def run_uhf(mol: OracleMol, nelec: int, multiplicity: int, max_iter=100, e_tol=1e-8, d_tol=1e-6, diis_vectors=8,
-            guess="gwh", diis_start=UHF_DIIS_START, eri=None, xc=None) -> UhfResult:
+            guess="gwh", diis_start=UHF_DIIS_START, eri=None, xc=None, aux: Optional[OracleMol] = None) -> UhfResult:
     """Unrestricted Hartree-Fock with the reference CPU path's semantics (run_libcint_uhf,
     backends/libcint/mqc_libcint_rhf.f90:682-974): F_s = H + J[D_a + D_b] - K[D_s], one DIIS over both spins
     (Fock matrices and commutators laid end to end) from iteration `diis_start`, dE and the rms over BOTH density
@@ -479,7 +479,8 @@ def run_uhf(mol: OracleMol, nelec: int, multiplicity: int, max_iter=100, e_tol=1
     S, T, V = int1e(mol)
     H = T + V
     n = mol.nao
-    if eri is None:
+    B = df_tensor(mol, aux) if aux is not None else None       # density-fitted J / K, as the cuEST path's run_uks_scf
+    if eri is None and B is None:
         eri = eri4(mol)
     X = build_orthogonalizer(S)
     m = X.shape[1]
@@ -491,12 +492,18 @@ def run_uhf(mol: OracleMol, nelec: int, multiplicity: int, max_iter=100, e_tol=1
     def assemble(Da, Db):
         # unrestricted Kohn-Sham (run_libcint_uhf with an XC context): exchange scaled by the functional's fraction,
         # the energy from the Fock matrices BEFORE the spin potentials are added, plus E_xc
-        J = np.einsum("ijkl,kl->ij", eri, Da + Db, optimize=True)
+        if B is not None:
+            J, Ka = build_jk_df(B, Da + Db)[0], build_jk_df(B, Da)[1]
+            Kb = build_jk_df(B, Db)[1]
+        else:
+            J = np.einsum("ijkl,kl->ij", eri, Da + Db, optimize=True)
+            Ka = np.einsum("ikjl,kl->ij", eri, Da, optimize=True) if exx != 0.0 else 0.0
+            Kb = np.einsum("ikjl,kl->ij", eri, Db, optimize=True) if exx != 0.0 else 0.0
         Fa = H + J
         Fb = H + J
         if exx != 0.0:
-            Fa = Fa - exx * np.einsum("ikjl,kl->ij", eri, Da, optimize=True)
-            Fb = Fb - exx * np.einsum("ikjl,kl->ij", eri, Db, optimize=True)
+            Fa = Fa - exx * Ka
+            Fb = Fb - exx * Kb
         e = 0.5 * float(np.sum(Da * (H + Fa)) + np.sum(Db * (H + Fb)))
         if xc is not None:
             exc, Va, Vb = xc.potential_uks(Da, Db)

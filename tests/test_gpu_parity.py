@@ -283,6 +283,37 @@ def test_unrestricted_runs_on_the_direct_path():
         assert abs(r.energy.scf - case["expected_energy"]) < 1e-9, (case["name"], r.energy.scf)
 
 
+def test_unrestricted_density_fitting_matches_oracle():
+    """UHF and UKS with density-fitted J / K -- the mode of the cuEST path's own unrestricted SCF (run_uks_scf,
+    mqc_cuest_scf.f90:637-1009): J from the total density, K_s from the occupied orbitals of each spin.  OH (UHF) and
+    CH3 (UKS-PBE) against the oracle with the same auxiliary set, iteration counts included; a closed-shell molecule run
+    unrestricted lands on the restricted density-fitted energy."""
+    oh = [c for c in _uhf_cases() if c["basis"] == "cc-pvdz" and c["symbols"] == ["O", "H"]][0]
+    ch3 = [c for c in _uks_cases() if c["symbols"][0] == "C" and c["functional"] == "pbe"][0]
+    for case, fn in ((oh, ""), (ch3, "pbe")):
+        z = [SYMBOL_TO_Z[s_.lower()] for s_ in case["symbols"]]
+        frag = fragment_bohr(z, np.array(case["xyz_angstrom"]) * ANGSTROM_TO_BOHR, multiplicity=2)
+        st = methods.ScfSettings(basis_set="cc-pvdz", functional=fn, density_fitting=True, aux_basis_set=AUX, energy_tol=1e-10,
+                                 density_tol=1e-8, guess="gwh")
+        r = methods.run_hip_scf(st, frag)
+        assert not r.has_error, r.error_message
+
+        def oracle(frag=frag, fn=fn):
+            mol = oracle_mol("cc-pvdz", frag)
+            return scf_record(so.run_uhf(mol, int(frag.nelec), 2, 100, 1e-10, 1e-8, aux=oracle_mol(AUX, frag),
+                                         xc=xc_oracle.XCOracle(mol, fn, 3) if fn else None))
+        o = recorded_oracle("unrestricted_df", frag, "cc-pvdz|%s|df:%s|grid3|1e-10|1e-8|gwh" % (fn, AUX), oracle)
+        assert abs(r.energy.scf - o["energy"]) < 1e-8, (fn, r.energy.scf, o["energy"])
+        assert r.scf_iterations == o["iterations"]
+        assert abs(r.energy.scf - case["expected_energy"]) < 5e-4          # a fitting error away from the exact-ERI golden
+    w = fragment_bohr(*WATER)
+    ru = methods.run_hip_scf(methods.ScfSettings(basis_set="cc-pvdz", density_fitting=True, aux_basis_set=AUX, energy_tol=1e-10,
+                                                 density_tol=1e-8, guess="gwh", unrestricted=True), w)
+    rr = methods.run_hip_scf(methods.ScfSettings(basis_set="cc-pvdz", density_fitting=True, aux_basis_set=AUX, energy_tol=1e-10,
+                                                 density_tol=1e-8, guess="gwh"), w)
+    assert not ru.has_error and abs(ru.energy.scf - rr.energy.scf) < 1e-9 and abs(ru.s_squared) < 1e-8
+
+
 def test_uks_closed_shell_limit_and_batch():
     """A closed-shell molecule run unrestricted lands on the restricted Kohn-Sham energy (the reference's own guard
     against a wrong spin stride, mqc_libcint_xc.F90:944-946); a batch of OH radicals in one call against the oracle."""
@@ -392,9 +423,9 @@ def test_fragments_above_140_functions_run_from_global_memory():
 
 
 def test_refusals_match_reference_behaviour():
-    st = methods.ScfSettings(basis_set="sto-3g", unrestricted=True, density_fitting=True)
-    r = methods.run_hip_scf(st, fragment_bohr(*WATER))
-    assert r.has_error and not r.has_energy              # UHF with density fitting: refused, as the CPU reference does
+    st = methods.ScfSettings(basis_set="sto-3g", density_fitting=True, aux_basis_set=AUX)
+    r = methods.run_hip_scf(st, fragment_bohr(*WATER), want_gradient=True)
+    assert r.has_error and not r.has_energy              # density-fitted gradients: refused, not replaced by something else
     st = methods.ScfSettings(basis_set="sto-3g", max_iter=2, energy_tol=1e-12, density_tol=1e-12)
     r = methods.run_hip_scf(st, fragment_bohr(*WATER))
     assert r.scf_status == methods.SCF_NOT_CONVERGED and r.has_error     # not converged is an error ...
