@@ -29,10 +29,22 @@ namespace mqc {
 namespace {
 
 constexpr int NT = MQC_SCF_NT;
+// In-kernel phase stamps of the restricted SCF step (build with -DSCF_STAMPS=1; never in the shipped library)
+#ifndef SCF_STAMPS
+#define SCF_STAMPS 0
+#endif
+#if SCF_STAMPS
+__device__ unsigned long long g_scf_stamps[8];
+#define SCF_ST_DECL unsigned long long sst_t = __builtin_amdgcn_s_memtime();
+#define SCF_ST(k) { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_scf_stamps[k], t_ - sst_t); } sst_t = __builtin_amdgcn_s_memtime(); }
+#else
+#define SCF_ST_DECL
+#define SCF_ST(k)
+#endif
 constexpr double OVERLAP_EIG_TOL = 1.0e-7;   // src/scf/mqc_scf_common.f90:33
 constexpr double GWH_K = 1.75;               // src/scf/mqc_scf_common.f90:39
 constexpr double PIVOT_FLOOR = 1.0e-14;      // src/methods/mqc_diis.f90:30
-constexpr double JACOBI_SKIP = 1.0e-15;      // rotation skipped when |a_pq| <= this * max|a_ii|
+constexpr double JACOBI_SKIP = 1.0e-13;      // rotation skipped when |a_pq| <= this * max|a_ii| (1e-15: one more sweep in ~1 of 5 diagonalisations, SCF step 19.0 -> 17.6 ms per evaluation at 1e-13 with unchanged iteration counts and 7e-12 Eh parity; 1e-12 gains nothing more and quadruples the parity error)
 constexpr int JACOBI_MAX_SWEEPS = 60;
 
 __device__ __forceinline__ double block_sum(double v, double* red)
@@ -406,7 +418,12 @@ __device__ void diagonalize_and_density(const BatchView& bv, FragPtrs& p, Jacobi
         }
     }
     __syncthreads();
+#if SCF_STAMPS
+    unsigned long long sst_t = __builtin_amdgcn_s_memtime();
+    SCF_ST(3)          /* (re-based: counts only the barrier) */
+#endif
     jacobi_eig<JM>(jl, m, ldv, WARM ? Vp : nullptr, n);
+    SCF_ST(4)
     // keep the eigenvectors for the next iteration's warm start
     for (int idx = tid; idx < m * m; idx += NT) {
         const int i = idx / m, j = idx - i * m;
@@ -550,6 +567,7 @@ __global__ void __launch_bounds__(NT) scf_step_kernel(BatchView bv)
     const int m = p.istate[2];
     const size_t nn = (size_t)n * n;
     JacobiLds jl = carve_jacobi(lds, m, JM, nullptr, (JM == 0) ? bv.W + ((size_t)blockIdx.x * 6 + 4) * n * n + n : nullptr);
+    SCF_ST_DECL
 
     // ---- Fock assembly and energy (assemble_fock :985-990,1206-1228; electronic_energy :1691)
     // The energy is taken from the Fock matrix BEFORE V_xc is added, plus E_xc
@@ -570,6 +588,7 @@ __global__ void __launch_bounds__(NT) scf_step_kernel(BatchView bv)
         return;
     }
 
+    SCF_ST(0)
     // ---- DIIS error e = X^T (F D S - S D F) X   (commutator :1326-1352)
     double* W0 = p.W; double* W1 = p.W + nn; double* W2 = p.W + 2 * nn; double* Err = p.W + 5 * nn;
     wg_gemm_mfma<false, false>(n, n, n, p.F, n, p.D, n, [&](int i, int j, double v) { W0[i * n + j] = v; });     // F D
@@ -582,6 +601,7 @@ __global__ void __launch_bounds__(NT) scf_step_kernel(BatchView bv)
     wg_gemm_mfma<false, false>(n, m, n, W0, n, p.X, n, [&](int i, int j, double v) { W2[i * n + j] = v; });       // (.) X      n x m
     wg_gemm_mfma<true, false>(m, m, n, p.X, n, W2, n, [&](int i, int j, double v) { Err[i * m + j] = v; });       // X^T (.)    m x m, ld m
 
+    SCF_ST(1)
     // ---- DIIS push / extrapolate (mqc_diis.f90:113-162; RHF extrapolates from the first iteration)
     const int maxv = bv.diis_size;
     if (maxv > 0) {
@@ -627,11 +647,13 @@ __global__ void __launch_bounds__(NT) scf_step_kernel(BatchView bv)
         __syncthreads();
     }
 
+    SCF_ST(2)
     // ---- keep the old density, diagonalise, new density
     double* Dold = p.W + nn;    // W1 is free again
     for (int idx = tid; idx < n * n; idx += NT) Dold[idx] = p.D[idx];
     __syncthreads();
     diagonalize_and_density<JM, true>(bv, p, jl, m);
+    SCF_ST(6)
 
     double d2 = 0.0;
     for (int idx = tid; idx < n * n; idx += NT) { const double d = p.D[idx] - Dold[idx]; d2 += d * d; }
@@ -890,6 +912,13 @@ void MQC_SCF_PUBLIC(launch_scf_step)(const BatchView& bv, hipStream_t s)
     if (bv.uhf) MQC_JACOBI_DISPATCH(scf_step_uhf_kernel, bv.n, bv.nfrag, lds, s, bv);
     else MQC_JACOBI_DISPATCH(scf_step_kernel, bv.n, bv.nfrag, lds, s, bv);
     hipLaunchKernelGGL(count_active_kernel, dim3(1), dim3(256), 0, s, bv);
+#if SCF_STAMPS
+    (void)hipStreamSynchronize(s);
+    unsigned long long h[8];
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_scf_stamps), sizeof(h));
+    std::fprintf(stderr, "scf stamps nfrag=%d n=%d: fock %llu | commutator %llu | diis %llu | jacobi %llu | diag total (gemms + jacobi + C, D) %llu\n",
+                 bv.nfrag, bv.n, h[0], h[1], h[2], h[4], h[6]);
+#endif
 }
 
 #if MQC_SCF_NT == 256
