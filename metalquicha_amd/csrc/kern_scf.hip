@@ -614,13 +614,35 @@ __global__ void __launch_bounds__(NT) scf_step_kernel(BatchView bv)
         for (int idx = tid; idx < n * n; idx += NT) fh[idx] = p.F[idx];
         for (int idx = tid; idx < m * m; idx += NT) eh[idx] = Err[idx];
         __syncthreads();
-        for (int age = 1; age <= n_stored; ++age) {
-            const int other = diis_slot_of_age(newest, n_stored, maxv, age) - 1;
-            const double* eo = p.diis_e + (size_t)other * nn;
-            double s = 0.0;
-            for (int idx = tid; idx < m * m; idx += NT) s += eh[idx] * eo[idx];
-            s = block_sum(s, jl.red);
-            if (tid == 0) { p.diis_b[slot * maxv + other] = s; p.diis_b[other * maxv + slot] = s; }
+        // the new row of the overlap matrix: all n_stored inner products in ONE pass over the newest error vector and one
+        // block reduction (a loop of block sums cost two barriers per stored vector)
+        {
+            __shared__ double bpart[NT / 64][DIIS_MAX];
+            double sv[DIIS_MAX];
+#pragma unroll
+            for (int a = 0; a < DIIS_MAX; ++a) sv[a] = 0.0;
+            for (int idx = tid; idx < m * m; idx += NT) {
+                const double en = eh[idx];
+#pragma unroll
+                for (int a = 0; a < DIIS_MAX; ++a)
+                    if (a < n_stored) sv[a] += en * p.diis_e[(size_t)(diis_slot_of_age(newest, n_stored, maxv, a + 1) - 1) * nn + idx];
+            }
+#pragma unroll
+            for (int a = 0; a < DIIS_MAX; ++a) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) sv[a] += __shfl_down(sv[a], off, 64);
+            }
+            if ((tid & 63) == 0) {
+#pragma unroll
+                for (int a = 0; a < DIIS_MAX; ++a) bpart[tid >> 6][a] = sv[a];
+            }
+            __syncthreads();
+            if (tid < n_stored) {
+                double t = 0.0;
+                for (int w = 0; w < NT / 64; ++w) t += bpart[w][tid];
+                const int other = diis_slot_of_age(newest, n_stored, maxv, tid + 1) - 1;
+                p.diis_b[slot * maxv + other] = t; p.diis_b[other * maxv + slot] = t;
+            }
         }
         __syncthreads();
         double* coef = jl.rc;     // reuse LDS (>= 9 doubles: mp/2 >= 9 needs m >= 18; fall back to red otherwise)
