@@ -37,6 +37,10 @@ import os
 import sys
 import time
 
+# torch initialises the HIP runtime before the engine's library is loaded: the hardware-queue request the library makes
+# for itself (engine.cpp: ask_for_hardware_queues; two lanes of four to eight streams) has to be in the environment here
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

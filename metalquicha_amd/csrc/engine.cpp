@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 #include <atomic>
@@ -936,8 +937,19 @@ int mqc_hip_abi_version(void) { return MQC_HIP_ABI_VERSION; }
 
 const char* mqc_hip_last_error(void) { return last_error_string().c_str(); }
 
+// The engine keeps two lanes of 1 + 3 (or 1 + 7) streams busy at once; with the HIP runtime's default of four hardware
+// queues per process they share queues and serialise (measured on one box: 138.4 ms per evaluation at 4 queues, 132.8 at
+// 8, 128.2 at 16).  The runtime reads GPU_MAX_HW_QUEUES when it initialises, so the library asks for 16 before its
+// first HIP call unless the variable is already set; a host that initialised HIP earlier exports it in the job script.
+static void ask_for_hardware_queues()
+{
+    static const bool done = [] { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); return true; }();
+    (void)done;
+}
+
 int mqc_hip_backend_available(void)
 {
+    ask_for_hardware_queues();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n > 0 ? 1 : 0;
@@ -961,6 +973,7 @@ int mqc_hip_context_get(int32_t local_rank, mqc_hip_context** out)
 {
     if (!out) return fail(MQC_HIP_ERR_VALIDATION, "null context pointer");
     if (g_ctx) { *out = g_ctx; return MQC_HIP_OK; }
+    ask_for_hardware_queues();
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(MQC_HIP_ERR_NO_DEVICE, "no HIP device is visible: the MI355X backend has no CPU fallback");

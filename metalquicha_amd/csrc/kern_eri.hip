@@ -205,7 +205,19 @@ struct EriListCache {
     int nap = 0;
 };
 constexpr int ERI_CACHE_WAYS = 4;
-constexpr int ERI_SIDE_STREAMS = 3;    // task-list launches of different classes are independent: round-robin.
+constexpr int ERI_SIDE_MAX = 7;        // task-list launches of different classes are independent: round-robin.
+// Side streams in use: 3 with the HIP runtime's default of four hardware queues per process, 7 when the process runs
+// with GPU_MAX_HW_QUEUES >= 8 (more streams than hardware queues only serialise); MQC_HIP_ERI_STREAMS overrides.
+static int eri_side_streams()
+{
+    static const int n = [] {
+        if (const char* e = std::getenv("MQC_HIP_ERI_STREAMS")) { const int v = std::atoi(e); return v < 1 ? 1 : (v > ERI_SIDE_MAX ? ERI_SIDE_MAX : v); }
+        const char* q = std::getenv("GPU_MAX_HW_QUEUES");
+        return (q && std::atoi(q) >= 8) ? ERI_SIDE_MAX : 3;
+    }();
+    return n;
+}
+#define ERI_SIDE_STREAMS eri_side_streams()
 // Three, not more: ROCm maps streams onto 4 hardware queues in creation order, and a lane's main stream plus its
 // three side streams (created back to back in mqc_hip_context_get) then sit on four different queues; a fourth
 // side stream shares the main stream's queue and its kernels wait behind the orthogonaliser.
@@ -218,8 +230,8 @@ struct EriSlotState {
     double bounds_tol = 0.0;
     std::vector<int> bucket[KERNEL_LMAX + 1][KERNEL_LMAX + 1];   // shell pairs by class, kept alive for the async upload
     DevicePool qpool, pairs;
-    hipStream_t side[ERI_SIDE_STREAMS] = {};
-    hipEvent_t fork = nullptr, join[ERI_SIDE_STREAMS] = {};
+    hipStream_t side[ERI_SIDE_MAX] = {};
+    hipEvent_t fork = nullptr, join[ERI_SIDE_MAX] = {};
 };
 }  // namespace
 
@@ -230,7 +242,7 @@ static uint64_t hash_words(const void* p, size_t bytes, uint64_t h)
     return h;
 }
 
-static hipStream_t g_preset_side[2][ERI_SIDE_STREAMS] = {};
+static hipStream_t g_preset_side[2][ERI_SIDE_MAX] = {};
 
 // side streams created by the context right after the lane's main stream (hardware-queue placement, see above)
 void eri_set_side_streams(int slot, const hipStream_t* streams, int count)
@@ -247,7 +259,7 @@ void eri_reset_state()
         EriSlotState& st = g_eri_state_slot[sl];
         if (st.fork) (void)hipEventDestroy(st.fork);
         st.fork = nullptr;
-        for (int k = 0; k < ERI_SIDE_STREAMS; ++k) {
+        for (int k = 0; k < ERI_SIDE_MAX; ++k) {
             if (st.join[k]) (void)hipEventDestroy(st.join[k]);
             st.join[k] = nullptr;
             if (st.side[k] && st.side[k] != g_preset_side[sl][k]) (void)hipStreamDestroy(st.side[k]);   // preset ones: the context's
@@ -473,7 +485,7 @@ void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, h
         }
         std::sort(cost.begin(), cost.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
         for (auto& ck : cost) issue_order.push_back(ck.second);
-        double load[ERI_SIDE_STREAMS + 1] = {};
+        double load[ERI_SIDE_MAX + 1] = {};
         for (auto& ck : cost) {
             int best = 0;
             for (int q = 1; q <= ERI_SIDE_STREAMS; ++q) if (load[q] < load[best]) best = q;
