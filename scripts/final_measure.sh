@@ -1,6 +1,8 @@
 #!/bin/bash
 # The measurement run behind profiles/r02_m..s: benches, kernel statistics and the separate --pmc passes, one MI355X.
 set -e
+# rocprofv3 initialises HIP before python starts: the queue request bench.py makes for itself has to be exported here
+export GPU_MAX_HW_QUEUES=16
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python bench.py > gpurun_out/r02_final_bench_default.json 2> gpurun_out/r02_final_bench_default.err
 python bench.py --functional b3lyp --no-secondary --no-cpu-baseline > gpurun_out/r02_final_bench_b3lyp.json 2> gpurun_out/r02_final_b3lyp.err
