@@ -540,7 +540,22 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         }
         int remaining = nf;
         int guard = 0;
+        // Kohn-Sham: the quadrature needs the density only, like J/K -- it runs on the lane's side stream next to the
+        // J/K build and joins before the SCF step (the event pair that synchronised orthogonaliser and guess is free now)
+        hipStream_t sxc = ctx->side[sl.id & 1][2];
+        // OFF by default: measured 1206 against 1230 ms per B3LYP evaluation (-2 %), but the J/K launches then wait inside
+        // the quadrature's shadow and their HIP-event times (the bench's per-stage figures) stop meaning anything
+        static const bool xc_side = [] { const char* e = std::getenv("MQC_HIP_XC_SIDE_STREAM"); return e && e[0] == '1'; }();
+        const bool xc_on_side = xc.ncomp > 0 && xc_side;
         while (remaining > 0 && guard < opts.max_iter + 2) {
+            if (xc_on_side) {
+                HIP_CHECK_RET(hipEventRecord(ctx->evo[sl.id & 1][0], s));
+                HIP_CHECK_RET(hipStreamWaitEvent(sxc, ctx->evo[sl.id & 1][0], 0));
+                HIP_CHECK_RET(hipEventRecord(sl.e2, sxc));
+                launch_xc(bv, true, sxc);
+                HIP_CHECK_RET(hipEventRecord(sl.e3, sxc));
+                HIP_CHECK_RET(hipEventRecord(ctx->evo[sl.id & 1][1], sxc));
+            }
             HIP_CHECK_RET(hipEventRecord(sl.e0, s));
             if (use_df) {
                 launch_df_jk(bv, true, s);
@@ -578,7 +593,8 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
             }
             HIP_CHECK_RET(hipEventRecord(sl.e1, s));
             if (guard == 0 && (rc = stage_check("J/K build")) != MQC_HIP_OK) return rc;
-            if (xc.ncomp > 0) {
+            if (xc_on_side) HIP_CHECK_RET(hipStreamWaitEvent(s, ctx->evo[sl.id & 1][1], 0));
+            else if (xc.ncomp > 0) {
                 HIP_CHECK_RET(hipEventRecord(sl.e2, s));
                 launch_xc(bv, true, s);
                 HIP_CHECK_RET(hipEventRecord(sl.e3, s));
