@@ -97,6 +97,7 @@ contains
       mol%n_atoms = fragment%n_atoms; mol%atomic_numbers = c_loc(z); mol%xyz = c_loc(xyz)
       mol%charge = fragment%charge; mol%multiplicity = fragment%multiplicity; mol%nelec = fragment%nelec
       mol%ghost = c_null_ptr
+      mol%n_point_charges = 0; mol%point_charge_xyz = c_null_ptr; mol%point_charges = c_null_ptr
       if (allocated(fragment%is_ghost)) then
          allocate (ghost(fragment%n_atoms))
          ghost = merge(1_c_int8_t, 0_c_int8_t, fragment%is_ghost)
@@ -137,6 +138,7 @@ contains
       res%orbital_energies = c_loc(eps); res%density = c_null_ptr
       res%orbital_energies_beta = c_null_ptr
       res%gradient = c_null_ptr
+      res%embedding_matrix = c_null_ptr; res%mulliken_charges = c_null_ptr
       if (need_gradient) then
          allocate (grad(3*fragment%n_atoms))
          grad = 0.0_c_double

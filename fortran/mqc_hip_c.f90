@@ -26,6 +26,10 @@ module mqc_hip_c
       integer(c_int32_t) :: charge
       integer(c_int32_t) :: multiplicity
       integer(c_int32_t) :: nelec
+      ! ABI 3: external point charges (embedding field of the FMO / EE-MBE callers)
+      integer(c_int32_t) :: n_point_charges = 0
+      type(c_ptr) :: point_charge_xyz = c_null_ptr   !! double [3*n_point_charges], Bohr
+      type(c_ptr) :: point_charges = c_null_ptr      !! double [n_point_charges]
    end type
 
    type, bind(C), public :: mqc_hip_basis_t
@@ -85,6 +89,10 @@ module mqc_hip_c
       integer(c_int32_t) :: n_alpha
       integer(c_int32_t) :: n_beta
       real(c_double) :: s_squared
+      ! ABI 3
+      real(c_double) :: e_embedding            !! tr(D u) with the point-charge field u
+      type(c_ptr) :: embedding_matrix          !! optional out, double [n_ao*n_ao]
+      type(c_ptr) :: mulliken_charges          !! optional out, double [n_atoms]
    end type
 
    public :: mqc_hip_backend_available, mqc_hip_context_get, mqc_hip_finalize, mqc_hip_last_error, &

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MQC_HIP_ABI_VERSION 2
+#define MQC_HIP_ABI_VERSION 3
 
 /* status codes (0 = ok).  VALIDATION mirrors ERROR_VALIDATION, GENERIC mirrors ERROR_GENERIC
  * (src/utils/mqc_error.f90:22-44). */
@@ -76,6 +76,13 @@ typedef struct {
     int32_t charge;
     int32_t multiplicity;
     int32_t nelec;                   /* excludes ghosts */
+    /* ABI 3: external point charges -- the embedding field of the FMO / EE-MBE callers
+     * (embedding_operator with esp = "ptc", backends/libcint/mqc_libcint_fmo.f90:1077-1160): the operator
+     * u = -sum_g q_g / |r - R_g| is added to the one-electron Hamiltonian, exactly as run_libcint_rhf's h_extra
+     * (mqc_libcint_rhf.f90:479-484); the charges do NOT enter the nuclear repulsion. */
+    int32_t n_point_charges;         /* 0 = none */
+    const double *point_charge_xyz;  /* [3*n_point_charges], Bohr */
+    const double *point_charges;     /* [n_point_charges] */
 } mqc_hip_molecule_t;
 
 /* molecular_basis_type flattened (src/basis/mqc_cgto.f90); RAW Basis-Set-Exchange
@@ -142,6 +149,12 @@ typedef struct {
     double *orbital_energies_beta;   /* optional out [n_ao] or NULL; written by unrestricted runs */
     int32_t n_alpha, n_beta;         /* occupied orbitals per spin (n_occ = n_alpha) */
     double s_squared;                /* <S^2> of the unrestricted determinant, 0 for restricted */
+    /* ABI 3 */
+    double e_embedding;              /* tr(D u): the part of e_total that is the interaction with the point charges
+                                        (inner_scf subtracts it, mqc_libcint_fmo.f90:1992-1997); 0 without charges */
+    double *embedding_matrix;        /* optional out [n_ao*n_ao] or NULL: u itself (nmer_term needs tr(D_split u), :1266-1272) */
+    double *mulliken_charges;        /* optional out [n_atoms] or NULL: q_A = Z_A - sum_{mu on A} (D S)_mu,mu
+                                        (fragment_charges, mqc_libcint_fmo.f90:2001-2021; ghosts carry Z = 0) */
 } mqc_hip_scf_result_t;
 
 /* ---- lifecycle -------------------------------------------------------------------- */

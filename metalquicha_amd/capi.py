@@ -31,7 +31,9 @@ c_uint8_p = C.POINTER(C.c_uint8)
 class Molecule(C.Structure):
     _fields_ = [("n_atoms", C.c_int32), ("atomic_numbers", c_int32_p), ("xyz", c_double_p),
                 ("ghost", c_uint8_p), ("charge", C.c_int32), ("multiplicity", C.c_int32),
-                ("nelec", C.c_int32)]
+                ("nelec", C.c_int32),
+                # ABI 3: external point charges (embedding field of the FMO / EE-MBE callers)
+                ("n_point_charges", C.c_int32), ("point_charge_xyz", c_double_p), ("point_charges", c_double_p)]
 
 
 class Basis(C.Structure):
@@ -56,7 +58,8 @@ class ScfResult(C.Structure):
                 ("lumo", C.c_double), ("has_orbitals", C.c_int32), ("orbital_energies", c_double_p),
                 ("density", c_double_p), ("has_error", C.c_int32), ("message", C.c_char * 256),
                 ("dipole", C.c_double * 3), ("has_dipole", C.c_int32), ("gradient", c_double_p), ("has_gradient", C.c_int32),
-                ("orbital_energies_beta", c_double_p), ("n_alpha", C.c_int32), ("n_beta", C.c_int32), ("s_squared", C.c_double)]
+                ("orbital_energies_beta", c_double_p), ("n_alpha", C.c_int32), ("n_beta", C.c_int32), ("s_squared", C.c_double),
+                ("e_embedding", C.c_double), ("embedding_matrix", c_double_p), ("mulliken_charges", c_double_p)]
 
 
 class Stats(C.Structure):

@@ -137,10 +137,11 @@ static int upload_topology(mqc_hip_context* ctx, const Topology& topo, TopologyD
     return MQC_HIP_OK;
 }
 
-static size_t per_fragment_main_doubles(int n, int natoms, bool uhf = false)
+static size_t per_fragment_main_doubles(int n, int natoms, bool uhf = false, int npc = 0)
 {
     const size_t nn = (size_t)n * n;
-    return (uhf ? 6 * nn + 2 * DIIS_MAX * nn + n : 0)   // beta spin: D C F J K Vprev, DIIS histories, eps
+    return (npc > 0 ? nn + 4 * (size_t)npc + 64 : 0)   // embedding operator U and the point charges (x, y, z, q)
+           + (uhf ? 6 * nn + 2 * DIIS_MAX * nn + n : 0)   // beta spin: D C F J K Vprev, DIIS histories, eps
            + 9 * nn    // S H X F D C J K Vprev
            + 6 * nn    // W
            + 2 * DIIS_MAX * nn   // DIIS histories
@@ -161,11 +162,11 @@ struct Slot {
 
 // carve one chunk's arrays out of the slot's pools
 static int carve_batch(mqc_hip_context* ctx, Slot& sl, const Topology& topo, const TopologyDev& td, int nfrag, bool with_eri, BatchView& bv,
-                       bool uhf = false)
+                       bool uhf = false, int npc = 0)
 {
     const int n = topo.nao;
     const size_t nn = (size_t)n * n, nf = (size_t)nfrag;
-    const size_t main_bytes = sizeof(double) * nf * per_fragment_main_doubles(n, topo.natoms, uhf) + 16384;
+    const size_t main_bytes = sizeof(double) * nf * per_fragment_main_doubles(n, topo.natoms, uhf, npc) + 16384;
     char* base = (char*)sl.main->ensure(main_bytes);
     if (!base) return fail(MQC_HIP_ERR_DEVICE, "out of device memory (SCF matrices)");
     auto take = [&base](size_t b) { char* p = base; base += (b + 255) & ~size_t(255); return p; };
@@ -196,6 +197,8 @@ static int carve_batch(mqc_hip_context* ctx, Slot& sl, const Topology& topo, con
     }
     bv.diis_state = (int*)take(sizeof(int) * nf * 2);
     bv.istate = (int*)take(sizeof(int) * nf * 4);
+    bv.npc = npc; bv.pc = nullptr; bv.U = nullptr;
+    if (npc > 0) { bv.pc = (double*)take(sizeof(double) * nf * npc * 4); bv.U = (double*)take(sizeof(double) * nf * nn); }
     bv.counters = (int*)sl.misc->ensure(256);
     if (!bv.counters) return fail(MQC_HIP_ERR_DEVICE, "out of device memory (counters)");
     bv.eri_count = (unsigned long long*)(bv.counters + 16);
@@ -278,7 +281,7 @@ static DevicePool g_guess_pool[2];
 
 int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, const std::vector<const double*>& xyz_in,
               const mqc_hip_scf_options_t& opts, std::vector<mqc_hip_scf_result_t*>& results_in, int lane,
-              const AtomicGuess* atomic_guess = nullptr)
+              const AtomicGuess* atomic_guess = nullptr, const std::vector<const mqc_hip_molecule_t*>* mols_in = nullptr)
 {
     // statistics are gathered locally and merged at the end (two lanes may run at once)
     struct StatsCtx { Stats stats; } local;
@@ -292,14 +295,25 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
     // the Schwarz ballot drop the same work in every lane, so whole waves skip it.
     std::vector<const double*> xyz(ntot);
     std::vector<mqc_hip_scf_result_t*> results(ntot);
+    // external point charges (FMO / EE-MBE embedding): the same count in every fragment of the group (part of its key)
+    const int npc = (mols_in && ntot > 0) ? (*mols_in)[0]->n_point_charges : 0;
+    std::vector<const mqc_hip_molecule_t*> pcmol(npc > 0 ? ntot : 0);
     {
         std::vector<std::pair<double, int>> key(ntot);
         for (int i = 0; i < ntot; ++i) key[i] = {-nuclear_repulsion(topo, xyz_in[i]), i};
         std::stable_sort(key.begin(), key.end());
         for (int k = 0; k < ntot; ++k) { xyz[k] = xyz_in[key[k].second]; results[k] = results_in[key[k].second]; }
+        if (npc > 0) for (int k = 0; k < ntot; ++k) pcmol[k] = (*mols_in)[key[k].second];
     }
     std::string msg;
     int rc = validate_options(opts, topo, msg);
+    if (rc == MQC_HIP_OK && npc > 0 && opts.want_gradient) {
+        msg = "analytic gradients of a fragment embedded in point charges are not built (the field's own derivative is missing)";
+        rc = MQC_HIP_ERR_UNSUPPORTED;
+    }
+    if (rc == MQC_HIP_OK && npc > 0)
+        for (int k = 0; k < ntot && rc == MQC_HIP_OK; ++k)
+            if (!pcmol[k]->point_charge_xyz || !pcmol[k]->point_charges) { msg = "point charges announced but their arrays are NULL"; rc = MQC_HIP_ERR_VALIDATION; }
     if (rc != MQC_HIP_OK) {
         for (auto* r : results) { fill_error(r, msg); r->scf_status = MQC_HIP_SCF_NOT_RUN; }
         return fail(rc, msg);
@@ -382,7 +396,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
     const int rad_pt = xc_tile_points(n);
     const size_t rad_tiles = xc.ncomp > 0 ? ((size_t)grid.npts + rad_pt - 1) / rad_pt : 0;
     const size_t rad_doubles = (xc.ncomp > 0 && rad_cache_on && !uhf_mem) ? rad_tiles * topo.shells.size() * 2 * rad_pt : 0;
-    const size_t per_frag = sizeof(double) * (per_fragment_main_doubles(n, topo.natoms, uhf_mem) + two_e + (xc.ncomp > 0 ? (size_t)n * n * (uhf_mem ? 2 : 1) + grid.npts : 0) + rad_doubles);
+    const size_t per_frag = sizeof(double) * (per_fragment_main_doubles(n, topo.natoms, uhf_mem, npc) + two_e + (xc.ncomp > 0 ? (size_t)n * n * (uhf_mem ? 2 : 1) + grid.npts : 0) + rad_doubles);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     free_b += ctx->pool_main.capacity() + ctx->pool_eri.capacity() + ctx->pool_df.capacity() + ctx->pool_gridw.capacity()
@@ -416,7 +430,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         {1, ctx->stream2, &ctx->pool_main2, &ctx->pool_eri2, &ctx->pool_misc2, &ctx->pool_gridw2, &ctx->pool_df2,
          ctx->evb0, ctx->evb1, ctx->evb2, ctx->evb3, ctx->evq2, ctx->evq3, h_counter + 32, ctx->evs[1][0], ctx->evs[1][1]}};
 
-    struct Job { int start = 0, nf = 0; BatchView bv{}; std::vector<double> hx; };
+    struct Job { int start = 0, nf = 0; BatchView bv{}; std::vector<double> hx, hpc; };
     std::vector<Job> jobs;
     for (int start = 0; start < ntot; start += (int)chunk) {
         Job j; j.start = start; j.nf = (int)std::min<long>(chunk, ntot - start);
@@ -438,7 +452,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         hipStream_t s = sl.s;
         const double t0 = now_s();
         BatchView& bv = job.bv;
-        int rc = carve_batch(ctx, sl, topo, td, nf, !use_df && !use_direct, bv, uhf);
+        int rc = carve_batch(ctx, sl, topo, td, nf, !use_df && !use_direct, bv, uhf, npc);
         if (rc != MQC_HIP_OK) return rc;
         bv.nalpha = nalpha; bv.nbeta = nbeta;
         bv.naux = naux; bv.aux = tdx; bv.unit = ctx->d_unit;
@@ -464,6 +478,18 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         job.hx.resize((size_t)nf * topo.natoms * 3);
         for (int f = 0; f < nf; ++f) std::memcpy(&job.hx[(size_t)f * topo.natoms * 3], xyz[job.start + f], sizeof(double) * topo.natoms * 3);
         HIP_CHECK_RET(hipMemcpyAsync(bv.xyz, job.hx.data(), sizeof(double) * job.hx.size(), hipMemcpyHostToDevice, s));
+        if (npc > 0) {
+            job.hpc.resize((size_t)nf * npc * 4);
+            for (int f = 0; f < nf; ++f) {
+                const mqc_hip_molecule_t* m = pcmol[job.start + f];
+                for (int g = 0; g < npc; ++g) {
+                    double* q = &job.hpc[((size_t)f * npc + g) * 4];
+                    q[0] = m->point_charge_xyz[3 * g]; q[1] = m->point_charge_xyz[3 * g + 1]; q[2] = m->point_charge_xyz[3 * g + 2];
+                    q[3] = m->point_charges[g];
+                }
+            }
+            HIP_CHECK_RET(hipMemcpyAsync((void*)bv.pc, job.hpc.data(), sizeof(double) * job.hpc.size(), hipMemcpyHostToDevice, s));
+        }
         HIP_CHECK_RET(hipMemsetAsync(bv.istate, 0, sizeof(int) * (size_t)nf * 4, s));
         HIP_CHECK_RET(hipMemsetAsync(bv.eri_count, 0, sizeof(unsigned long long), s));
         const double t1 = now_s();
@@ -746,6 +772,37 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
                 r->has_dipole = 1;
             }
             if (r->orbital_energies) std::memcpy(r->orbital_energies, &eps[(size_t)f * n], sizeof(double) * nmo);
+            if (npc > 0 || r->mulliken_charges) {
+                // what the embedded callers read besides the energy: tr(D u), u itself, Mulliken populations
+                // (inner_scf / fragment_charges, mqc_libcint_fmo.f90:1992-2021) -- n^2 host work on matrices copied back
+                const size_t nn = (size_t)n * n;
+                std::vector<double> hd(nn), hm(nn);
+                HIP_CHECK_RET(hipMemcpyAsync(hd.data(), bv.D + (size_t)f * nn, sizeof(double) * nn, hipMemcpyDeviceToHost, s));
+                HIP_CHECK_RET(hipStreamSynchronize(s));
+                if (uhf) {
+                    HIP_CHECK_RET(hipMemcpy(hm.data(), bv.Db + (size_t)f * nn, sizeof(double) * nn, hipMemcpyDeviceToHost));
+                    for (size_t k = 0; k < nn; ++k) hd[k] += hm[k];
+                }
+                if (npc > 0) {
+                    HIP_CHECK_RET(hipMemcpy(hm.data(), bv.U + (size_t)f * nn, sizeof(double) * nn, hipMemcpyDeviceToHost));
+                    double e = 0.0;
+                    for (size_t k = 0; k < nn; ++k) e += hd[k] * hm[k];
+                    r->e_embedding = e;
+                    if (r->embedding_matrix) std::memcpy(r->embedding_matrix, hm.data(), sizeof(double) * nn);
+                }
+                if (r->mulliken_charges) {
+                    HIP_CHECK_RET(hipMemcpy(hm.data(), bv.S + (size_t)f * nn, sizeof(double) * nn, hipMemcpyDeviceToHost));
+                    for (int a = 0; a < topo.natoms; ++a) r->mulliken_charges[a] = topo.zeff[a];
+                    for (size_t sh = 0; sh < topo.shells.size(); ++sh) {
+                        const int a = topo.shells[sh].atom, o0 = topo.shells[sh].aoff, nf_sh = 2 * topo.shells[sh].l + 1;
+                        for (int mu = o0; mu < o0 + nf_sh; ++mu) {
+                            double pop = 0.0;
+                            for (int nu = 0; nu < n; ++nu) pop += hd[(size_t)mu * n + nu] * hm[(size_t)nu * n + mu];
+                            r->mulliken_charges[a] -= pop;
+                        }
+                    }
+                }
+            }
             if (r->density) {
                 HIP_CHECK_RET(hipMemcpyAsync(r->density, bv.D + (size_t)f * n * n, sizeof(double) * n * n, hipMemcpyDeviceToHost, s));
                 HIP_CHECK_RET(hipStreamSynchronize(s));
@@ -1098,8 +1155,10 @@ int mqc_hip_get_stats(mqc_hip_context* ctx, mqc_hip_stats_t* st)
 static void init_result(mqc_hip_scf_result_t* r)
 {
     double* oe = r->orbital_energies; double* dn = r->density; double* gr = r->gradient; double* ob = r->orbital_energies_beta;
+    double* em = r->embedding_matrix; double* mq = r->mulliken_charges;
     std::memset(r, 0, sizeof(*r));
     r->orbital_energies = oe; r->density = dn; r->gradient = gr; r->orbital_energies_beta = ob;
+    r->embedding_matrix = em; r->mulliken_charges = mq;
     r->scf_status = MQC_HIP_SCF_NOT_RUN;
 }
 
@@ -1127,12 +1186,13 @@ int mqc_hip_scf_run_batch(mqc_hip_context* ctx, int64_t nfrag, const mqc_hip_mol
         // consecutive fragments that point at the very same element and basis arrays share their key
         const bool same_as_last = last >= 0 && mols[i].n_atoms == mols[last].n_atoms && mols[i].atomic_numbers == mols[last].atomic_numbers &&
                                   mols[i].ghost == mols[last].ghost && mols[i].nelec == mols[last].nelec && mols[i].charge == mols[last].charge &&
-                                  mols[i].multiplicity == mols[last].multiplicity &&
+                                  mols[i].multiplicity == mols[last].multiplicity && mols[i].n_point_charges == mols[last].n_point_charges &&
                                   std::memcmp(&orbitals[i], &orbitals[last], sizeof(mqc_hip_basis_t)) == 0 &&
                                   (!(opts->density_fitting && auxes) || std::memcmp(&auxes[i], &auxes[last], sizeof(mqc_hip_basis_t)) == 0);
         if (!same_as_last) {
             last_key = topology_key(mols[i], orbitals[i]);
             if (opts->density_fitting && auxes) last_key += "//" + topology_key(mols[i], auxes[i]);
+            if (mols[i].n_point_charges > 0) last_key += "//pc" + std::to_string(mols[i].n_point_charges);
             last_group = &groups[last_key];
         }
         last = i;
@@ -1146,6 +1206,7 @@ int mqc_hip_scf_run_batch(mqc_hip_context* ctx, int64_t nfrag, const mqc_hip_mol
         const std::vector<int64_t>* idx;
         std::shared_ptr<Topology> topo, aux;
         std::vector<const double*> xyz;
+        std::vector<const mqc_hip_molecule_t*> mol;
         std::vector<mqc_hip_scf_result_t*> res;
         std::shared_ptr<AtomicGuess> guess;
         int rc = MQC_HIP_OK;
@@ -1197,12 +1258,12 @@ int mqc_hip_scf_run_batch(mqc_hip_context* ctx, int64_t nfrag, const mqc_hip_mol
                 w.guess.reset();
             }
         }
-        for (auto i : idx) { w.xyz.push_back(mols[i].xyz); w.res.push_back(&results[i]); }
+        for (auto i : idx) { w.xyz.push_back(mols[i].xyz); w.mol.push_back(&mols[i]); w.res.push_back(&results[i]); }
         work.push_back(std::move(w));
     }
     auto run_one = [&](Work& w, int lane) {
         (void)hipSetDevice(ctx->device);
-        w.rc = run_batch(ctx, *w.topo, w.aux.get(), w.xyz, *opts, w.res, lane, w.guess.get());
+        w.rc = run_batch(ctx, *w.topo, w.aux.get(), w.xyz, *opts, w.res, lane, w.guess.get(), &w.mol);
         if (w.rc != MQC_HIP_OK) w.msg = mqc_hip_last_error();      // the error text is thread-local
     };
     if (work.size() >= 2 && ctx->concurrent_groups) {

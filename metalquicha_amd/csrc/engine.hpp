@@ -144,6 +144,9 @@ struct BatchView {      // plain pointers handed to kernels
     int* counters;                // [4]: n_not_done, ...
     unsigned long long* eri_count;   // [1]: shell quartets the integral kernels formed (Schwarz survivors), or nullptr
     double* dip;                  // [nfrag][4]: tr(D x), tr(D y), tr(D z) about the origin, -
+    int npc;                      // external point charges per fragment (0 = none)
+    const double* pc;             // [nfrag][npc][4] = x, y, z, q
+    double* U;                    // [nfrag][n*n] embedding operator -sum_g q_g/|r - R_g| (part of H), or nullptr
     int slot;                     // 0/1: which pipeline slot (stream, pools, launcher scratch) this batch view lives in
     XcSpec xc;                    // ncomp == 0: no XC term
     GridDev grid;

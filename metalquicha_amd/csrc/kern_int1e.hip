@@ -22,9 +22,11 @@ __device__ void int1e_block(const BatchView& bv, int f, int A, int B)
     const double ax = xyz[3 * atA], ay = xyz[3 * atA + 1], az = xyz[3 * atA + 2];
     const double bx = xyz[3 * atB], by = xyz[3 * atB + 1], bz = xyz[3 * atB + 2];
     const double ab2 = (ax - bx) * (ax - bx) + (ay - by) * (ay - by) + (az - bz) * (az - bz);
-    double sc[NCA * NCB], tc[NCA * NCB], vc[NCA * NCB];
+    double sc[NCA * NCB], tc[NCA * NCB], vc[NCA * NCB], uc[NCA * NCB];
 #pragma unroll
-    for (int i = 0; i < NCA * NCB; ++i) { sc[i] = 0.0; tc[i] = 0.0; vc[i] = 0.0; }
+    for (int i = 0; i < NCA * NCB; ++i) { sc[i] = 0.0; tc[i] = 0.0; vc[i] = 0.0; uc[i] = 0.0; }
+    const int npc = bv.npc;
+    const double* pc = bv.pc + (size_t)f * npc * 4;
     const int npa = tp.sh_nprim[A], npb = tp.sh_nprim[B];
     const double* ea = tp.exps + tp.sh_poff[A]; const double* ca = tp.coefs + tp.sh_poff[A];
     const double* eb = tp.exps + tp.sh_poff[B]; const double* cb = tp.coefs + tp.sh_poff[B];
@@ -61,12 +63,15 @@ __device__ void int1e_block(const BatchView& bv, int f, int A, int B)
                             ++iab;
                         }
                 }
-            // nuclear attraction: sum over (non-ghost) centres
-            for (int at = 0; at < tp.natoms; ++at) {
-                const double zq = tp.zeff[at];
+            // nuclear attraction: sum over (non-ghost) centres, then the external point charges of an embedded
+            // fragment (embedding_operator, mqc_libcint_fmo.f90:1143-1151), kept apart in uc
+            for (int at = 0; at < tp.natoms + npc; ++at) {
+                const bool ext = at >= tp.natoms;
+                const double* ctr = ext ? pc + 4 * (at - tp.natoms) : xyz + 3 * at;
+                const double zq = ext ? ctr[3] : tp.zeff[at];
                 if (zq == 0.0) continue;
                 double R[nherm(L)];
-                hermite_r<L>(p, px - xyz[3 * at], py - xyz[3 * at + 1], pz - xyz[3 * at + 2], bv.boys, R);
+                hermite_r<L>(p, px - ctr[0], py - ctr[1], pz - ctr[2], bv.boys, R);
                 const double pref = -zq * 2.0 * M_PI * ip_ * kab;
                 int k = 0;
 #pragma unroll
@@ -87,7 +92,8 @@ __device__ void int1e_block(const BatchView& bv, int f, int A, int B)
 #pragma unroll
                                         for (int w = 0; w <= i2 + j2; ++w)
                                             v += ex.get(i0, j0, t) * ey.get(i1, j1, u) * ez.get(i2, j2, w) * R[hidx(t, u, w)];
-                                vc[k] += pref * v;
+                                vc[k] += ext ? 0.0 : pref * v;
+                                uc[k] += ext ? pref * v : 0.0;
                                 ++k;
                             }
                     }
@@ -105,7 +111,7 @@ __device__ void int1e_block(const BatchView& bv, int f, int A, int B)
     for (int i = 0; i < NSA; ++i)
 #pragma unroll
         for (int j = 0; j < NSB; ++j) {
-            double s = 0.0, t = 0.0, v = 0.0;
+            double s = 0.0, t = 0.0, v = 0.0, u = 0.0;
 #pragma unroll
             for (int ia = 0; ia < NCA; ++ia) {
                 double wa = 1.0;
@@ -119,13 +125,15 @@ __device__ void int1e_block(const BatchView& bv, int f, int A, int B)
                     s += w * sc[ia * NCB + ib];
                     t += w * tc[ia * NCB + ib];
                     v += w * vc[ia * NCB + ib];
+                    u += w * uc[ia * NCB + ib];
                 }
             }
             const size_t ij = (size_t)(oa + i) * n + ob + j, ji = (size_t)(ob + j) * n + oa + i;
             S[ij] = s; S[ji] = s;
             T[ij] = t; T[ji] = t;
             V[ij] = v; V[ji] = v;
-            H[ij] = t + v; H[ji] = t + v;
+            H[ij] = t + v + u; H[ji] = t + v + u;
+            if (npc > 0) { double* U = bv.U + (size_t)f * n * n; U[ij] = u; U[ji] = u; }
         }
 }
 

@@ -276,9 +276,10 @@ def run_hip_scf(settings: ScfSettings, fragment: PhysicalFragment, result: Optio
         return result
 
 
-_MOL_DTYPE = np.dtype({"names": ["n_atoms", "atomic_numbers", "xyz", "ghost", "charge", "multiplicity", "nelec"],
-                       "formats": ["<i4", "<u8", "<u8", "<u8", "<i4", "<i4", "<i4"],
-                       "offsets": [0, 8, 16, 24, 32, 36, 40], "itemsize": C.sizeof(capi.Molecule)})
+_MOL_DTYPE = np.dtype({"names": ["n_atoms", "atomic_numbers", "xyz", "ghost", "charge", "multiplicity", "nelec",
+                                 "n_point_charges", "point_charge_xyz", "point_charges"],
+                       "formats": ["<i4", "<u8", "<u8", "<u8", "<i4", "<i4", "<i4", "<i4", "<u8", "<u8"],
+                       "offsets": [0, 8, 16, 24, 32, 36, 40, 44, 48, 56], "itemsize": C.sizeof(capi.Molecule)})
 _BAS_DTYPE = np.dtype({"names": ["spherical", "n_atoms", "nshell_per_atom", "n_shells", "shell_l", "shell_nprim",
                                  "exponents", "coefficients"],
                        "formats": ["<i4", "<i4", "<u8", "<i4", "<u8", "<u8", "<u8", "<u8"],
@@ -323,16 +324,22 @@ class FragmentGroup:
     multiplicity: Optional[np.ndarray] = None
     ghost: Optional[np.ndarray] = None     # (n_atoms,) bool, same for the whole group
     nelec: Optional[np.ndarray] = None     # (m,), default sum(Z of real atoms) - charge
+    point_charge_xyz: Optional[np.ndarray] = None   # (m, n_pc, 3) Bohr: the embedding field of an FMO / EE-MBE fragment
+    point_charges: Optional[np.ndarray] = None      # (m, n_pc)
 
 
 def run_hip_scf_groups(settings: ScfSettings, groups: Sequence[FragmentGroup], want_gradient: bool = False,
-                       gradients_out: Optional[list] = None) -> List[np.ndarray]:
+                       gradients_out: Optional[list] = None, extras: Sequence[str] = (),
+                       extras_out: Optional[list] = None) -> List[np.ndarray]:
     """All fragments of all groups in ONE mqc_hip_scf_run_batch call; returns, per group, a structured array
     viewing the engine's result records (fields of capi.ScfResult: e_total, iterations, has_error, message ...).
 
     The C structs are filled as numpy structured arrays with the header's exact layout
     (tests/test_host_logic.py checks the sizes), so marshalling a few thousand fragments is a
-    handful of vector operations rather than a Python loop over ctypes objects."""
+    handful of vector operations rather than a Python loop over ctypes objects.
+
+    `extras` names per-fragment arrays to bring back besides the records -- "density" (m, n, n), "embedding_matrix"
+    (m, n, n), "mulliken_charges" (m, n_atoms) -- appended to `extras_out` as one dict per group."""
     sizes = [int(g.xyz.shape[0]) for g in groups]
     n = int(sum(sizes))
     if n == 0:
@@ -372,6 +379,16 @@ def run_hip_scf_groups(settings: ScfSettings, groups: Sequence[FragmentGroup], w
         mols["charge"][sl] = charge
         mols["multiplicity"][sl] = 1 if g.multiplicity is None else np.asarray(g.multiplicity, dtype=np.int32)
         mols["nelec"][sl] = nelec
+        if g.point_charges is not None:
+            pq = np.ascontiguousarray(g.point_charges, dtype=np.float64)
+            px = np.ascontiguousarray(g.point_charge_xyz, dtype=np.float64)
+            npc = int(pq.shape[1])
+            if pq.shape != (m, npc) or px.shape != (m, npc, 3):
+                raise ValueError("FragmentGroup.point_charges must be (m, n_pc) with point_charge_xyz (m, n_pc, 3)")
+            keep += [pq, px]
+            mols["n_point_charges"][sl] = npc
+            mols["point_charges"][sl] = pq.ctypes.data + np.arange(m, dtype=np.uint64) * np.uint64(npc * 8)
+            mols["point_charge_xyz"][sl] = px.ctypes.data + np.arange(m, dtype=np.uint64) * np.uint64(npc * 3 * 8)
         bass[sl] = _basis_record(fb, na)
         if df:
             ab = _flat_basis_z(settings.aux_basis_set, z)
@@ -392,6 +409,25 @@ def run_hip_scf_groups(settings: ScfSettings, groups: Sequence[FragmentGroup], w
             lo += m
         if gradients_out is not None:
             gradients_out.extend(grads)
+    if extras:
+        rec0 = np.frombuffer(res, dtype=_RES_DTYPE)
+        lo = 0
+        for g, m in zip(groups, sizes):
+            z = np.ascontiguousarray(g.element_numbers, dtype=np.int32)
+            nao = _flat_basis_z(settings.basis_set, z).nao
+            got = {}
+            for name in extras:
+                if name not in ("density", "embedding_matrix", "mulliken_charges"):
+                    raise ValueError("unknown extra output " + name)
+                width = len(z) if name == "mulliken_charges" else nao * nao
+                arr = np.zeros((m, width))
+                if m:
+                    rec0[name][lo:lo + m] = arr.ctypes.data + np.arange(m, dtype=np.uint64) * np.uint64(width * 8)
+                got[name] = arr if name == "mulliken_charges" else arr.reshape(m, nao, nao)
+            lo += m
+            if extras_out is not None:
+                extras_out.append(got)
+            keep.append(got)
     rc = lib.mqc_hip_scf_run_batch(ctx, n, mols.ctypes.data_as(C.POINTER(capi.Molecule)),
                                    bass.ctypes.data_as(C.POINTER(capi.Basis)),
                                    auxs.ctypes.data_as(C.POINTER(capi.Basis)) if df else None, C.byref(opts), res)

@@ -166,6 +166,29 @@ def int1e(mol: OracleMol):
     return S, T, V
 
 
+def point_charge_potential(mol: OracleMol, points, charges) -> np.ndarray:
+    """u = -sum_g q_g <mu| 1/|r - R_g| |nu>: the point-charge part of the FMO embedding operator
+    (embedding_operator, backends/libcint/mqc_libcint_fmo.f90:1143-1151).  The nuclear-attraction routine with the
+    charges in the place of the nuclei is exactly this operator."""
+    n = mol.nao
+    S = np.zeros((n, n)); T = np.zeros((n, n)); U = np.zeros((n, n))
+    q = np.ascontiguousarray(charges, dtype=np.float64)
+    pts = np.ascontiguousarray(np.asarray(points, dtype=np.float64).reshape(-1, 3))
+    lib().orc_int1e(*mol._basis_args(), ctypes.c_int(len(q)), _dp(q), _dp(pts), _dp(S), _dp(T), _dp(U))
+    return U
+
+
+def mulliken_charges(mol: OracleMol, D, S) -> np.ndarray:
+    """q_A = Z_A - sum_{mu on A} (D S)_mu,mu (mulliken_charges via fragment_charges, mqc_libcint_fmo.f90:2001-2021)."""
+    pop = np.einsum("ij,ji->i", D, S)
+    q = np.array(mol.z, dtype=np.float64)
+    nf = nfun(mol.sh_l, mol.cart)
+    for sh in range(mol.nshell):
+        atom = int(np.argmin(np.sum((mol.xyz - mol.sh_xyz[sh]) ** 2, axis=1)))
+        q[atom] -= float(np.sum(pop[mol.sh_aoff[sh]: mol.sh_aoff[sh] + nf[sh]]))
+    return q
+
+
 def eri4(mol: OracleMol) -> np.ndarray:
     n = mol.nao
     eri = np.zeros((n, n, n, n))
@@ -360,8 +383,11 @@ class ScfResult:
 
 def run_rhf(mol: OracleMol, nelec: int, max_iter=100, e_tol=1e-8, d_tol=1e-6, diis_vectors=8,
             guess="gwh", aux: Optional[OracleMol] = None, xc=None, k_scale=1.0,
-            eri=None, B=None) -> ScfResult:
+            eri=None, B=None, h_extra=None) -> ScfResult:
     """Closed-shell SCF with the reference CPU path's semantics.
+
+    h_extra: optional one-electron operator added to H before anything else reads it
+        (mqc_libcint_rhf.f90:479-484), the FMO embedding field.
 
     xc: optional object with `.exx` (exact-exchange fraction) and
         `.potential(D) -> (exc, vxc)` (see oracle/xc_oracle.py).
@@ -371,6 +397,8 @@ def run_rhf(mol: OracleMol, nelec: int, max_iter=100, e_tol=1e-8, d_tol=1e-6, di
     nocc = nelec // 2
     S, T, V = int1e(mol)
     H = T + V
+    if h_extra is not None:
+        H = H + h_extra
     n = mol.nao
     if aux is not None and B is None:
         B = df_tensor(mol, aux)

@@ -89,3 +89,46 @@ def recorded_oracle(label, frag, settings_text, compute):
 def scf_record(o):
     return {"energy": float(o.energy), "iterations": int(o.iterations), "converged": bool(o.converged)}
 
+
+
+# ---- FMO / EE-MBE (point-charge embedding) -------------------------------------------------------------------------
+W3_ANGSTROM = np.array([[0, 0, 0], [0, -0.7572, 0.5865], [0, 0.7572, 0.5865],
+                        [0, 0, 2.9], [0, -0.7572, 3.4865], [0, 0.7572, 3.4865],
+                        [0, 0, 5.8], [0, -0.7572, 6.3865], [0, 0.7572, 6.3865]], dtype=float)
+EEMBE_W3_GOLDEN = -227.9704573337      # manifest row "EE-MBE water trimer 6-31g (CPU)", validation_tests_cpu.json:2194-2198
+
+
+def w3_system():
+    """The reference's three stacked waters (validation/inputs/sample_inputs/w3.xyz), fragments = molecules."""
+    from metalquicha_amd import mbe
+    return mbe.system_from_xyz(["O", "H", "H"] * 3, W3_ANGSTROM, [[0, 1, 2], [3, 4, 5], [6, 7, 8]])
+
+
+def oracle_make_mol(system, basis):
+    z = np.asarray(system.element_numbers); xyz = np.ascontiguousarray(system.coordinates.T)
+
+    def make(atoms):
+        atoms = list(atoms)
+        fb = build_flat_basis(basis, z[atoms], allow_cartesian=True)
+        return so.make_mol(z[atoms], xyz[atoms], fb.nshell_per_atom, fb.shell_l, fb.shell_nprim, fb.exps, fb.coefs,
+                           cart=not fb.spherical)
+    return make
+
+
+def oracle_fmo_solver(system, basis, e_tol=1e-9, d_tol=1e-7, max_iter=100):
+    """The CPU oracle behind fmo.run_fmo2's solver interface: lets the host logic be checked without a GPU."""
+    from metalquicha_amd.fmo import EmbeddedResult
+    make = oracle_make_mol(system, basis)
+    z = np.asarray(system.element_numbers); xyz = np.ascontiguousarray(system.coordinates.T)
+
+    def solve(jobs, q_all):
+        out = []
+        for job in jobs:
+            mol = make(job.atoms)
+            u = so.point_charge_potential(mol, xyz[list(job.field_atoms)], q_all[list(job.field_atoms)]) if job.field_atoms else None
+            r = so.run_rhf(mol, int(np.sum(z[list(job.atoms)])), max_iter=max_iter, e_tol=e_tol, d_tol=d_tol, guess="gwh", h_extra=u)
+            S, _, _ = so.int1e(mol)
+            out.append(EmbeddedResult(r.energy, float(np.sum(r.D * u)) if u is not None else 0.0, r.iterations, r.D,
+                                      so.mulliken_charges(mol, r.D, S), u))
+        return out
+    return solve

@@ -1,0 +1,84 @@
+"""FMO2 / EE-MBE with point-charge embedding, no GPU: the oracle against the reference's golden energy, the host driver
+(metalquicha_amd/fmo.py) against the oracle through an oracle-backed solver, and its two-rank exchange over gloo."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from metalquicha_amd import fmo
+from metalquicha_amd.methods import ScfSettings
+from oracle import fmo_oracle, scf_oracle as so
+from tests.helpers import EEMBE_W3_GOLDEN, oracle_fmo_solver, oracle_make_mol, w3_system
+
+FRAGS = [[0, 1, 2], [3, 4, 5], [6, 7, 8]]
+
+
+def _oracle(expansion):
+    system = w3_system()
+    return fmo_oracle.run_fmo2(oracle_make_mol(system, "6-31g"), np.asarray(system.element_numbers),
+                               np.ascontiguousarray(system.coordinates.T), FRAGS, expansion=expansion)
+
+
+def test_oracle_reproduces_the_reference_eembe_water_trimer():
+    r = _oracle("mbe")
+    assert r.converged
+    assert abs(r.energy - EEMBE_W3_GOLDEN) < 1e-9
+    assert r.response_sum == 0.0                       # EE-MBE carries no response term (nmer_term, :1266-1272)
+
+
+def test_point_charge_operator_is_the_nuclear_attraction_of_the_charges():
+    system = w3_system()
+    mol = oracle_make_mol(system, "6-31g")([0, 1, 2])
+    _, _, V = so.int1e(mol)
+    assert np.allclose(so.point_charge_potential(mol, mol.xyz, mol.z), V, atol=1e-13)
+    S, _, _ = so.int1e(mol)
+    r = so.run_rhf(mol, 10)
+    q = so.mulliken_charges(mol, r.D, S)
+    assert abs(np.sum(q)) < 1e-9 and q[0] < 0 < q[1]
+
+
+def test_host_driver_equals_the_oracle_for_both_expansions():
+    system = w3_system()
+    for expansion in ("mbe", "fmo"):
+        ref = _oracle(expansion)
+        run = fmo.run_fmo2(system, ScfSettings(basis_set="6-31g"), expansion=expansion, solver=oracle_fmo_solver(system, "6-31g"))
+        assert run.converged and run.outer_iterations == ref.outer_iterations
+        assert abs(run.energy - ref.energy) < 1e-11
+        assert abs(run.response_sum - ref.response_sum) < 1e-11
+        assert np.allclose(run.charges, ref.charges, atol=1e-11)
+        assert np.allclose(run.monomer_energy, ref.monomer_energy, atol=1e-11)
+    assert abs(run.response_sum) > 1e-5                # the fmo expansion's response is not zero for three fragments
+
+
+def test_two_rank_gloo_fmo_equals_serial(tmp_path):
+    """world_size = 2 over gloo: fragments and pairs round-robin over the ranks, one all-reduce per pass
+    (exchange_monomers, mqc_libcint_fmo.f90:1890-1948); both ranks must end on the serial energy."""
+    script = tmp_path / "rank.py"
+    script.write_text(
+        "import sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import numpy as np, torch, torch.distributed as dist\n"
+        "from metalquicha_amd import fmo\n"
+        "from metalquicha_amd.methods import ScfSettings\n"
+        "from tests.helpers import oracle_fmo_solver, w3_system\n"
+        "dist.init_process_group('gloo', init_method='env://')\n"
+        "r, w = dist.get_rank(), dist.get_world_size()\n"
+        "def allreduce(a):\n"
+        "    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).copy()); dist.all_reduce(t); return t.numpy()\n"
+        "system = w3_system(); solver = oracle_fmo_solver(system, '6-31g')\n"
+        "for expansion in ('mbe', 'fmo'):\n"
+        "    par = fmo.run_fmo2(system, ScfSettings(basis_set='6-31g'), expansion=expansion, rank=r, world=w, allreduce=allreduce, solver=solver)\n"
+        "    ser = fmo.run_fmo2(system, ScfSettings(basis_set='6-31g'), expansion=expansion, solver=solver)\n"
+        "    assert abs(par.energy - ser.energy) < 1e-11, (par.energy, ser.energy)\n"
+        "    assert abs(par.response_sum - ser.response_sum) < 1e-11\n"
+        "print('rank', r, 'ok')\n"
+        "dist.destroy_process_group()\n" % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29537")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29537", str(script)],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("ok") == 2

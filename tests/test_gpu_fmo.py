@@ -1,0 +1,101 @@
+"""GPU parity tests of the embedded callers: point charges in the one-electron Hamiltonian
+through the C ABI (ABI 3), and FMO2 / EE-MBE of whole-molecule fragments through fmo.run_fmo2 -> engine batch calls,
+against the oracle and the reference's golden energy for the EE-MBE water trimer."""
+import numpy as np
+import pytest
+
+from metalquicha_amd import fmo, mbe, methods
+from metalquicha_amd.methods import FragmentGroup, ScfSettings
+from oracle import fmo_oracle, scf_oracle as so
+from tests.helpers import EEMBE_W3_GOLDEN, oracle_make_mol, w3_system
+
+pytestmark = pytest.mark.gpu
+
+FRAGS = [[0, 1, 2], [3, 4, 5], [6, 7, 8]]
+
+
+def _settings(basis="6-31g", **kw):
+    return ScfSettings(basis_set=basis, energy_tol=1e-9, density_tol=1e-7, guess="gwh", **kw)
+
+
+@pytest.mark.parametrize("basis", ["6-31g", "cc-pvdz"])
+def test_embedded_fragment_matches_oracle(basis):
+    """One water and one water pair of the trimer in the field of made-up charges on the other atoms: energy, tr(D u),
+    u itself, the density and the Mulliken charges (1e-9 / 1e-8 on matrices), and a second fragment of the same
+    batch in vacuum-like zero charges giving the plain RHF energy."""
+    system = w3_system()
+    z = np.asarray(system.element_numbers); xyz = np.ascontiguousarray(system.coordinates.T)
+    rng = np.random.default_rng(5)
+    make = oracle_make_mol(system, basis)
+    for atoms in ([0, 1, 2], [0, 1, 2, 3, 4, 5]):
+        out = [a for a in range(9) if a not in atoms]
+        q = np.stack([rng.uniform(-0.8, 0.8, size=len(out)), np.zeros(len(out))])
+        g = FragmentGroup(z[atoms].astype(np.int32), np.stack([xyz[atoms]] * 2), np.zeros(2, dtype=np.int32),
+                          point_charge_xyz=np.stack([xyz[out]] * 2), point_charges=q)
+        extras = []
+        rec = methods.run_hip_scf_groups(_settings(basis), [g], extras=("density", "embedding_matrix", "mulliken_charges"),
+                                         extras_out=extras)[0]
+        assert not rec["has_error"].any(), rec["message"]
+        mol = make(atoms)
+        u = so.point_charge_potential(mol, xyz[out], q[0])
+        ref = so.run_rhf(mol, int(np.sum(z[atoms])), e_tol=1e-9, d_tol=1e-7, h_extra=u)
+        vac = so.run_rhf(mol, int(np.sum(z[atoms])), e_tol=1e-9, d_tol=1e-7)
+        S, _, _ = so.int1e(mol)
+        assert abs(rec["e_total"][0] - ref.energy) < 1e-9
+        assert rec["iterations"][0] == ref.iterations
+        assert abs(rec["e_embedding"][0] - float(np.sum(ref.D * u))) < 1e-9
+        assert np.max(np.abs(extras[0]["embedding_matrix"][0] - u)) < 1e-11
+        assert np.max(np.abs(extras[0]["density"][0] - ref.D)) < 1e-7
+        assert np.max(np.abs(extras[0]["mulliken_charges"][0] - so.mulliken_charges(mol, ref.D, S))) < 1e-7
+        assert abs(rec["e_total"][1] - vac.energy) < 1e-9 and abs(rec["e_embedding"][1]) < 1e-14
+        assert abs(rec["e_nuclear"][0] - so.nuclear_repulsion(mol)) < 1e-10      # the charges stay out of E_nuc
+
+
+def test_eembe_water_trimer_reference_golden():
+    """validation_tests_cpu.json 'EE-MBE water trimer 6-31g (CPU)' = -227.9704573337: monomer passes and the pair
+    phase as engine batches, Mulliken charges from the engine."""
+    system = w3_system()
+    run = fmo.run_fmo2(system, _settings(), expansion="mbe")
+    assert not run.errors, run.errors
+    assert run.converged
+    assert abs(run.energy - EEMBE_W3_GOLDEN) < 1e-8
+    ref = fmo_oracle.run_fmo2(oracle_make_mol(system, "6-31g"), np.asarray(system.element_numbers),
+                              np.ascontiguousarray(system.coordinates.T), FRAGS, expansion="mbe")
+    assert run.outer_iterations == ref.outer_iterations
+    assert abs(run.energy - ref.energy) < 1e-9
+    assert np.max(np.abs(run.charges - ref.charges)) < 1e-7
+
+
+def test_fmo2_point_charge_water_trimer_matches_oracle():
+    system = w3_system()
+    run = fmo.run_fmo2(system, _settings(), expansion="fmo")
+    assert not run.errors, run.errors
+    ref = fmo_oracle.run_fmo2(oracle_make_mol(system, "6-31g"), np.asarray(system.element_numbers),
+                              np.ascontiguousarray(system.coordinates.T), FRAGS, expansion="fmo")
+    assert run.converged and run.outer_iterations == ref.outer_iterations
+    assert abs(run.energy - ref.energy) < 1e-9
+    assert abs(run.response_sum - ref.response_sum) < 1e-9
+    for p, c in ref.pair_corrections.items():
+        assert abs(run.pair_corrections[p] - c) < 1e-9
+
+
+def test_eembe_water_cluster_matches_oracle():
+    """(H2O)8 of the bench's cluster builder, cc-pVDZ: 8 monomers x passes + 28 pairs, every pass one batch."""
+    system = mbe.water_cluster(2, seed=11)
+    frags = [list(map(int, m)) for m in system.monomers]
+    run = fmo.run_fmo2(system, _settings("cc-pvdz"), expansion="mbe")
+    assert not run.errors, run.errors
+    ref = fmo_oracle.run_fmo2(oracle_make_mol(system, "cc-pvdz"), np.asarray(system.element_numbers),
+                              np.ascontiguousarray(system.coordinates.T), frags, expansion="mbe")
+    assert run.converged and run.outer_iterations == ref.outer_iterations
+    assert abs(run.energy - ref.energy) < 2e-9
+    assert np.max(np.abs(run.monomer_energy - ref.monomer_energy)) < 1e-9
+
+
+def test_embedded_gradient_is_refused():
+    system = w3_system()
+    z = np.asarray(system.element_numbers); xyz = np.ascontiguousarray(system.coordinates.T)
+    g = FragmentGroup(z[:3].astype(np.int32), xyz[None, :3], np.zeros(1, dtype=np.int32),
+                      point_charge_xyz=xyz[None, 3:], point_charges=np.full((1, 6), 0.1))
+    rec = methods.run_hip_scf_groups(_settings(), [g], want_gradient=True, gradients_out=[])[0]
+    assert rec["has_error"][0] and b"point charges" in bytes(rec["message"][0])

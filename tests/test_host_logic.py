@@ -44,7 +44,7 @@ def test_capi_exports_every_declared_symbol():
     assert declared == set(capi.DECLARED_SYMBOLS)
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert lib.mqc_hip_abi_version() == 2
+    assert lib.mqc_hip_abi_version() == 3
 
 
 def test_engine_fails_loudly_without_a_device():
@@ -255,7 +255,7 @@ def test_fortran_iso_c_binding_module_links():
         pytest.skip("no flang in this image")
     out = subprocess.run(["bash", os.path.join(ROOT, "fortran", "check_link.sh")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "abi version 2" in out.stdout
+    assert "abi version 3" in out.stdout
 
 
 def test_vectorised_marshalling_layouts_match_ctypes():
