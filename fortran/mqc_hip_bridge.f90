@@ -98,6 +98,7 @@ contains
       mol%charge = fragment%charge; mol%multiplicity = fragment%multiplicity; mol%nelec = fragment%nelec
       mol%ghost = c_null_ptr
       mol%n_point_charges = 0; mol%point_charge_xyz = c_null_ptr; mol%point_charges = c_null_ptr
+      mol%h_extra = c_null_ptr
       if (allocated(fragment%is_ghost)) then
          allocate (ghost(fragment%n_atoms))
          ghost = merge(1_c_int8_t, 0_c_int8_t, fragment%is_ghost)

@@ -30,6 +30,7 @@ module mqc_hip_c
       integer(c_int32_t) :: n_point_charges = 0
       type(c_ptr) :: point_charge_xyz = c_null_ptr   !! double [3*n_point_charges], Bohr
       type(c_ptr) :: point_charges = c_null_ptr      !! double [n_point_charges]
+      type(c_ptr) :: h_extra = c_null_ptr            !! double [n_ao*n_ao] or c_null_ptr: run_libcint_rhf's h_extra
    end type
 
    type, bind(C), public :: mqc_hip_basis_t

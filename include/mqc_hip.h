@@ -83,6 +83,10 @@ typedef struct {
     int32_t n_point_charges;         /* 0 = none */
     const double *point_charge_xyz;  /* [3*n_point_charges], Bohr */
     const double *point_charges;     /* [n_point_charges] */
+    const double *h_extra;           /* [n_ao*n_ao] row-major symmetric, or NULL: any further one-electron operator added to
+                                        H as it stands (run_libcint_rhf's h_extra) -- the exact Coulomb field of near
+                                        fragments' electrons in FMO (local_coulomb, mqc_libcint_fmo.f90:1337-1406).
+                                        Counted in e_embedding and embedding_matrix together with the charges' part. */
 } mqc_hip_molecule_t;
 
 /* molecular_basis_type flattened (src/basis/mqc_cgto.f90); RAW Basis-Set-Exchange

@@ -33,7 +33,8 @@ class Molecule(C.Structure):
                 ("ghost", c_uint8_p), ("charge", C.c_int32), ("multiplicity", C.c_int32),
                 ("nelec", C.c_int32),
                 # ABI 3: external point charges (embedding field of the FMO / EE-MBE callers)
-                ("n_point_charges", C.c_int32), ("point_charge_xyz", c_double_p), ("point_charges", c_double_p)]
+                ("n_point_charges", C.c_int32), ("point_charge_xyz", c_double_p), ("point_charges", c_double_p),
+                ("h_extra", c_double_p)]
 
 
 class Basis(C.Structure):

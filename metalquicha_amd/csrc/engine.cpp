@@ -137,10 +137,11 @@ static int upload_topology(mqc_hip_context* ctx, const Topology& topo, TopologyD
     return MQC_HIP_OK;
 }
 
-static size_t per_fragment_main_doubles(int n, int natoms, bool uhf = false, int npc = 0)
+static size_t per_fragment_main_doubles(int n, int natoms, bool uhf = false, int npc = 0, bool hx = false)
 {
     const size_t nn = (size_t)n * n;
-    return (npc > 0 ? nn + 4 * (size_t)npc + 64 : 0)   // embedding operator U and the point charges (x, y, z, q)
+    return ((npc > 0 || hx) ? nn + 4 * (size_t)npc + 64 : 0)   // embedding operator U and the point charges (x, y, z, q)
+           + (hx ? nn + 32 : 0)                                  // the caller's h_extra
            + (uhf ? 6 * nn + 2 * DIIS_MAX * nn + n : 0)   // beta spin: D C F J K Vprev, DIIS histories, eps
            + 9 * nn    // S H X F D C J K Vprev
            + 6 * nn    // W
@@ -162,11 +163,11 @@ struct Slot {
 
 // carve one chunk's arrays out of the slot's pools
 static int carve_batch(mqc_hip_context* ctx, Slot& sl, const Topology& topo, const TopologyDev& td, int nfrag, bool with_eri, BatchView& bv,
-                       bool uhf = false, int npc = 0)
+                       bool uhf = false, int npc = 0, bool hx = false)
 {
     const int n = topo.nao;
     const size_t nn = (size_t)n * n, nf = (size_t)nfrag;
-    const size_t main_bytes = sizeof(double) * nf * per_fragment_main_doubles(n, topo.natoms, uhf, npc) + 16384;
+    const size_t main_bytes = sizeof(double) * nf * per_fragment_main_doubles(n, topo.natoms, uhf, npc, hx) + 16384;
     char* base = (char*)sl.main->ensure(main_bytes);
     if (!base) return fail(MQC_HIP_ERR_DEVICE, "out of device memory (SCF matrices)");
     auto take = [&base](size_t b) { char* p = base; base += (b + 255) & ~size_t(255); return p; };
@@ -197,8 +198,10 @@ static int carve_batch(mqc_hip_context* ctx, Slot& sl, const Topology& topo, con
     }
     bv.diis_state = (int*)take(sizeof(int) * nf * 2);
     bv.istate = (int*)take(sizeof(int) * nf * 4);
-    bv.npc = npc; bv.pc = nullptr; bv.U = nullptr;
-    if (npc > 0) { bv.pc = (double*)take(sizeof(double) * nf * npc * 4); bv.U = (double*)take(sizeof(double) * nf * nn); }
+    bv.npc = npc; bv.pc = nullptr; bv.U = nullptr; bv.Hx = nullptr;
+    if (npc > 0) bv.pc = (double*)take(sizeof(double) * nf * npc * 4);
+    if (npc > 0 || hx) bv.U = (double*)take(sizeof(double) * nf * nn);
+    if (hx) bv.Hx = (double*)take(sizeof(double) * nf * nn);
     bv.counters = (int*)sl.misc->ensure(256);
     if (!bv.counters) return fail(MQC_HIP_ERR_DEVICE, "out of device memory (counters)");
     bv.eri_count = (unsigned long long*)(bv.counters + 16);
@@ -297,18 +300,20 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
     std::vector<mqc_hip_scf_result_t*> results(ntot);
     // external point charges (FMO / EE-MBE embedding): the same count in every fragment of the group (part of its key)
     const int npc = (mols_in && ntot > 0) ? (*mols_in)[0]->n_point_charges : 0;
-    std::vector<const mqc_hip_molecule_t*> pcmol(npc > 0 ? ntot : 0);
+    const bool hx = mols_in && ntot > 0 && (*mols_in)[0]->h_extra != nullptr;     // all or none within a group (its key says so)
+    const bool embedded = npc > 0 || hx;
+    std::vector<const mqc_hip_molecule_t*> pcmol(embedded ? ntot : 0);
     {
         std::vector<std::pair<double, int>> key(ntot);
         for (int i = 0; i < ntot; ++i) key[i] = {-nuclear_repulsion(topo, xyz_in[i]), i};
         std::stable_sort(key.begin(), key.end());
         for (int k = 0; k < ntot; ++k) { xyz[k] = xyz_in[key[k].second]; results[k] = results_in[key[k].second]; }
-        if (npc > 0) for (int k = 0; k < ntot; ++k) pcmol[k] = (*mols_in)[key[k].second];
+        if (embedded) for (int k = 0; k < ntot; ++k) pcmol[k] = (*mols_in)[key[k].second];
     }
     std::string msg;
     int rc = validate_options(opts, topo, msg);
-    if (rc == MQC_HIP_OK && npc > 0 && opts.want_gradient) {
-        msg = "analytic gradients of a fragment embedded in point charges are not built (the field's own derivative is missing)";
+    if (rc == MQC_HIP_OK && embedded && opts.want_gradient) {
+        msg = "analytic gradients of a fragment embedded in point charges or an extra one-electron operator are not built (the field's own derivative is missing)";
         rc = MQC_HIP_ERR_UNSUPPORTED;
     }
     if (rc == MQC_HIP_OK && npc > 0)
@@ -396,7 +401,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
     const int rad_pt = xc_tile_points(n);
     const size_t rad_tiles = xc.ncomp > 0 ? ((size_t)grid.npts + rad_pt - 1) / rad_pt : 0;
     const size_t rad_doubles = (xc.ncomp > 0 && rad_cache_on && !uhf_mem) ? rad_tiles * topo.shells.size() * 2 * rad_pt : 0;
-    const size_t per_frag = sizeof(double) * (per_fragment_main_doubles(n, topo.natoms, uhf_mem, npc) + two_e + (xc.ncomp > 0 ? (size_t)n * n * (uhf_mem ? 2 : 1) + grid.npts : 0) + rad_doubles);
+    const size_t per_frag = sizeof(double) * (per_fragment_main_doubles(n, topo.natoms, uhf_mem, npc, hx) + two_e + (xc.ncomp > 0 ? (size_t)n * n * (uhf_mem ? 2 : 1) + grid.npts : 0) + rad_doubles);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     free_b += ctx->pool_main.capacity() + ctx->pool_eri.capacity() + ctx->pool_df.capacity() + ctx->pool_gridw.capacity()
@@ -452,7 +457,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         hipStream_t s = sl.s;
         const double t0 = now_s();
         BatchView& bv = job.bv;
-        int rc = carve_batch(ctx, sl, topo, td, nf, !use_df && !use_direct, bv, uhf, npc);
+        int rc = carve_batch(ctx, sl, topo, td, nf, !use_df && !use_direct, bv, uhf, npc, hx);
         if (rc != MQC_HIP_OK) return rc;
         bv.nalpha = nalpha; bv.nbeta = nbeta;
         bv.naux = naux; bv.aux = tdx; bv.unit = ctx->d_unit;
@@ -490,6 +495,9 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
             }
             HIP_CHECK_RET(hipMemcpyAsync((void*)bv.pc, job.hpc.data(), sizeof(double) * job.hpc.size(), hipMemcpyHostToDevice, s));
         }
+        if (hx)
+            for (int f = 0; f < nf; ++f)
+                HIP_CHECK_RET(hipMemcpyAsync((void*)(bv.Hx + (size_t)f * n * n), pcmol[job.start + f]->h_extra, sizeof(double) * n * n, hipMemcpyHostToDevice, s));
         HIP_CHECK_RET(hipMemsetAsync(bv.istate, 0, sizeof(int) * (size_t)nf * 4, s));
         HIP_CHECK_RET(hipMemsetAsync(bv.eri_count, 0, sizeof(unsigned long long), s));
         const double t1 = now_s();
@@ -772,7 +780,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
                 r->has_dipole = 1;
             }
             if (r->orbital_energies) std::memcpy(r->orbital_energies, &eps[(size_t)f * n], sizeof(double) * nmo);
-            if (npc > 0 || r->mulliken_charges) {
+            if (embedded || r->mulliken_charges) {
                 // what the embedded callers read besides the energy: tr(D u), u itself, Mulliken populations
                 // (inner_scf / fragment_charges, mqc_libcint_fmo.f90:1992-2021) -- n^2 host work on matrices copied back
                 const size_t nn = (size_t)n * n;
@@ -783,7 +791,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
                     HIP_CHECK_RET(hipMemcpy(hm.data(), bv.Db + (size_t)f * nn, sizeof(double) * nn, hipMemcpyDeviceToHost));
                     for (size_t k = 0; k < nn; ++k) hd[k] += hm[k];
                 }
-                if (npc > 0) {
+                if (embedded) {
                     HIP_CHECK_RET(hipMemcpy(hm.data(), bv.U + (size_t)f * nn, sizeof(double) * nn, hipMemcpyDeviceToHost));
                     double e = 0.0;
                     for (size_t k = 0; k < nn; ++k) e += hd[k] * hm[k];
@@ -1186,13 +1194,14 @@ int mqc_hip_scf_run_batch(mqc_hip_context* ctx, int64_t nfrag, const mqc_hip_mol
         // consecutive fragments that point at the very same element and basis arrays share their key
         const bool same_as_last = last >= 0 && mols[i].n_atoms == mols[last].n_atoms && mols[i].atomic_numbers == mols[last].atomic_numbers &&
                                   mols[i].ghost == mols[last].ghost && mols[i].nelec == mols[last].nelec && mols[i].charge == mols[last].charge &&
-                                  mols[i].multiplicity == mols[last].multiplicity && mols[i].n_point_charges == mols[last].n_point_charges &&
+                                  mols[i].multiplicity == mols[last].multiplicity && mols[i].n_point_charges == mols[last].n_point_charges && (mols[i].h_extra != nullptr) == (mols[last].h_extra != nullptr) &&
                                   std::memcmp(&orbitals[i], &orbitals[last], sizeof(mqc_hip_basis_t)) == 0 &&
                                   (!(opts->density_fitting && auxes) || std::memcmp(&auxes[i], &auxes[last], sizeof(mqc_hip_basis_t)) == 0);
         if (!same_as_last) {
             last_key = topology_key(mols[i], orbitals[i]);
             if (opts->density_fitting && auxes) last_key += "//" + topology_key(mols[i], auxes[i]);
             if (mols[i].n_point_charges > 0) last_key += "//pc" + std::to_string(mols[i].n_point_charges);
+            if (mols[i].h_extra) last_key += "//hx";
             last_group = &groups[last_key];
         }
         last = i;

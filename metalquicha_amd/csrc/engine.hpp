@@ -146,7 +146,8 @@ struct BatchView {      // plain pointers handed to kernels
     double* dip;                  // [nfrag][4]: tr(D x), tr(D y), tr(D z) about the origin, -
     int npc;                      // external point charges per fragment (0 = none)
     const double* pc;             // [nfrag][npc][4] = x, y, z, q
-    double* U;                    // [nfrag][n*n] embedding operator -sum_g q_g/|r - R_g| (part of H), or nullptr
+    double* U;                    // [nfrag][n*n] embedding operator -sum_g q_g/|r - R_g| + h_extra (part of H), or nullptr
+    const double* Hx;             // [nfrag][n*n] the caller's h_extra matrices, or nullptr
     int slot;                     // 0/1: which pipeline slot (stream, pools, launcher scratch) this batch view lives in
     XcSpec xc;                    // ncomp == 0: no XC term
     GridDev grid;

@@ -132,8 +132,10 @@ __device__ void int1e_block(const BatchView& bv, int f, int A, int B)
             S[ij] = s; S[ji] = s;
             T[ij] = t; T[ji] = t;
             V[ij] = v; V[ji] = v;
-            H[ij] = t + v + u; H[ji] = t + v + u;
-            if (npc > 0) { double* U = bv.U + (size_t)f * n * n; U[ij] = u; U[ji] = u; }
+            double uij = u, uji = u;
+            if (bv.Hx) { const double* hx = bv.Hx + (size_t)f * n * n; uij += hx[ij]; uji += hx[ji]; }
+            H[ij] = t + v + uij; H[ji] = t + v + uji;
+            if (bv.U) { double* U = bv.U + (size_t)f * n * n; U[ij] = uij; U[ji] = uji; }
         }
 }
 

@@ -16,8 +16,14 @@ bookkeeping the reference's Fortran host code does:
   e_resp = tr((D - D_I (+) D_J) u) for the "fmo" expansion; E_scf as it stands for the "mbe" (EE-MBE) expansion;
 * `calculate_polymers` (:1566-1689) at level 2: dE_IJ = e_internal + e_resp - E_I - E_J, total = sum E_I + sum dE_IJ.
 
-Scope: whole-molecule fragments (no severed bonds, caps or AFO projector), closed shells, level 2, esp = "ptc" with
-Mulliken charges -- the exact-ESP operator of near fragments (`local_coulomb`) and CHELPG stay with the reference.
+* `esp = "exact"` (the reference's default for FMO): fragments within `resppc` van der Waals sums (`near_fragments`,
+  :1276-1316) give their bare nuclei as charges and their electrons through the exact Coulomb operator J[D_K] in the
+  fragment's basis (`local_coulomb`, :1337-1406: the J build over the supersystem fragment + neighbour with only the
+  neighbour's block of the density filled); here J comes from the engine's in-core J/K kernel (`mqc_hip_jk_incore`) on
+  the same supersystem and enters the SCF as `h_extra` (ABI 3); the far fragments stay Mulliken charges.
+
+Scope: whole-molecule fragments (no severed bonds, caps or AFO projector), closed shells, level 2, Mulliken far field
+-- CHELPG charges stay with the reference.
 """
 from __future__ import annotations
 
@@ -34,7 +40,9 @@ from .methods import FragmentGroup, ScfSettings
 @dataclass
 class EmbeddedJob:
     atoms: Tuple[int, ...]                   # atoms of the fragment / pair, in basis order
-    field_atoms: Tuple[int, ...] = ()        # outside atoms whose charges make the field (empty = in vacuum)
+    field_atoms: Tuple[int, ...] = ()        # outside atoms that act as point charges (empty = none)
+    field_charges: Optional[np.ndarray] = None   # their weights: Mulliken charge (far) or bare nuclear charge (near)
+    h_extra: Optional[np.ndarray] = None     # (n, n): the near fragments' exact Coulomb operator, or None
 
 
 @dataclass
@@ -48,7 +56,55 @@ class EmbeddedResult:
     error: str = ""
 
 
-Solver = Callable[[Sequence[EmbeddedJob], np.ndarray], List[EmbeddedResult]]
+Solver = Callable[[Sequence[EmbeddedJob]], List[EmbeddedResult]]
+Coulomb = Callable[[Sequence[int], Sequence[int], np.ndarray], np.ndarray]
+
+# Bondi's van der Waals radii with Rowland and Taylor's hydrogen, Angstrom, Z = 1..18 (src/core/mqc_elements.f90:58-60)
+VDW_ANGSTROM = (1.10, 1.40, 1.81, 1.53, 1.92, 1.70, 1.55, 1.52, 1.47, 1.54, 2.27, 1.73, 1.84, 2.10, 1.80, 1.80, 1.75, 1.88)
+
+
+def near_fragments(system: FragmentedSystem, group: Sequence[int], resppc: float) -> List[int]:
+    """Fragments outside `group` treated exactly: closest atom pair within `resppc` sums of van der Waals radii; all of
+    them when resppc < 0 (near_fragments / unitless_distance, mqc_libcint_fmo.f90:1276-1335)."""
+    from .basis import ANGSTROM_TO_BOHR
+    z = np.asarray(system.element_numbers); xyz = system.coordinates.T
+    inside = [int(a) for g in group for a in system.monomers[g]]
+    near = []
+    for k in range(system.n_monomers):
+        if k in group:
+            continue
+        if resppc < 0.0:
+            near.append(k); continue
+        other = [int(b) for b in system.monomers[k]]
+        if max(int(z[a]) for a in inside + other) > len(VDW_ANGSTROM):
+            raise ValueError("fmo: no van der Waals radius tabulated here for an element of fragment %d" % k)
+        d = np.linalg.norm(xyz[inside][:, None, :] - xyz[other][None, :, :], axis=2)
+        scale = (np.array([VDW_ANGSTROM[int(z[a]) - 1] for a in inside])[:, None]
+                 + np.array([VDW_ANGSTROM[int(z[b]) - 1] for b in other])[None, :]) * ANGSTROM_TO_BOHR
+        if float(np.min(d / scale)) <= resppc:
+            near.append(k)
+    return near
+
+
+def hip_cross_coulomb(system: FragmentedSystem, settings: ScfSettings) -> Coulomb:
+    """J[D_K] of a neighbour's electrons in the basis of `atoms`: the engine's in-core J/K kernel on the supersystem
+    atoms + neighbour with only the neighbour's block of the density filled, leading block of J (local_coulomb)."""
+    import ctypes as C
+    from . import capi
+    from .methods import PhysicalFragment, _Marshalled, _flat_basis
+
+    def coulomb(atoms: Sequence[int], other: Sequence[int], d_other: np.ndarray) -> np.ndarray:
+        idx = list(atoms) + list(other)
+        frag = PhysicalFragment(np.asarray(system.element_numbers)[idx], system.coordinates[:, idx])
+        m = _Marshalled(frag, _flat_basis(settings.basis_set, frag))
+        n, nk = m.fb.nao, d_other.shape[0]
+        D = np.zeros((n, n)); D[n - nk:, n - nk:] = d_other
+        J, K = np.zeros((n, n)), np.zeros((n, n))
+        capi.check(capi.load_library().mqc_hip_jk_incore(capi.get_context(settings.device_rank), C.byref(m.mol), C.byref(m.bas),
+                                                         capi.dptr(D), capi.dptr(J), capi.dptr(K)))
+        return J[:n - nk, :n - nk].copy()
+
+    return coulomb
 
 
 def hip_solver(system: FragmentedSystem, settings: ScfSettings) -> Solver:
@@ -57,17 +113,19 @@ def hip_solver(system: FragmentedSystem, settings: ScfSettings) -> Solver:
     coords = np.ascontiguousarray(system.coordinates.T)
     z_all = np.asarray(system.element_numbers)
 
-    def solve(jobs: Sequence[EmbeddedJob], q_all: np.ndarray) -> List[EmbeddedResult]:
+    def solve(jobs: Sequence[EmbeddedJob]) -> List[EmbeddedResult]:
         by_key: Dict[tuple, List[int]] = {}
         for k, job in enumerate(jobs):
-            by_key.setdefault((tuple(int(v) for v in z_all[list(job.atoms)]), len(job.field_atoms)), []).append(k)
+            by_key.setdefault((tuple(int(v) for v in z_all[list(job.atoms)]), len(job.field_atoms), job.h_extra is not None), []).append(k)
         groups, index = [], []
-        for (zseq, npc), ks in by_key.items():
+        for (zseq, npc, hx), ks in by_key.items():
             xyz = np.stack([coords[list(jobs[k].atoms)] for k in ks])
             g = FragmentGroup(np.array(zseq, dtype=np.int32), xyz, np.zeros(len(ks), dtype=np.int32))
             if npc:
                 g.point_charge_xyz = np.stack([coords[list(jobs[k].field_atoms)] for k in ks])
-                g.point_charges = np.stack([q_all[list(jobs[k].field_atoms)] for k in ks])
+                g.point_charges = np.stack([np.asarray(jobs[k].field_charges, dtype=np.float64) for k in ks])
+            if hx:
+                g.h_extra = np.stack([jobs[k].h_extra for k in ks])
             groups.append(g); index.append(ks)
         extras_out: list = []
         recs = run_hip_scf_groups(settings, groups, extras=("density", "embedding_matrix", "mulliken_charges"),
@@ -82,7 +140,7 @@ def hip_solver(system: FragmentedSystem, settings: ScfSettings) -> Solver:
                 r.e_total = float(rec["e_total"][pos]); r.e_embedding = float(rec["e_embedding"][pos])
                 r.iterations = int(rec["iterations"][pos])
                 r.density = ex["density"][pos]; r.charges = ex["mulliken_charges"][pos]
-                r.u = ex["embedding_matrix"][pos] if jobs[k].field_atoms else None
+                r.u = ex["embedding_matrix"][pos] if (jobs[k].field_atoms or jobs[k].h_extra is not None) else None
         return out
 
     return solve
@@ -104,8 +162,11 @@ class FmoRun:
 
 def run_fmo2(system: FragmentedSystem, settings: ScfSettings, expansion: str = "fmo", max_outer: int = 50,
              outer_tol: float = 1.0e-7, rank: int = 0, world: int = 1,
-             allreduce: Optional[Callable[[np.ndarray], np.ndarray]] = None, solver: Optional[Solver] = None) -> FmoRun:
-    """FMO2 ("fmo") or electrostatically embedded MBE2 ("mbe") of whole-molecule fragments in Mulliken point charges.
+             allreduce: Optional[Callable[[np.ndarray], np.ndarray]] = None, solver: Optional[Solver] = None,
+             esp: str = "ptc", resppc: float = 2.0, coulomb: Optional[Coulomb] = None) -> FmoRun:
+    """FMO2 ("fmo") or electrostatically embedded MBE2 ("mbe") of whole-molecule fragments; the field of the others is
+    Mulliken point charges (`esp = "ptc"`) or, for fragments within `resppc`, bare nuclei plus the exact Coulomb
+    operator of their electrons (`esp = "exact"`, the reference's FMO default).
 
     With `world` > 1 every rank runs this on the same system, solves the fragments / pairs with index = rank (mod world)
     and `allreduce` (element-wise SUM over ranks of a float64 array) is the one exchange per pass."""
@@ -113,7 +174,14 @@ def run_fmo2(system: FragmentedSystem, settings: ScfSettings, expansion: str = "
         raise ValueError("expansion must be 'fmo' or 'mbe'")
     if world > 1 and allreduce is None:
         raise ValueError("several ranks need an allreduce")
+    if esp not in ("ptc", "exact"):
+        raise ValueError("esp must be 'ptc' or 'exact'")
     solve = solver or hip_solver(system, settings)
+    cutoff = resppc if esp == "exact" else 0.0                  # effective_resppc, :1032-1045
+    exact = esp == "exact" and cutoff != 0.0
+    if exact and coulomb is None:
+        coulomb = hip_cross_coulomb(system, settings)
+    z_all = np.asarray(system.element_numbers)
     share = allreduce if world > 1 else (lambda a: a)
     n_atoms, nfrag = len(system.element_numbers), system.n_monomers
     frags = [tuple(int(a) for a in m) for m in system.monomers]
@@ -126,10 +194,24 @@ def run_fmo2(system: FragmentedSystem, settings: ScfSettings, expansion: str = "
     dens: List[Optional[np.ndarray]] = [None] * nfrag
     nao = [0] * nfrag
 
+    def embedded_job(group: Sequence[int]) -> EmbeddedJob:
+        # embedding_operator (:1077-1160): near fragments = nuclei + exact J, the others = Mulliken charges
+        atoms = tuple(a for g in group for a in frags[g])
+        inside = set(atoms)
+        near = near_fragments(system, group, cutoff) if exact else []
+        near_atoms = set(a for k in near for a in frags[k])
+        out = tuple(a for a in range(n_atoms) if a not in inside)
+        w = np.array([float(z_all[a]) if a in near_atoms else q_all[a] for a in out])
+        hx = None
+        for k in near:
+            j = coulomb(atoms, frags[k], dens[k])
+            hx = j if hx is None else hx + j
+        return EmbeddedJob(atoms, out, w, hx)
+
     def monomer_pass(bare: bool):
         nonlocal total_iters
-        jobs = [EmbeddedJob(frags[i], () if bare else tuple(a for a in range(n_atoms) if a not in set(frags[i]))) for i in mine]
-        res = solve(jobs, q_all)
+        jobs = [EmbeddedJob(frags[i]) if bare else embedded_job([i]) for i in mine]
+        res = solve(jobs)
         new_e = np.zeros(nfrag); new_i = np.zeros(nfrag); new_q = np.zeros(n_atoms)
         for i, r in zip(mine, res):
             if r.error:
@@ -139,8 +221,8 @@ def run_fmo2(system: FragmentedSystem, settings: ScfSettings, expansion: str = "
             dens[i] = r.density; nao[i] = r.density.shape[0]
             total_iters += r.iterations
         e_total[:] = share(new_e); e_int[:] = share(new_i); q_all[:] = share(new_q)
-        if world > 1 and expansion == "fmo":
-            # the pair phase needs every monomer density (d_split): exchanged flattened, one slot per fragment
+        if world > 1 and (expansion == "fmo" or exact):
+            # the pair phase (d_split) and the exact field need every monomer density: exchanged flattened
             sizes = share(np.array([float(nao[i]) if i in mine else 0.0 for i in range(nfrag)])).astype(int)
             flat = np.zeros(int(np.sum(sizes ** 2)))
             off = np.concatenate([[0], np.cumsum(sizes ** 2)])
@@ -166,12 +248,8 @@ def run_fmo2(system: FragmentedSystem, settings: ScfSettings, expansion: str = "
 
     pairs = list(itertools.combinations(range(nfrag), 2))
     my_pairs = [p for t, p in enumerate(pairs) if t % world == rank]
-    jobs = []
-    for i, j in my_pairs:
-        atoms = frags[i] + frags[j]
-        inside = set(atoms)
-        jobs.append(EmbeddedJob(atoms, tuple(a for a in range(n_atoms) if a not in inside)))
-    res = solve(jobs, q_all) if jobs else []
+    jobs = [embedded_job([i, j]) for i, j in my_pairs]
+    res = solve(jobs) if jobs else []
     corr = np.zeros(len(pairs)); resp = np.zeros(len(pairs))
     index = {p: t for t, p in enumerate(pairs)}
     for (i, j), r in zip(my_pairs, res):

@@ -277,9 +277,9 @@ def run_hip_scf(settings: ScfSettings, fragment: PhysicalFragment, result: Optio
 
 
 _MOL_DTYPE = np.dtype({"names": ["n_atoms", "atomic_numbers", "xyz", "ghost", "charge", "multiplicity", "nelec",
-                                 "n_point_charges", "point_charge_xyz", "point_charges"],
-                       "formats": ["<i4", "<u8", "<u8", "<u8", "<i4", "<i4", "<i4", "<i4", "<u8", "<u8"],
-                       "offsets": [0, 8, 16, 24, 32, 36, 40, 44, 48, 56], "itemsize": C.sizeof(capi.Molecule)})
+                                 "n_point_charges", "point_charge_xyz", "point_charges", "h_extra"],
+                       "formats": ["<i4", "<u8", "<u8", "<u8", "<i4", "<i4", "<i4", "<i4", "<u8", "<u8", "<u8"],
+                       "offsets": [0, 8, 16, 24, 32, 36, 40, 44, 48, 56, 64], "itemsize": C.sizeof(capi.Molecule)})
 _BAS_DTYPE = np.dtype({"names": ["spherical", "n_atoms", "nshell_per_atom", "n_shells", "shell_l", "shell_nprim",
                                  "exponents", "coefficients"],
                        "formats": ["<i4", "<i4", "<u8", "<i4", "<u8", "<u8", "<u8", "<u8"],
@@ -326,6 +326,7 @@ class FragmentGroup:
     nelec: Optional[np.ndarray] = None     # (m,), default sum(Z of real atoms) - charge
     point_charge_xyz: Optional[np.ndarray] = None   # (m, n_pc, 3) Bohr: the embedding field of an FMO / EE-MBE fragment
     point_charges: Optional[np.ndarray] = None      # (m, n_pc)
+    h_extra: Optional[np.ndarray] = None            # (m, n_ao, n_ao): a further one-electron operator added to H (run_libcint_rhf's h_extra)
 
 
 def run_hip_scf_groups(settings: ScfSettings, groups: Sequence[FragmentGroup], want_gradient: bool = False,
@@ -389,6 +390,12 @@ def run_hip_scf_groups(settings: ScfSettings, groups: Sequence[FragmentGroup], w
             mols["n_point_charges"][sl] = npc
             mols["point_charges"][sl] = pq.ctypes.data + np.arange(m, dtype=np.uint64) * np.uint64(npc * 8)
             mols["point_charge_xyz"][sl] = px.ctypes.data + np.arange(m, dtype=np.uint64) * np.uint64(npc * 3 * 8)
+        if g.h_extra is not None:
+            hx = np.ascontiguousarray(g.h_extra, dtype=np.float64)
+            if hx.shape != (m, fb.nao, fb.nao):
+                raise ValueError("FragmentGroup.h_extra must be (m, n_ao, n_ao)")
+            keep.append(hx)
+            mols["h_extra"][sl] = hx.ctypes.data + np.arange(m, dtype=np.uint64) * np.uint64(fb.nao * fb.nao * 8)
         bass[sl] = _basis_record(fb, na)
         if df:
             ab = _flat_basis_z(settings.aux_basis_set, z)

@@ -5,8 +5,12 @@ Follows backends/libcint/mqc_libcint_fmo.f90 for non-covalent fragments (whole m
   than outer_tol), solve_fragment :1408-1482 / inner_scf :1950-1999 (energy = E_scf - tr(D u)), embedding_operator
   :1077-1160 with esp = "ptc" (every outside atom a Mulliken point charge, effective_resppc :1032-1045),
   nmer_term :1162-1274 (e_internal, e_resp), calculate_polymers :1566-1689 (level 2: dE_IJ = E'_IJ - E'_I - E'_J).
-Pinned by the reference's manifest row "EE-MBE water trimer 6-31g (CPU)" = -227.9704573337
-(validation/validation_tests_cpu.json:2194-2198; deck eembe_water3.json: expansion ee-mbe, level 2, Mulliken far field).
+  esp = "exact": fragments within `resppc` (near_fragments :1276-1316, closest atom pair over the sum of the van der
+  Waals radii, unitless_distance :1318-1335) give their bare nuclei as charges and their electrons through the exact
+  Coulomb operator J[D_K] in the fragment's basis (local_coulomb :1337-1406); the others stay Mulliken charges.
+Pinned by the reference's manifest rows "EE-MBE water trimer 6-31g (CPU)" = -227.9704573337 (deck eembe_water3.json:
+expansion ee-mbe, level 2, Mulliken far field) and "FMO2 water trimer 6-31g (CPU)" = -227.9705411684 (deck
+fmo_water3.json: esp exact, resppc 2.0) -- validation/validation_tests_cpu.json:2188-2198.
 Nothing in the product path imports this file.
 """
 from __future__ import annotations
@@ -32,36 +36,72 @@ class FmoOracleResult:
     pair_corrections: dict = field(default_factory=dict)
 
 
+# Bondi's van der Waals radii with Rowland and Taylor's hydrogen, Angstrom (src/core/mqc_elements.f90:58-60), Z = 1..18
+VDW_ANGSTROM = [1.10, 1.40, 1.81, 1.53, 1.92, 1.70, 1.55, 1.52, 1.47, 1.54, 2.27, 1.73, 1.84, 2.10, 1.80, 1.80, 1.75, 1.88]
+ANGSTROM_TO_BOHR = 1.8897261254578281
+
+
+def near_fragments(z, xyz, frags, group, resppc):
+    """Fragments outside `group` whose closest atom pair lies within `resppc` van der Waals sums (all of them when
+    resppc < 0)."""
+    near = []
+    inside = [a for g in group for a in frags[g]]
+    for k in range(len(frags)):
+        if k in group:
+            continue
+        if resppc < 0.0:
+            near.append(k); continue
+        best = min(np.linalg.norm(xyz[a] - xyz[b]) / ((VDW_ANGSTROM[int(z[a]) - 1] + VDW_ANGSTROM[int(z[b]) - 1]) * ANGSTROM_TO_BOHR)
+                   for a in inside for b in frags[k])
+        if best <= resppc:
+            near.append(k)
+    return near
+
+
 def run_fmo2(make_mol: Callable[[Sequence[int]], "so.OracleMol"], z: np.ndarray, xyz: np.ndarray,
              fragments: Sequence[Sequence[int]], expansion: str = "fmo", max_outer: int = 50, outer_tol: float = 1e-7,
-             scf_max_iter: int = 100, e_tol: float = 1e-9, d_tol: float = 1e-7) -> FmoOracleResult:
+             scf_max_iter: int = 100, e_tol: float = 1e-9, d_tol: float = 1e-7, esp: str = "ptc",
+             resppc: float = 2.0) -> FmoOracleResult:
     """make_mol(atom indices) -> OracleMol of those atoms; z (n_atoms,), xyz (n_atoms, 3) Bohr."""
     n_atoms, nfrag = len(z), len(fragments)
     frags = [list(map(int, f)) for f in fragments]
     mols = [make_mol(f) for f in frags]
     nelec = [int(sum(z[f])) for f in frags]
+    cutoff = 0.0 if esp == "ptc" else resppc          # effective_resppc
+    state: list = []
 
-    def field_of(mol, inside, q_all):
+    def field_of(mol, group, q_all):
+        inside = [a for g in group for a in frags[g]]
+        near = near_fragments(z, xyz, frags, group, cutoff) if (esp == "exact" and cutoff != 0.0) else []
+        near_atoms = set(a for k in near for a in frags[k])
         out = [a for a in range(n_atoms) if a not in inside]
         if not out:
             return None
-        return so.point_charge_potential(mol, xyz[out], q_all[out])
+        w = np.array([float(z[a]) if a in near_atoms else q_all[a] for a in out])
+        u = so.point_charge_potential(mol, xyz[out], w)
+        n0 = mol.nao
+        for k in near:
+            # the electrons of a near fragment: J[D_K] over the supersystem group + K, group block (local_coulomb)
+            sup = make_mol(inside + frags[k])
+            eri = so.eri4(sup)
+            u = u + np.einsum("ijkl,kl->ij", eri[:n0, :n0, n0:, n0:], state[k][2])
+        return u
 
     def solve(i, q_all, bare):
-        u = None if bare else field_of(mols[i], set(frags[i]), q_all)
+        u = None if bare else field_of(mols[i], [i], q_all)
         r = so.run_rhf(mols[i], nelec[i], max_iter=scf_max_iter, e_tol=e_tol, d_tol=d_tol, guess="gwh", h_extra=u)
         S, _, _ = so.int1e(mols[i])
         e_int = r.energy - (float(np.sum(r.D * u)) if u is not None else 0.0)
         return r.energy, e_int, r.D, so.mulliken_charges(mols[i], r.D, S)
 
     q_all = np.zeros(n_atoms)
-    state = [solve(i, q_all, True) for i in range(nfrag)]
+    state[:] = [solve(i, q_all, True) for i in range(nfrag)]
     e_prev = sum(s[1] for s in state)
     converged, outer_done = False, 0
     for outer in range(1, max_outer + 1):
         for i in range(nfrag):
             q_all[frags[i]] = state[i][3]
-        state = [solve(i, q_all, False) for i in range(nfrag)]
+        state[:] = [solve(i, q_all, False) for i in range(nfrag)]      # every fragment reads the previous pass
         e_sum = sum(s[1] for s in state)
         outer_done = outer
         if abs(e_sum - e_prev) < outer_tol:
@@ -75,7 +115,7 @@ def run_fmo2(make_mol: Callable[[Sequence[int]], "so.OracleMol"], z: np.ndarray,
     for i, j in itertools.combinations(range(nfrag), 2):
         atoms = frags[i] + frags[j]
         mol = make_mol(atoms)
-        u = field_of(mol, set(atoms), q_all)
+        u = field_of(mol, [i, j], q_all)
         r = so.run_rhf(mol, nelec[i] + nelec[j], max_iter=scf_max_iter, e_tol=e_tol, d_tol=d_tol, guess="gwh", h_extra=u)
         e_internal, e_resp = r.energy, 0.0
         if u is not None and expansion != "mbe":

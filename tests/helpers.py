@@ -96,6 +96,7 @@ W3_ANGSTROM = np.array([[0, 0, 0], [0, -0.7572, 0.5865], [0, 0.7572, 0.5865],
                         [0, 0, 2.9], [0, -0.7572, 3.4865], [0, 0.7572, 3.4865],
                         [0, 0, 5.8], [0, -0.7572, 6.3865], [0, 0.7572, 6.3865]], dtype=float)
 EEMBE_W3_GOLDEN = -227.9704573337      # manifest row "EE-MBE water trimer 6-31g (CPU)", validation_tests_cpu.json:2194-2198
+FMO2_W3_GOLDEN = -227.9705411684       # manifest row "FMO2 water trimer 6-31g (CPU)", validation_tests_cpu.json:2188-2192
 
 
 def w3_system():
@@ -121,14 +122,27 @@ def oracle_fmo_solver(system, basis, e_tol=1e-9, d_tol=1e-7, max_iter=100):
     make = oracle_make_mol(system, basis)
     z = np.asarray(system.element_numbers); xyz = np.ascontiguousarray(system.coordinates.T)
 
-    def solve(jobs, q_all):
+    def solve(jobs):
         out = []
         for job in jobs:
             mol = make(job.atoms)
-            u = so.point_charge_potential(mol, xyz[list(job.field_atoms)], q_all[list(job.field_atoms)]) if job.field_atoms else None
+            u = so.point_charge_potential(mol, xyz[list(job.field_atoms)], job.field_charges) if job.field_atoms else None
+            if job.h_extra is not None:
+                u = job.h_extra if u is None else u + job.h_extra
             r = so.run_rhf(mol, int(np.sum(z[list(job.atoms)])), max_iter=max_iter, e_tol=e_tol, d_tol=d_tol, guess="gwh", h_extra=u)
             S, _, _ = so.int1e(mol)
             out.append(EmbeddedResult(r.energy, float(np.sum(r.D * u)) if u is not None else 0.0, r.iterations, r.D,
                                       so.mulliken_charges(mol, r.D, S), u))
         return out
     return solve
+
+
+def oracle_cross_coulomb(system, basis):
+    """J[D_K] of a neighbour's electrons in the basis of `atoms`, from the oracle's four-centre integrals."""
+    make = oracle_make_mol(system, basis)
+
+    def coulomb(atoms, other, d_other):
+        sup = make(list(atoms) + list(other))
+        n0 = sup.nao - d_other.shape[0]
+        return np.einsum("ijkl,kl->ij", so.eri4(sup)[:n0, :n0, n0:, n0:], d_other)
+    return coulomb

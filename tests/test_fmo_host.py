@@ -11,15 +11,45 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from metalquicha_amd import fmo
 from metalquicha_amd.methods import ScfSettings
 from oracle import fmo_oracle, scf_oracle as so
-from tests.helpers import EEMBE_W3_GOLDEN, oracle_fmo_solver, oracle_make_mol, w3_system
+from tests.helpers import EEMBE_W3_GOLDEN, FMO2_W3_GOLDEN, oracle_cross_coulomb, oracle_fmo_solver, oracle_make_mol, w3_system
 
 FRAGS = [[0, 1, 2], [3, 4, 5], [6, 7, 8]]
 
 
-def _oracle(expansion):
+def _oracle(expansion, **kw):
     system = w3_system()
     return fmo_oracle.run_fmo2(oracle_make_mol(system, "6-31g"), np.asarray(system.element_numbers),
-                               np.ascontiguousarray(system.coordinates.T), FRAGS, expansion=expansion)
+                               np.ascontiguousarray(system.coordinates.T), FRAGS, expansion=expansion, **kw)
+
+
+def test_oracle_reproduces_the_reference_fmo2_water_trimer():
+    """The reference's default FMO2: exact ESP of near fragments (all three waters are within 2.0 van der Waals sums)."""
+    r = _oracle("fmo", esp="exact")
+    assert r.converged
+    assert abs(r.energy - FMO2_W3_GOLDEN) < 1e-9
+    assert abs(r.response_sum) > 1e-5
+
+
+def test_near_fragment_cutoff():
+    system = w3_system()
+    assert fmo.near_fragments(system, [0], 2.0) == [1, 2]          # O-O 5.8 A / 3.04 A = 1.91
+    assert fmo.near_fragments(system, [0], 1.5) == [1]
+    assert fmo.near_fragments(system, [0, 1], 0.5) == []
+    assert fmo.near_fragments(system, [2], -1.0) == [0, 1]
+    z = np.asarray(system.element_numbers); xyz = np.ascontiguousarray(system.coordinates.T)
+    for cut in (2.0, 1.5, 0.5, -1.0):
+        assert fmo_oracle.near_fragments(z, xyz, FRAGS, [0], cut) == fmo.near_fragments(system, [0], cut)
+
+
+def test_host_driver_exact_esp_equals_the_oracle():
+    system = w3_system()
+    for resppc in (2.0, 1.5):                                          # 1.5: the far water of each end is a point charge
+        ref = _oracle("fmo", esp="exact", resppc=resppc)
+        run = fmo.run_fmo2(system, ScfSettings(basis_set="6-31g"), expansion="fmo", esp="exact", resppc=resppc,
+                           solver=oracle_fmo_solver(system, "6-31g"), coulomb=oracle_cross_coulomb(system, "6-31g"))
+        assert run.converged and run.outer_iterations == ref.outer_iterations
+        assert abs(run.energy - ref.energy) < 1e-11
+        assert abs(run.response_sum - ref.response_sum) < 1e-11
 
 
 def test_oracle_reproduces_the_reference_eembe_water_trimer():
@@ -63,15 +93,15 @@ def test_two_rank_gloo_fmo_equals_serial(tmp_path):
         "import numpy as np, torch, torch.distributed as dist\n"
         "from metalquicha_amd import fmo\n"
         "from metalquicha_amd.methods import ScfSettings\n"
-        "from tests.helpers import oracle_fmo_solver, w3_system\n"
+        "from tests.helpers import oracle_cross_coulomb, oracle_fmo_solver, w3_system\n"
         "dist.init_process_group('gloo', init_method='env://')\n"
         "r, w = dist.get_rank(), dist.get_world_size()\n"
         "def allreduce(a):\n"
         "    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).copy()); dist.all_reduce(t); return t.numpy()\n"
-        "system = w3_system(); solver = oracle_fmo_solver(system, '6-31g')\n"
-        "for expansion in ('mbe', 'fmo'):\n"
-        "    par = fmo.run_fmo2(system, ScfSettings(basis_set='6-31g'), expansion=expansion, rank=r, world=w, allreduce=allreduce, solver=solver)\n"
-        "    ser = fmo.run_fmo2(system, ScfSettings(basis_set='6-31g'), expansion=expansion, solver=solver)\n"
+        "system = w3_system(); solver = oracle_fmo_solver(system, '6-31g'); cc = oracle_cross_coulomb(system, '6-31g')\n"
+        "for expansion, esp in (('mbe', 'ptc'), ('fmo', 'ptc'), ('fmo', 'exact')):\n"
+        "    par = fmo.run_fmo2(system, ScfSettings(basis_set='6-31g'), expansion=expansion, esp=esp, rank=r, world=w, allreduce=allreduce, solver=solver, coulomb=cc)\n"
+        "    ser = fmo.run_fmo2(system, ScfSettings(basis_set='6-31g'), expansion=expansion, esp=esp, solver=solver, coulomb=cc)\n"
         "    assert abs(par.energy - ser.energy) < 1e-11, (par.energy, ser.energy)\n"
         "    assert abs(par.response_sum - ser.response_sum) < 1e-11\n"
         "print('rank', r, 'ok')\n"

@@ -7,7 +7,7 @@ import pytest
 from metalquicha_amd import fmo, mbe, methods
 from metalquicha_amd.methods import FragmentGroup, ScfSettings
 from oracle import fmo_oracle, scf_oracle as so
-from tests.helpers import EEMBE_W3_GOLDEN, oracle_make_mol, w3_system
+from tests.helpers import EEMBE_W3_GOLDEN, FMO2_W3_GOLDEN, oracle_cross_coulomb, oracle_make_mol, w3_system
 
 pytestmark = pytest.mark.gpu
 
@@ -77,6 +77,62 @@ def test_fmo2_point_charge_water_trimer_matches_oracle():
     assert abs(run.response_sum - ref.response_sum) < 1e-9
     for p, c in ref.pair_corrections.items():
         assert abs(run.pair_corrections[p] - c) < 1e-9
+
+
+def test_extra_one_electron_operator_matches_oracle():
+    """h_extra through the ABI (run_libcint_rhf's argument of the same name): a symmetric random operator on one of two
+    fragments of a batch, with and without point charges beside it; energy, tr(D u), u = charges' part + h_extra."""
+    system = w3_system()
+    z = np.asarray(system.element_numbers); xyz = np.ascontiguousarray(system.coordinates.T)
+    mol = oracle_make_mol(system, "6-31g")([0, 1, 2])
+    n = mol.nao
+    rng = np.random.default_rng(3)
+    hx = rng.normal(scale=0.02, size=(2, n, n)); hx = 0.5 * (hx + hx.transpose(0, 2, 1)); hx[1] = 0.0
+    q = rng.uniform(-0.5, 0.5, size=6)
+    for with_charges in (False, True):
+        g = FragmentGroup(z[:3].astype(np.int32), np.stack([xyz[:3]] * 2), np.zeros(2, dtype=np.int32), h_extra=hx)
+        if with_charges:
+            g.point_charge_xyz = np.stack([xyz[3:]] * 2); g.point_charges = np.stack([q, q])
+        extras = []
+        rec = methods.run_hip_scf_groups(_settings(), [g], extras=("density", "embedding_matrix"), extras_out=extras)[0]
+        assert not rec["has_error"].any(), rec["message"]
+        upc = so.point_charge_potential(mol, xyz[3:], q) if with_charges else np.zeros((n, n))
+        for f in range(2):
+            u = upc + hx[f]
+            ref = so.run_rhf(mol, 10, e_tol=1e-9, d_tol=1e-7, h_extra=u)
+            assert abs(rec["e_total"][f] - ref.energy) < 1e-9
+            assert abs(rec["e_embedding"][f] - float(np.sum(ref.D * u))) < 1e-9
+            assert np.max(np.abs(extras[0]["embedding_matrix"][f] - u)) < 1e-11
+
+
+def test_cross_coulomb_of_a_neighbour_matches_oracle():
+    system = w3_system()
+    st = _settings()
+    mol = oracle_make_mol(system, "6-31g")([3, 4, 5])
+    d = so.run_rhf(mol, 10).D
+    for atoms in ([0, 1, 2], [0, 1, 2, 6, 7, 8]):
+        j = fmo.hip_cross_coulomb(system, st)(atoms, [3, 4, 5], d)
+        assert np.max(np.abs(j - oracle_cross_coulomb(system, "6-31g")(atoms, [3, 4, 5], d))) < 1e-11
+
+
+def test_fmo2_exact_esp_water_trimer_reference_golden():
+    """validation_tests_cpu.json 'FMO2 water trimer 6-31g (CPU)' = -227.9705411684: the reference's default FMO2 (exact
+    ESP of the near fragments, resppc 2.0) -- nuclei as charges, J[D_K] from the engine's J/K kernel as h_extra."""
+    system = w3_system()
+    run = fmo.run_fmo2(system, _settings(), expansion="fmo", esp="exact")
+    assert not run.errors, run.errors
+    assert run.converged
+    assert abs(run.energy - FMO2_W3_GOLDEN) < 1e-8
+    ref = fmo_oracle.run_fmo2(oracle_make_mol(system, "6-31g"), np.asarray(system.element_numbers),
+                              np.ascontiguousarray(system.coordinates.T), FRAGS, expansion="fmo", esp="exact")
+    assert run.outer_iterations == ref.outer_iterations
+    assert abs(run.energy - ref.energy) < 1e-9
+    assert abs(run.response_sum - ref.response_sum) < 1e-9
+    # a tighter cutoff turns the far water of each end into charges: mixed field
+    run = fmo.run_fmo2(system, _settings(), expansion="fmo", esp="exact", resppc=1.5)
+    ref = fmo_oracle.run_fmo2(oracle_make_mol(system, "6-31g"), np.asarray(system.element_numbers),
+                              np.ascontiguousarray(system.coordinates.T), FRAGS, expansion="fmo", esp="exact", resppc=1.5)
+    assert abs(run.energy - ref.energy) < 1e-9
 
 
 def test_eembe_water_cluster_matches_oracle():
