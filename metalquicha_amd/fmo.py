@@ -22,7 +22,7 @@ bookkeeping the reference's Fortran host code does:
   neighbour's block of the density filled); here J comes from the engine's in-core J/K kernel (`mqc_hip_jk_incore`) on
   the same supersystem and enters the SCF as `h_extra` (ABI 3); the far fragments stay Mulliken charges.
 
-Scope: whole-molecule fragments (no severed bonds, caps or AFO projector), closed shells, level 2, Mulliken far field
+Scope: whole-molecule fragments (no severed bonds, caps or AFO projector), closed shells, Mulliken far field
 -- CHELPG charges stay with the reference.
 """
 from __future__ import annotations
@@ -155,7 +155,7 @@ class FmoRun:
     outer_iterations: int
     converged: bool
     charges: np.ndarray                        # Mulliken charge of every atom of the system, in the settled field
-    pair_corrections: Dict[Tuple[int, int], float] = field(default_factory=dict)
+    pair_corrections: Dict[Tuple[int, ...], float] = field(default_factory=dict)   # dE_S of every n-mer, |S| >= 2
     scf_iterations: int = 0
     errors: List[str] = field(default_factory=list)
 
@@ -163,13 +163,14 @@ class FmoRun:
 def run_fmo2(system: FragmentedSystem, settings: ScfSettings, expansion: str = "fmo", max_outer: int = 50,
              outer_tol: float = 1.0e-7, rank: int = 0, world: int = 1,
              allreduce: Optional[Callable[[np.ndarray], np.ndarray]] = None, solver: Optional[Solver] = None,
-             esp: str = "ptc", resppc: float = 2.0, coulomb: Optional[Coulomb] = None) -> FmoRun:
+             esp: str = "ptc", resppc: float = 2.0, coulomb: Optional[Coulomb] = None, level: int = 2) -> FmoRun:
     """FMO2 ("fmo") or electrostatically embedded MBE2 ("mbe") of whole-molecule fragments; the field of the others is
     Mulliken point charges (`esp = "ptc"`) or, for fragments within `resppc`, bare nuclei plus the exact Coulomb
     operator of their electrons (`esp = "exact"`, the reference's FMO default).
 
     With `world` > 1 every rank runs this on the same system, solves the fragments / pairs with index = rank (mod world)
-    and `allreduce` (element-wise SUM over ranks of a float64 array) is the one exchange per pass."""
+    and `allreduce` (element-wise SUM over ranks of a float64 array) is the one exchange per pass.  `level` is the
+    largest n-mer (2 = FMO2; at level = number of fragments the corrections telescope to the supermolecular energy)."""
     if expansion not in ("fmo", "mbe"):
         raise ValueError("expansion must be 'fmo' or 'mbe'")
     if world > 1 and allreduce is None:
@@ -246,26 +247,35 @@ def run_fmo2(system: FragmentedSystem, settings: ScfSettings, expansion: str = "
         e_prev = e_sum
     mono = e_total.copy() if expansion == "mbe" else e_int.copy()
 
-    pairs = list(itertools.combinations(range(nfrag), 2))
-    my_pairs = [p for t, p in enumerate(pairs) if t % world == rank]
-    jobs = [embedded_job([i, j]) for i, j in my_pairs]
+    # every n-mer from pairs up to the level, one bag of independent tasks = ONE batch call (calculate_polymers,
+    # :1566-1689): value_S = e_internal + e_resp; dE_S = value_S - sum of dE_T over the proper non-empty subsets T
+    # (subtract_subsets, :1761-1778), with dE_{i} = E_i, so the response sits inside the recursion
+    level = min(level, nfrag)
+    terms = [t for size in range(2, level + 1) for t in itertools.combinations(range(nfrag), size)]
+    my_terms = [t for k, t in enumerate(terms) if k % world == rank]
+    jobs = [embedded_job(list(t)) for t in my_terms]
     res = solve(jobs) if jobs else []
-    corr = np.zeros(len(pairs)); resp = np.zeros(len(pairs))
-    index = {p: t for t, p in enumerate(pairs)}
-    for (i, j), r in zip(my_pairs, res):
+    value = np.zeros(len(terms)); resp = np.zeros(len(terms))
+    index = {t: k for k, t in enumerate(terms)}
+    for members, r in zip(my_terms, res):
         if r.error:
-            errors.append("pair (%d, %d): %s" % (i, j, r.error)); continue
+            errors.append("n-mer %s: %s" % (members, r.error)); continue
         total_iters += r.iterations
         e_internal, e_resp = r.e_total, 0.0
         if r.u is not None and expansion != "mbe":
-            ni = nao[i]
             d_split = np.zeros_like(r.density)
-            d_split[:ni, :ni] = dens[i]; d_split[ni:, ni:] = dens[j]
+            at = 0
+            for m in members:
+                d_split[at:at + nao[m], at:at + nao[m]] = dens[m]; at += nao[m]
             e_internal -= r.e_embedding
             e_resp = float(np.sum((r.density - d_split) * r.u))
-        corr[index[(i, j)]] = e_internal + e_resp - mono[i] - mono[j]
-        resp[index[(i, j)]] = e_resp
-    corr = share(corr); resp = share(resp)
-    pair_sum = float(np.sum(corr))
+        value[index[members]] = e_internal + e_resp
+        resp[index[members]] = e_resp
+    value = share(value); resp = share(resp)
+    corr: Dict[Tuple[int, ...], float] = {(i,): float(mono[i]) for i in range(nfrag)}
+    for members in terms:                                   # ordered by size: every subset is final before its supersets
+        corr[members] = float(value[index[members]]) - sum(corr[t] for sub in range(1, len(members))
+                                                           for t in itertools.combinations(members, sub))
+    pair_sum = float(sum(corr[t] for t in terms))
     return FmoRun(float(np.sum(mono)) + pair_sum, mono, pair_sum, float(np.sum(resp)), outer_done, converged and not errors,
-                  q_all.copy(), {p: float(corr[t]) for p, t in index.items()}, total_iters, errors)
+                  q_all.copy(), {t: corr[t] for t in terms}, total_iters, errors)

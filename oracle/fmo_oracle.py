@@ -61,7 +61,7 @@ def near_fragments(z, xyz, frags, group, resppc):
 def run_fmo2(make_mol: Callable[[Sequence[int]], "so.OracleMol"], z: np.ndarray, xyz: np.ndarray,
              fragments: Sequence[Sequence[int]], expansion: str = "fmo", max_outer: int = 50, outer_tol: float = 1e-7,
              scf_max_iter: int = 100, e_tol: float = 1e-9, d_tol: float = 1e-7, esp: str = "ptc",
-             resppc: float = 2.0) -> FmoOracleResult:
+             resppc: float = 2.0, level: int = 2) -> FmoOracleResult:
     """make_mol(atom indices) -> OracleMol of those atoms; z (n_atoms,), xyz (n_atoms, 3) Bohr."""
     n_atoms, nfrag = len(z), len(fragments)
     frags = [list(map(int, f)) for f in fragments]
@@ -111,20 +111,32 @@ def run_fmo2(make_mol: Callable[[Sequence[int]], "so.OracleMol"], z: np.ndarray,
     for i in range(nfrag):
         q_all[frags[i]] = state[i][3]
     mono = np.array([s[0] if expansion == "mbe" else s[1] for s in state])
-    pair_sum, response_sum, corr = 0.0, 0.0, {}
-    for i, j in itertools.combinations(range(nfrag), 2):
-        atoms = frags[i] + frags[j]
-        mol = make_mol(atoms)
-        u = field_of(mol, [i, j], q_all)
-        r = so.run_rhf(mol, nelec[i] + nelec[j], max_iter=scf_max_iter, e_tol=e_tol, d_tol=d_tol, guess="gwh", h_extra=u)
-        e_internal, e_resp = r.energy, 0.0
-        if u is not None and expansion != "mbe":
-            ni = mols[i].nao
-            d_split = np.zeros_like(r.D)
-            d_split[:ni, :ni] = state[i][2]; d_split[ni:, ni:] = state[j][2]
-            e_internal -= float(np.sum(r.D * u))
-            e_resp = float(np.sum((r.D - d_split) * u))
-        c = e_internal + e_resp - mono[i] - mono[j]
-        corr[(i, j)] = c
-        pair_sum += c; response_sum += e_resp
-    return FmoOracleResult(float(np.sum(mono) + pair_sum), mono, pair_sum, response_sum, outer_done, converged, q_all.copy(), corr)
+    # every n-mer from pairs up to the level (calculate_polymers :1566-1689): value_S = e_internal + e_resp, then
+    # dE_S = value_S - sum over proper non-empty subsets T of dE_T (subtract_subsets :1761-1778), dE_{i} = E_i
+    level = min(level, nfrag)
+    response_sum, corr = 0.0, {(i,): float(mono[i]) for i in range(nfrag)}
+    for size in range(2, level + 1):
+        for members in itertools.combinations(range(nfrag), size):
+            atoms = [a for m in members for a in frags[m]]
+            mol = make_mol(atoms)
+            u = field_of(mol, list(members), q_all)
+            r = so.run_rhf(mol, sum(nelec[m] for m in members), max_iter=scf_max_iter, e_tol=e_tol, d_tol=d_tol, guess="gwh", h_extra=u)
+            e_internal, e_resp = r.energy, 0.0
+            if u is not None and expansion != "mbe":
+                d_split = np.zeros_like(r.D)
+                at = 0
+                for m in members:
+                    nm = mols[m].nao
+                    d_split[at:at + nm, at:at + nm] = state[m][2]; at += nm
+                e_internal -= float(np.sum(r.D * u))
+                e_resp = float(np.sum((r.D - d_split) * u))
+            corr[members] = e_internal + e_resp
+            response_sum += e_resp
+    for size in range(2, level + 1):
+        for members in itertools.combinations(range(nfrag), size):
+            for sub in range(1, size):
+                for t in itertools.combinations(members, sub):
+                    corr[members] -= corr[t]
+    pair_sum = float(sum(c for t, c in corr.items() if len(t) >= 2))
+    return FmoOracleResult(float(np.sum(mono) + pair_sum), mono, pair_sum, response_sum, outer_done, converged, q_all.copy(),
+                           {t: c for t, c in corr.items() if len(t) >= 2})

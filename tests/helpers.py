@@ -96,6 +96,7 @@ W3_ANGSTROM = np.array([[0, 0, 0], [0, -0.7572, 0.5865], [0, 0.7572, 0.5865],
                         [0, 0, 2.9], [0, -0.7572, 3.4865], [0, 0.7572, 3.4865],
                         [0, 0, 5.8], [0, -0.7572, 6.3865], [0, 0.7572, 6.3865]], dtype=float)
 EEMBE_W3_GOLDEN = -227.9704573337      # manifest row "EE-MBE water trimer 6-31g (CPU)", validation_tests_cpu.json:2194-2198
+FMO3_W3_GOLDEN = -227.970497639        # rows "FMO3 / EE-MBE3 water trimer 6-31g, exact at full level (CPU)", :2200-2210
 FMO2_W3_GOLDEN = -227.9705411684       # manifest row "FMO2 water trimer 6-31g (CPU)", validation_tests_cpu.json:2188-2192
 
 

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from metalquicha_amd import fmo
 from metalquicha_amd.methods import ScfSettings
 from oracle import fmo_oracle, scf_oracle as so
-from tests.helpers import EEMBE_W3_GOLDEN, FMO2_W3_GOLDEN, oracle_cross_coulomb, oracle_fmo_solver, oracle_make_mol, w3_system
+from tests.helpers import EEMBE_W3_GOLDEN, FMO2_W3_GOLDEN, FMO3_W3_GOLDEN, oracle_cross_coulomb, oracle_fmo_solver, oracle_make_mol, w3_system
 
 FRAGS = [[0, 1, 2], [3, 4, 5], [6, 7, 8]]
 
@@ -28,6 +28,20 @@ def test_oracle_reproduces_the_reference_fmo2_water_trimer():
     assert r.converged
     assert abs(r.energy - FMO2_W3_GOLDEN) < 1e-9
     assert abs(r.response_sum) > 1e-5
+
+
+def test_level_three_telescopes_to_the_supermolecule():
+    """Manifest rows 'FMO3 / EE-MBE3 water trimer 6-31g, exact at full level': at level = number of fragments the
+    corrections telescope (response inside the recursion) and both expansions give the supermolecular RHF energy."""
+    system = w3_system()
+    for kw in (dict(expansion="fmo", esp="exact"), dict(expansion="mbe")):
+        ref = _oracle(level=3, **kw)
+        assert abs(ref.energy - FMO3_W3_GOLDEN) < 1e-9
+        run = fmo.run_fmo2(system, ScfSettings(basis_set="6-31g"), level=3, solver=oracle_fmo_solver(system, "6-31g"),
+                           coulomb=oracle_cross_coulomb(system, "6-31g"), **kw)
+        assert abs(run.energy - ref.energy) < 1e-11
+        assert abs(run.pair_corrections[(0, 1, 2)] - ref.pair_corrections[(0, 1, 2)]) < 1e-11
+        assert sorted(run.pair_corrections) == [(0, 1), (0, 1, 2), (0, 2), (1, 2)]
 
 
 def test_near_fragment_cutoff():

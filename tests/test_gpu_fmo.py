@@ -7,7 +7,7 @@ import pytest
 from metalquicha_amd import fmo, mbe, methods
 from metalquicha_amd.methods import FragmentGroup, ScfSettings
 from oracle import fmo_oracle, scf_oracle as so
-from tests.helpers import EEMBE_W3_GOLDEN, FMO2_W3_GOLDEN, oracle_cross_coulomb, oracle_make_mol, w3_system
+from tests.helpers import EEMBE_W3_GOLDEN, FMO2_W3_GOLDEN, FMO3_W3_GOLDEN, oracle_cross_coulomb, oracle_make_mol, w3_system
 
 pytestmark = pytest.mark.gpu
 
@@ -133,6 +133,17 @@ def test_fmo2_exact_esp_water_trimer_reference_golden():
     ref = fmo_oracle.run_fmo2(oracle_make_mol(system, "6-31g"), np.asarray(system.element_numbers),
                               np.ascontiguousarray(system.coordinates.T), FRAGS, expansion="fmo", esp="exact", resppc=1.5)
     assert abs(run.energy - ref.energy) < 1e-9
+
+
+def test_level_three_reference_goldens():
+    """'FMO3 / EE-MBE3 water trimer 6-31g, exact at full level (CPU)' = -227.970497639 for both expansions: monomers,
+    pairs and the trimer in one pair-phase batch, corrections telescoping to the supermolecular energy."""
+    system = w3_system()
+    for kw in (dict(expansion="fmo", esp="exact"), dict(expansion="mbe")):
+        run = fmo.run_fmo2(system, _settings(), level=3, **kw)
+        assert not run.errors, run.errors
+        assert abs(run.energy - FMO3_W3_GOLDEN) < 1e-8
+        assert len(run.pair_corrections) == 4
 
 
 def test_eembe_water_cluster_matches_oracle():
