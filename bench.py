@@ -285,6 +285,21 @@ def main():
             secondary["single_call"] = {"scf_iterations_per_s": its / dt, "fragments": len(frags), "seconds": dt,
                                         "ms_per_fragment": 1e3 * dt / len(frags),
                                         "note": "one fragment per mqc_hip_scf_run (unchanged do_fragment_work): a batch of one"}
+            # the embedded callers on the same cluster: FMO2 with the Mulliken point-charge field
+            # through fmo.run_fmo2 -- monomer passes to self-consistency + the pair phase, fresh geometry, one warm-up
+            try:
+                from metalquicha_amd import fmo as _fmo
+                fst = methods.ScfSettings(basis_set=args.basis, guess="gwh", energy_tol=1e-9, density_tol=1e-7, device_rank=local_rank)
+                _fmo.run_fmo2(moved(3100), fst, expansion="fmo")
+                t1 = time.perf_counter()
+                fr = _fmo.run_fmo2(moved(3101), fst, expansion="fmo")
+                dt = time.perf_counter() - t1
+                secondary["fmo2_point_charge_field"] = {
+                    "wall_s": dt, "scf_iterations": fr.scf_iterations, "scf_iterations_per_s": fr.scf_iterations / dt,
+                    "outer_passes": fr.outer_iterations, "converged": bool(fr.converged), "energy_hartree": fr.energy,
+                    "note": "mqc_libcint_fmo.f90 run_fmo2 with esp = ptc, Mulliken charges; every pass one engine batch"}
+            except Exception as e:      # a secondary must not take the headline line down with it
+                secondary["fmo2_point_charge_field"] = {"error": str(e)}
             # BASELINE.json configs[1]: ONE benzene, B3LYP/cc-pVDZ, density-fitted J/K (n = 114, grid level 3); a fresh
             # rotation per repeat so that nothing is served from a geometry-keyed cache
             import numpy as _np

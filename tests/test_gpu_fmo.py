@@ -7,6 +7,7 @@ import pytest
 from metalquicha_amd import fmo, mbe, methods
 from metalquicha_amd.methods import FragmentGroup, ScfSettings
 from oracle import fmo_oracle, scf_oracle as so
+from oracle import xc_oracle
 from tests.helpers import EEMBE_W3_GOLDEN, FMO2_W3_GOLDEN, FMO3_W3_GOLDEN, oracle_cross_coulomb, oracle_make_mol, w3_system
 
 pytestmark = pytest.mark.gpu
@@ -103,6 +104,28 @@ def test_extra_one_electron_operator_matches_oracle():
             assert abs(rec["e_total"][f] - ref.energy) < 1e-9
             assert abs(rec["e_embedding"][f] - float(np.sum(ref.D * u))) < 1e-9
             assert np.max(np.abs(extras[0]["embedding_matrix"][f] - u)) < 1e-11
+
+
+def test_embedded_kohn_sham_and_density_fitted_fragments_match_oracle():
+    """The field enters H only, so every two-electron path sees it: B3LYP with exact ERIs and density-fitted RHF of a
+    water in the charges of its two neighbours (cc-pVDZ), against the oracle with the same h_extra."""
+    from tests.helpers import fragment_bohr, oracle_mol
+    system = w3_system()
+    z = np.asarray(system.element_numbers); xyz = np.ascontiguousarray(system.coordinates.T)
+    q = np.array([-0.7, 0.35, 0.35, -0.6, 0.3, 0.3])
+    frag = fragment_bohr(z[:3], xyz[:3])
+    mol = oracle_mol("cc-pvdz", frag)
+    u = so.point_charge_potential(mol, xyz[3:], q)
+    g = FragmentGroup(z[:3].astype(np.int32), xyz[None, :3], np.zeros(1, dtype=np.int32),
+                      point_charge_xyz=xyz[None, 3:], point_charges=q[None, :])
+    aux = "mqc-even-tempered-jkfit"
+    for kw, okw in ((dict(functional="b3lyp"), dict(xc=xc_oracle.XCOracle(mol, "b3lyp", 3))),
+                    (dict(density_fitting=True, aux_basis_set=aux), dict(aux=oracle_mol(aux, frag)))):
+        rec = methods.run_hip_scf_groups(_settings("cc-pvdz", **kw), [g])[0]
+        assert not rec["has_error"][0], rec["message"][0]
+        ref = so.run_rhf(mol, 10, e_tol=1e-9, d_tol=1e-7, h_extra=u, **okw)
+        assert abs(rec["e_total"][0] - ref.energy) < 2e-9
+        assert abs(rec["e_embedding"][0] - float(np.sum(ref.D * u))) < 1e-8
 
 
 def test_cross_coulomb_of_a_neighbour_matches_oracle():
