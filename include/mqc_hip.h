@@ -202,6 +202,13 @@ int mqc_hip_jk_incore(mqc_hip_context *ctx, const mqc_hip_molecule_t *mol, const
                       const double *D, double *J, double *K);
 /* symmetric eigen-decomposition by the engine's LDS Jacobi kernel: A (n x n) -> w ascending,
  * V columns = eigenvectors, row-major (diagonalize_fock_device, mqc_cuest_scf.f90:1132-1221) */
+/* J[D] for MANY fragments of ONE topology (same elements and basis, n geometries, n densities) in single launches:
+ * the batched form of local_coulomb (backends/libcint/mqc_libcint_fmo.f90:1337-1406), where the FMO driver needs the
+ * Coulomb operator of a neighbour's density over the supersystem fragment + neighbour for every (fragment, neighbour)
+ * pair of a pass.  D and J are [n][n_ao*n_ao] row-major, contiguous; in-core exact ERIs (n_ao <= 116). */
+int mqc_hip_coulomb_batch(mqc_hip_context *ctx, int64_t n_fragments, const mqc_hip_molecule_t *mols,
+                          const mqc_hip_basis_t *orbital, const double *D, double *J);
+
 int mqc_hip_syev(mqc_hip_context *ctx, int32_t n, const double *A, double *w, double *V);
 /* DIIS coefficients from an age-ordered overlap matrix, the device routine's algorithm
  * (diis_coefficients/solve_diis, src/methods/mqc_diis.f90:164-273) */

@@ -78,7 +78,7 @@ class Stats(C.Structure):
 DECLARED_SYMBOLS = [
     "mqc_hip_backend_available", "mqc_hip_context_get", "mqc_hip_finalize", "mqc_hip_last_error",
     "mqc_hip_abi_version", "mqc_hip_default_options", "mqc_hip_scf_run", "mqc_hip_scf_run_batch",
-    "mqc_hip_int1e", "mqc_hip_eri_packed", "mqc_hip_jk_incore", "mqc_hip_syev",
+    "mqc_hip_int1e", "mqc_hip_eri_packed", "mqc_hip_jk_incore", "mqc_hip_coulomb_batch", "mqc_hip_syev",
     "mqc_hip_diis_coefficients", "mqc_hip_get_stats", "mqc_hip_device_name",
 ]
 
@@ -113,6 +113,7 @@ def load_library():
     lib.mqc_hip_int1e.argtypes = [C.c_void_p, C.POINTER(Molecule), C.POINTER(Basis), c_double_p, c_double_p, c_double_p]
     lib.mqc_hip_eri_packed.argtypes = [C.c_void_p, C.POINTER(Molecule), C.POINTER(Basis), C.c_double, c_double_p]
     lib.mqc_hip_jk_incore.argtypes = [C.c_void_p, C.POINTER(Molecule), C.POINTER(Basis), c_double_p, c_double_p, c_double_p]
+    lib.mqc_hip_coulomb_batch.argtypes = [C.c_void_p, C.c_int64, C.POINTER(Molecule), C.POINTER(Basis), c_double_p, c_double_p]
     lib.mqc_hip_syev.argtypes = [C.c_void_p, C.c_int32, c_double_p, c_double_p, c_double_p]
     lib.mqc_hip_diis_coefficients.argtypes = [C.c_void_p, C.c_int32, c_double_p, c_double_p, c_int32_p]
     lib.mqc_hip_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]

@@ -1384,6 +1384,58 @@ int mqc_hip_jk_incore(mqc_hip_context* ctx, const mqc_hip_molecule_t* mol, const
     return MQC_HIP_OK;
 }
 
+int mqc_hip_coulomb_batch(mqc_hip_context* ctx, int64_t nfrag, const mqc_hip_molecule_t* mols, const mqc_hip_basis_t* bas,
+                          const double* D, double* J)
+{
+    if (!ctx || nfrag < 0 || (nfrag > 0 && (!mols || !bas || !D || !J))) return fail(MQC_HIP_ERR_VALIDATION, "null argument");
+    if (nfrag == 0) return MQC_HIP_OK;
+    HIP_CHECK_RET(hipSetDevice(ctx->device));
+    for (int64_t i = 0; i < nfrag; ++i) {
+        if (!mols[i].atomic_numbers || !mols[i].xyz || mols[i].n_atoms != mols[0].n_atoms ||
+            std::memcmp(mols[i].atomic_numbers, mols[0].atomic_numbers, sizeof(int32_t) * mols[0].n_atoms) != 0 || mols[i].ghost != mols[0].ghost)
+            return fail(MQC_HIP_ERR_VALIDATION, "coulomb batch: every fragment must have the elements of the first (one topology per call)");
+    }
+    Topology topo;
+    std::string err;
+    int rc = build_topology(mols[0], *bas, topo, err);
+    if (rc != MQC_HIP_OK) return fail(rc, err);
+    if (!incore_supported(topo.nao)) return fail(MQC_HIP_ERR_UNSUPPORTED, "fragment too large for the in-core ERI path");
+    TopologyDev td;
+    rc = upload_topology(ctx, topo, td);
+    if (rc != MQC_HIP_OK) return rc;
+    const int n = topo.nao;
+    const size_t nn = (size_t)n * n, np = (size_t)topo.npair;
+    // chunks sized to the free HBM: the packed tensor of every fragment of a chunk is resident at once
+    const size_t per_frag = sizeof(double) * (per_fragment_main_doubles(n, topo.natoms) + np * np);
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    free_b += ctx->pool_main.capacity() + ctx->pool_eri.capacity();
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(nfrag, (int64_t)((double)free_b * 0.7 / (double)per_frag)));
+    Slot sl0{0, ctx->stream, &ctx->pool_main, &ctx->pool_eri, &ctx->pool_misc, &ctx->pool_gridw, &ctx->pool_df,
+             ctx->ev0, ctx->ev1, ctx->ev2, ctx->ev3, ctx->evq0, ctx->evq1, nullptr, ctx->evs[0][0], ctx->evs[0][1]};
+    std::vector<double> hx;
+    for (int64_t start = 0; start < nfrag; start += chunk) {
+        const int nf = (int)std::min<int64_t>(chunk, nfrag - start);
+        BatchView bv{};
+        rc = carve_batch(ctx, sl0, topo, td, nf, true, bv);
+        if (rc != MQC_HIP_OK) return rc;
+        bv.nocc = std::max(1, topo.nelec / 2); bv.exx = 1.0; bv.Vxc = nullptr; bv.xc = XcSpec(); bv.xc.ncomp = 0;
+        bv.naux = 0; bv.unit = ctx->d_unit;
+        hx.resize((size_t)nf * topo.natoms * 3);
+        for (int f = 0; f < nf; ++f) std::memcpy(&hx[(size_t)f * topo.natoms * 3], mols[start + f].xyz, sizeof(double) * topo.natoms * 3);
+        HIP_CHECK_RET(hipMemcpyAsync(bv.xyz, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIP_CHECK_RET(hipMemsetAsync(bv.istate, 0, sizeof(int) * (size_t)nf * 4, ctx->stream));
+        HIP_CHECK_RET(hipMemsetAsync(bv.eri_count, 0, sizeof(unsigned long long), ctx->stream));
+        launch_eri(bv, topo, 0.0, ctx->stream, hx.data());
+        HIP_CHECK_RET(hipMemcpyAsync(bv.D, D + (size_t)start * nn, sizeof(double) * nn * nf, hipMemcpyHostToDevice, ctx->stream));
+        launch_jk_incore(bv, false, ctx->stream);
+        HIP_CHECK_RET(hipStreamSynchronize(ctx->stream));
+        HIP_CHECK_RET(hipGetLastError());
+        HIP_CHECK_RET(hipMemcpy(J + (size_t)start * nn, bv.J, sizeof(double) * nn * nf, hipMemcpyDeviceToHost));
+    }
+    return MQC_HIP_OK;
+}
+
 int mqc_hip_syev(mqc_hip_context* ctx, int32_t n, const double* A, double* w, double* V)
 {
     if (!ctx || !A || !w || !V || n <= 0) return fail(MQC_HIP_ERR_VALIDATION, "bad arguments");

@@ -19,8 +19,9 @@ bookkeeping the reference's Fortran host code does:
 * `esp = "exact"` (the reference's default for FMO): fragments within `resppc` van der Waals sums (`near_fragments`,
   :1276-1316) give their bare nuclei as charges and their electrons through the exact Coulomb operator J[D_K] in the
   fragment's basis (`local_coulomb`, :1337-1406: the J build over the supersystem fragment + neighbour with only the
-  neighbour's block of the density filled); here J comes from the engine's in-core J/K kernel (`mqc_hip_jk_incore`) on
-  the same supersystem and enters the SCF as `h_extra` (ABI 3); the far fragments stay Mulliken charges.
+  neighbour's block of the density filled); here J comes from the engine's in-core integral and J kernels on the same
+  supersystems, all (fragment, neighbour) pairs of a pass in one `mqc_hip_coulomb_batch` call per element sequence, and
+  enters the SCF as `h_extra` (ABI 3); the far fragments stay Mulliken charges.
 
 Scope: whole-molecule fragments (no severed bonds, caps or AFO projector), closed shells, Mulliken far field
 -- CHELPG charges stay with the reference.
@@ -57,7 +58,8 @@ class EmbeddedResult:
 
 
 Solver = Callable[[Sequence[EmbeddedJob]], List[EmbeddedResult]]
-Coulomb = Callable[[Sequence[int], Sequence[int], np.ndarray], np.ndarray]
+CoulombRequest = Tuple[Sequence[int], Sequence[int], np.ndarray]      # (atoms, neighbour's atoms, neighbour's density)
+Coulomb = Callable[[Sequence[CoulombRequest]], List[np.ndarray]]      # -> J[D_K] in the basis of `atoms`, one per request
 
 # Bondi's van der Waals radii with Rowland and Taylor's hydrogen, Angstrom, Z = 1..18 (src/core/mqc_elements.f90:58-60)
 VDW_ANGSTROM = (1.10, 1.40, 1.81, 1.53, 1.92, 1.70, 1.55, 1.52, 1.47, 1.54, 2.27, 1.73, 1.84, 2.10, 1.80, 1.80, 1.75, 1.88)
@@ -87,22 +89,40 @@ def near_fragments(system: FragmentedSystem, group: Sequence[int], resppc: float
 
 
 def hip_cross_coulomb(system: FragmentedSystem, settings: ScfSettings) -> Coulomb:
-    """J[D_K] of a neighbour's electrons in the basis of `atoms`: the engine's in-core J/K kernel on the supersystem
-    atoms + neighbour with only the neighbour's block of the density filled, leading block of J (local_coulomb)."""
+    """J[D_K] of a neighbour's electrons in the basis of `atoms`, for all requests of a pass at once: the engine's
+    in-core integral and J kernels on the supersystems atoms + neighbour with only the neighbour's block of the density
+    filled, leading block of J (local_coulomb) -- ONE `mqc_hip_coulomb_batch` call per element sequence."""
     import ctypes as C
     from . import capi
-    from .methods import PhysicalFragment, _Marshalled, _flat_basis
+    from .methods import _BAS_DTYPE, _MOL_DTYPE, _basis_record, _flat_basis_z
+    z_all = np.asarray(system.element_numbers, dtype=np.int32)
+    coords = np.ascontiguousarray(system.coordinates.T)
 
-    def coulomb(atoms: Sequence[int], other: Sequence[int], d_other: np.ndarray) -> np.ndarray:
-        idx = list(atoms) + list(other)
-        frag = PhysicalFragment(np.asarray(system.element_numbers)[idx], system.coordinates[:, idx])
-        m = _Marshalled(frag, _flat_basis(settings.basis_set, frag))
-        n, nk = m.fb.nao, d_other.shape[0]
-        D = np.zeros((n, n)); D[n - nk:, n - nk:] = d_other
-        J, K = np.zeros((n, n)), np.zeros((n, n))
-        capi.check(capi.load_library().mqc_hip_jk_incore(capi.get_context(settings.device_rank), C.byref(m.mol), C.byref(m.bas),
-                                                         capi.dptr(D), capi.dptr(J), capi.dptr(K)))
-        return J[:n - nk, :n - nk].copy()
+    def coulomb(requests: Sequence[CoulombRequest]) -> List[np.ndarray]:
+        out: List[Optional[np.ndarray]] = [None] * len(requests)
+        by_key: Dict[tuple, List[int]] = {}
+        for r, (atoms, other, d_other) in enumerate(requests):
+            by_key.setdefault((tuple(int(v) for v in z_all[list(atoms) + list(other)]), int(d_other.shape[0])), []).append(r)
+        lib = capi.load_library()
+        ctx = capi.get_context(settings.device_rank)
+        for (zseq, nk), rs in by_key.items():
+            z = np.array(zseq, dtype=np.int32)
+            fb = _flat_basis_z(settings.basis_set, z)
+            n, m, na = fb.nao, len(rs), len(z)
+            xyz = np.ascontiguousarray(np.stack([coords[list(requests[r][0]) + list(requests[r][1])] for r in rs]))
+            D = np.zeros((m, n, n)); J = np.zeros((m, n, n))
+            for pos, r in enumerate(rs):
+                D[pos, n - nk:, n - nk:] = requests[r][2]
+            mols = np.zeros(m, dtype=_MOL_DTYPE)
+            mols["n_atoms"] = na; mols["atomic_numbers"] = z.ctypes.data
+            mols["xyz"] = xyz.ctypes.data + np.arange(m, dtype=np.uint64) * np.uint64(na * 3 * 8)
+            mols["multiplicity"] = 1; mols["nelec"] = int(np.sum(z))
+            bas = np.zeros(1, dtype=_BAS_DTYPE); bas[0] = _basis_record(fb, na)
+            capi.check(lib.mqc_hip_coulomb_batch(ctx, m, mols.ctypes.data_as(C.POINTER(capi.Molecule)),
+                                                 bas.ctypes.data_as(C.POINTER(capi.Basis)), capi.dptr(D), capi.dptr(J)))
+            for pos, r in enumerate(rs):
+                out[r] = J[pos, :n - nk, :n - nk].copy()
+        return out      # type: ignore[return-value]
 
     return coulomb
 
@@ -195,23 +215,28 @@ def run_fmo2(system: FragmentedSystem, settings: ScfSettings, expansion: str = "
     dens: List[Optional[np.ndarray]] = [None] * nfrag
     nao = [0] * nfrag
 
-    def embedded_job(group: Sequence[int]) -> EmbeddedJob:
-        # embedding_operator (:1077-1160): near fragments = nuclei + exact J, the others = Mulliken charges
-        atoms = tuple(a for g in group for a in frags[g])
-        inside = set(atoms)
-        near = near_fragments(system, group, cutoff) if exact else []
-        near_atoms = set(a for k in near for a in frags[k])
-        out = tuple(a for a in range(n_atoms) if a not in inside)
-        w = np.array([float(z_all[a]) if a in near_atoms else q_all[a] for a in out])
-        hx = None
-        for k in near:
-            j = coulomb(atoms, frags[k], dens[k])
-            hx = j if hx is None else hx + j
-        return EmbeddedJob(atoms, out, w, hx)
+    def embedded_jobs(groups: Sequence[Sequence[int]]) -> List[EmbeddedJob]:
+        # embedding_operator (:1077-1160): near fragments = nuclei + exact J, the others = Mulliken charges; the
+        # Coulomb operators of all (group, near fragment) pairs of the pass come from ONE batched request
+        jobs, requests, owner = [], [], []
+        for g, group in enumerate(groups):
+            atoms = tuple(a for m in group for a in frags[m])
+            inside = set(atoms)
+            near = near_fragments(system, group, cutoff) if exact else []
+            near_atoms = set(a for k in near for a in frags[k])
+            out = tuple(a for a in range(n_atoms) if a not in inside)
+            w = np.array([float(z_all[a]) if a in near_atoms else q_all[a] for a in out])
+            jobs.append(EmbeddedJob(atoms, out, w, None))
+            for k in near:
+                requests.append((atoms, frags[k], dens[k])); owner.append(g)
+        if requests:
+            for g, j in zip(owner, coulomb(requests)):
+                jobs[g].h_extra = j if jobs[g].h_extra is None else jobs[g].h_extra + j
+        return jobs
 
     def monomer_pass(bare: bool):
         nonlocal total_iters
-        jobs = [EmbeddedJob(frags[i]) if bare else embedded_job([i]) for i in mine]
+        jobs = [EmbeddedJob(frags[i]) for i in mine] if bare else embedded_jobs([[i] for i in mine])
         res = solve(jobs)
         new_e = np.zeros(nfrag); new_i = np.zeros(nfrag); new_q = np.zeros(n_atoms)
         for i, r in zip(mine, res):
@@ -253,7 +278,7 @@ def run_fmo2(system: FragmentedSystem, settings: ScfSettings, expansion: str = "
     level = min(level, nfrag)
     terms = [t for size in range(2, level + 1) for t in itertools.combinations(range(nfrag), size)]
     my_terms = [t for k, t in enumerate(terms) if k % world == rank]
-    jobs = [embedded_job(list(t)) for t in my_terms]
+    jobs = embedded_jobs([list(t) for t in my_terms])
     res = solve(jobs) if jobs else []
     value = np.zeros(len(terms)); resp = np.zeros(len(terms))
     index = {t: k for k, t in enumerate(terms)}

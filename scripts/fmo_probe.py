@@ -1,6 +1,6 @@
 """Times the embedded callers on the bench's cluster: (H2O)64 RHF/cc-pVDZ, Mulliken point-charge field (esp = "ptc").
 EE-MBE2 and FMO2 through fmo.run_fmo2: 64 monomers per pass, 2016 pairs with 186 charges each in the pair phase.
-    python scripts/fmo_probe.py [n_side]"""
+    python scripts/fmo_probe.py [n_side] [exact]      -- "exact": FMO2 with the exact Coulomb field of the near fragments too"""
 import os
 import sys
 import time
@@ -22,3 +22,11 @@ for expansion in ("mbe", "fmo", "mbe", "fmo"):
     dt = time.time() - t
     print("%-3s  E = %.10f  (plain MBE2 %.10f)  outer passes %d  SCF iterations %d  %.3f s  errors %d" %
           (expansion, run.energy, e_mbe, run.outer_iterations, run.scf_iterations, dt, len(run.errors)), flush=True)
+if len(sys.argv) > 2 and sys.argv[2] == "exact":
+    for rep in range(2):
+        t = time.time()
+        run = fmo.run_fmo2(system, st, expansion="fmo", esp="exact")
+        dt = time.time() - t
+        near = [len(fmo.near_fragments(system, [i], 2.0)) for i in range(system.n_monomers)]
+        print("fmo exact  E = %.10f  outer passes %d  SCF iterations %d  near fragments per monomer %.1f  %.3f s  errors %d" %
+              (run.energy, run.outer_iterations, run.scf_iterations, sum(near) / len(near), dt, len(run.errors)), flush=True)

@@ -139,11 +139,15 @@ def oracle_fmo_solver(system, basis, e_tol=1e-9, d_tol=1e-7, max_iter=100):
 
 
 def oracle_cross_coulomb(system, basis):
-    """J[D_K] of a neighbour's electrons in the basis of `atoms`, from the oracle's four-centre integrals."""
+    """J[D_K] of a neighbour's electrons in the basis of `atoms`, from the oracle's four-centre integrals (the batch
+    interface of fmo.Coulomb)."""
     make = oracle_make_mol(system, basis)
 
-    def coulomb(atoms, other, d_other):
-        sup = make(list(atoms) + list(other))
-        n0 = sup.nao - d_other.shape[0]
-        return np.einsum("ijkl,kl->ij", so.eri4(sup)[:n0, :n0, n0:, n0:], d_other)
+    def coulomb(requests):
+        out = []
+        for atoms, other, d_other in requests:
+            sup = make(list(atoms) + list(other))
+            n0 = sup.nao - d_other.shape[0]
+            out.append(np.einsum("ijkl,kl->ij", so.eri4(sup)[:n0, :n0, n0:, n0:], d_other))
+        return out
     return coulomb

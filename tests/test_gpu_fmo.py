@@ -129,13 +129,18 @@ def test_embedded_kohn_sham_and_density_fitted_fragments_match_oracle():
 
 
 def test_cross_coulomb_of_a_neighbour_matches_oracle():
+    """mqc_hip_coulomb_batch behind fmo.hip_cross_coulomb: monomer + neighbour and pair + neighbour supersystems of two
+    element sequences and several geometries in one request list, against the oracle's four-centre integrals."""
     system = w3_system()
     st = _settings()
-    mol = oracle_make_mol(system, "6-31g")([3, 4, 5])
-    d = so.run_rhf(mol, 10).D
-    for atoms in ([0, 1, 2], [0, 1, 2, 6, 7, 8]):
-        j = fmo.hip_cross_coulomb(system, st)(atoms, [3, 4, 5], d)
-        assert np.max(np.abs(j - oracle_cross_coulomb(system, "6-31g")(atoms, [3, 4, 5], d))) < 1e-11
+    make = oracle_make_mol(system, "6-31g")
+    dens = {k: so.run_rhf(make(FRAGS[k]), 10).D for k in range(3)}
+    requests = [([0, 1, 2], [3, 4, 5], dens[1]), ([0, 1, 2], [6, 7, 8], dens[2]), ([3, 4, 5], [0, 1, 2], dens[0]),
+                ([0, 1, 2, 6, 7, 8], [3, 4, 5], dens[1]), ([0, 1, 2, 3, 4, 5], [6, 7, 8], dens[2])]
+    got = fmo.hip_cross_coulomb(system, st)(requests)
+    ref = oracle_cross_coulomb(system, "6-31g")(requests)
+    for g, r in zip(got, ref):
+        assert g.shape == r.shape and np.max(np.abs(g - r)) < 1e-11
 
 
 def test_fmo2_exact_esp_water_trimer_reference_golden():
