@@ -113,7 +113,7 @@ def load_library():
     lib.mqc_hip_int1e.argtypes = [C.c_void_p, C.POINTER(Molecule), C.POINTER(Basis), c_double_p, c_double_p, c_double_p]
     lib.mqc_hip_eri_packed.argtypes = [C.c_void_p, C.POINTER(Molecule), C.POINTER(Basis), C.c_double, c_double_p]
     lib.mqc_hip_jk_incore.argtypes = [C.c_void_p, C.POINTER(Molecule), C.POINTER(Basis), c_double_p, c_double_p, c_double_p]
-    lib.mqc_hip_coulomb_batch.argtypes = [C.c_void_p, C.c_int64, C.POINTER(Molecule), C.POINTER(Basis), c_double_p, c_double_p]
+    lib.mqc_hip_coulomb_batch.argtypes = [C.c_void_p, C.c_int64, C.POINTER(Molecule), C.POINTER(Basis), C.c_int32, c_double_p, c_double_p]
     lib.mqc_hip_syev.argtypes = [C.c_void_p, C.c_int32, c_double_p, c_double_p, c_double_p]
     lib.mqc_hip_diis_coefficients.argtypes = [C.c_void_p, C.c_int32, c_double_p, c_double_p, c_int32_p]
     lib.mqc_hip_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]

@@ -1385,7 +1385,7 @@ int mqc_hip_jk_incore(mqc_hip_context* ctx, const mqc_hip_molecule_t* mol, const
 }
 
 int mqc_hip_coulomb_batch(mqc_hip_context* ctx, int64_t nfrag, const mqc_hip_molecule_t* mols, const mqc_hip_basis_t* bas,
-                          const double* D, double* J)
+                          int32_t n_source_atoms, const double* D, double* J)
 {
     if (!ctx || nfrag < 0 || (nfrag > 0 && (!mols || !bas || !D || !J))) return fail(MQC_HIP_ERR_VALIDATION, "null argument");
     if (nfrag == 0) return MQC_HIP_OK;
@@ -1400,6 +1400,28 @@ int mqc_hip_coulomb_batch(mqc_hip_context* ctx, int64_t nfrag, const mqc_hip_mol
     int rc = build_topology(mols[0], *bas, topo, err);
     if (rc != MQC_HIP_OK) return fail(rc, err);
     if (!incore_supported(topo.nao)) return fail(MQC_HIP_ERR_UNSUPPORTED, "fragment too large for the in-core ERI path");
+    if (n_source_atoms < 0 || n_source_atoms >= topo.natoms) return fail(MQC_HIP_ERR_VALIDATION, "coulomb batch: n_source_atoms must be within 0 .. n_atoms - 1");
+    const bool cross = n_source_atoms > 0;
+    if (cross) {
+        // keep the quartets that join a pair on the leading atoms with a pair on the source atoms (either side may be
+        // the bra: the class fixes the order); twin entries are dropped with the rest, the plain lists cover everything
+        const int first_src = topo.natoms - n_source_atoms;
+        auto on_src = [&](int sh) { return topo.shells[sh].atom >= first_src; };
+        for (auto& cl : topo.classes) {
+            std::vector<int> q, sets;
+            for (size_t e = 0; 4 * e + 3 < cl.quartets.size(); ++e) {
+                const int* s4 = &cl.quartets[4 * e];
+                const bool bra_src = on_src(s4[0]) && on_src(s4[1]), bra_lead = !on_src(s4[0]) && !on_src(s4[1]);
+                const bool ket_src = on_src(s4[2]) && on_src(s4[3]), ket_lead = !on_src(s4[2]) && !on_src(s4[3]);
+                if (!((bra_src && ket_lead) || (bra_lead && ket_src))) continue;
+                q.insert(q.end(), s4, s4 + 4);
+                if (e < cl.set_quartets.size()) sets.push_back(cl.set_quartets[e]);
+            }
+            cl.quartets.swap(q); cl.set_quartets.swap(sets);
+            cl.twin_entries.clear(); cl.rest.clear(); cl.set_twin.clear(); cl.set_rest.clear();
+        }
+        topo.key += "|cross" + std::to_string(n_source_atoms);
+    }
     TopologyDev td;
     rc = upload_topology(ctx, topo, td);
     if (rc != MQC_HIP_OK) return rc;
@@ -1426,6 +1448,8 @@ int mqc_hip_coulomb_batch(mqc_hip_context* ctx, int64_t nfrag, const mqc_hip_mol
         HIP_CHECK_RET(hipMemcpyAsync(bv.xyz, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice, ctx->stream));
         HIP_CHECK_RET(hipMemsetAsync(bv.istate, 0, sizeof(int) * (size_t)nf * 4, ctx->stream));
         HIP_CHECK_RET(hipMemsetAsync(bv.eri_count, 0, sizeof(unsigned long long), ctx->stream));
+        // a restricted list leaves most of the tensor untouched: those blocks must read as zero
+        if (cross) HIP_CHECK_RET(hipMemsetAsync(bv.eri, 0, sizeof(double) * (size_t)nf * np * np, ctx->stream));
         launch_eri(bv, topo, 0.0, ctx->stream, hx.data());
         HIP_CHECK_RET(hipMemcpyAsync(bv.D, D + (size_t)start * nn, sizeof(double) * nn * nf, hipMemcpyHostToDevice, ctx->stream));
         launch_jk_incore(bv, false, ctx->stream);

@@ -88,6 +88,25 @@ def near_fragments(system: FragmentedSystem, group: Sequence[int], resppc: float
     return near
 
 
+def fragment_separations(system: FragmentedSystem) -> np.ndarray:
+    """(n_frag, n_frag) closest atom pair of every two fragments in sums of van der Waals radii -- near_fragments' measure
+    for all pairs at once (the pair phase asks it for every n-mer)."""
+    from .basis import ANGSTROM_TO_BOHR
+    z = np.asarray(system.element_numbers); xyz = system.coordinates.T
+    if int(np.max(z)) > len(VDW_ANGSTROM):
+        raise ValueError("fmo: no van der Waals radius tabulated here for an element of the system")
+    r = np.array([VDW_ANGSTROM[int(v) - 1] for v in z]) * ANGSTROM_TO_BOHR
+    u = np.linalg.norm(xyz[:, None, :] - xyz[None, :, :], axis=2) / (r[:, None] + r[None, :])
+    nf = system.n_monomers
+    sep = np.zeros((nf, nf))
+    idx = [np.asarray(m, dtype=np.int64) for m in system.monomers]
+    for a in range(nf):
+        rows = u[idx[a]]
+        for b in range(a + 1, nf):
+            sep[a, b] = sep[b, a] = float(np.min(rows[:, idx[b]]))
+    return sep
+
+
 def hip_cross_coulomb(system: FragmentedSystem, settings: ScfSettings) -> Coulomb:
     """J[D_K] of a neighbour's electrons in the basis of `atoms`, for all requests of a pass at once: the engine's
     in-core integral and J kernels on the supersystems atoms + neighbour with only the neighbour's block of the density
@@ -102,10 +121,10 @@ def hip_cross_coulomb(system: FragmentedSystem, settings: ScfSettings) -> Coulom
         out: List[Optional[np.ndarray]] = [None] * len(requests)
         by_key: Dict[tuple, List[int]] = {}
         for r, (atoms, other, d_other) in enumerate(requests):
-            by_key.setdefault((tuple(int(v) for v in z_all[list(atoms) + list(other)]), int(d_other.shape[0])), []).append(r)
+            by_key.setdefault((tuple(int(v) for v in z_all[list(atoms) + list(other)]), int(d_other.shape[0]), len(other)), []).append(r)
         lib = capi.load_library()
         ctx = capi.get_context(settings.device_rank)
-        for (zseq, nk), rs in by_key.items():
+        for (zseq, nk, n_src), rs in by_key.items():
             z = np.array(zseq, dtype=np.int32)
             fb = _flat_basis_z(settings.basis_set, z)
             n, m, na = fb.nao, len(rs), len(z)
@@ -119,7 +138,7 @@ def hip_cross_coulomb(system: FragmentedSystem, settings: ScfSettings) -> Coulom
             mols["multiplicity"] = 1; mols["nelec"] = int(np.sum(z))
             bas = np.zeros(1, dtype=_BAS_DTYPE); bas[0] = _basis_record(fb, na)
             capi.check(lib.mqc_hip_coulomb_batch(ctx, m, mols.ctypes.data_as(C.POINTER(capi.Molecule)),
-                                                 bas.ctypes.data_as(C.POINTER(capi.Basis)), capi.dptr(D), capi.dptr(J)))
+                                                 bas.ctypes.data_as(C.POINTER(capi.Basis)), n_src, capi.dptr(D), capi.dptr(J)))
             for pos, r in enumerate(rs):
                 out[r] = J[pos, :n - nk, :n - nk].copy()
         return out      # type: ignore[return-value]
@@ -206,6 +225,15 @@ def run_fmo2(system: FragmentedSystem, settings: ScfSettings, expansion: str = "
     share = allreduce if world > 1 else (lambda a: a)
     n_atoms, nfrag = len(system.element_numbers), system.n_monomers
     frags = [tuple(int(a) for a in m) for m in system.monomers]
+    sep = fragment_separations(system) if (exact and cutoff >= 0.0) else None
+
+    def near_of(group: Sequence[int]) -> List[int]:
+        if not exact:
+            return []
+        if sep is None:                                         # resppc < 0: everything exact
+            return [k for k in range(nfrag) if k not in group]
+        close = np.min(sep[list(group)], axis=0) <= cutoff
+        return [k for k in range(nfrag) if close[k] and k not in group]
     mine = [i for i in range(nfrag) if i % world == rank]
     errors: List[str] = []
     total_iters = 0
@@ -222,7 +250,7 @@ def run_fmo2(system: FragmentedSystem, settings: ScfSettings, expansion: str = "
         for g, group in enumerate(groups):
             atoms = tuple(a for m in group for a in frags[m])
             inside = set(atoms)
-            near = near_fragments(system, group, cutoff) if exact else []
+            near = near_of(group)
             near_atoms = set(a for k in near for a in frags[k])
             out = tuple(a for a in range(n_atoms) if a not in inside)
             w = np.array([float(z_all[a]) if a in near_atoms else q_all[a] for a in out])

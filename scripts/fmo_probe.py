@@ -23,10 +23,21 @@ for expansion in ("mbe", "fmo", "mbe", "fmo"):
     print("%-3s  E = %.10f  (plain MBE2 %.10f)  outer passes %d  SCF iterations %d  %.3f s  errors %d" %
           (expansion, run.energy, e_mbe, run.outer_iterations, run.scf_iterations, dt, len(run.errors)), flush=True)
 if len(sys.argv) > 2 and sys.argv[2] == "exact":
+    inner = fmo.hip_cross_coulomb(system, st)
+    clock = {"coulomb": 0.0, "requests": 0}
+
+    def timed_coulomb(requests):
+        t0 = time.time()
+        out = inner(requests)
+        clock["coulomb"] += time.time() - t0; clock["requests"] += len(requests)
+        return out
+
     for rep in range(2):
+        clock["coulomb"] = 0.0; clock["requests"] = 0
         t = time.time()
-        run = fmo.run_fmo2(system, st, expansion="fmo", esp="exact")
+        run = fmo.run_fmo2(system, st, expansion="fmo", esp="exact", coulomb=timed_coulomb)
         dt = time.time() - t
+        print("           Coulomb batches: %d supersystems, %.3f s of the %.3f s" % (clock["requests"], clock["coulomb"], dt))
         near = [len(fmo.near_fragments(system, [i], 2.0)) for i in range(system.n_monomers)]
         print("fmo exact  E = %.10f  outer passes %d  SCF iterations %d  near fragments per monomer %.1f  %.3f s  errors %d" %
               (run.energy, run.outer_iterations, run.scf_iterations, sum(near) / len(near), dt, len(run.errors)), flush=True)

@@ -68,3 +68,14 @@ def pack_eri(eri4: np.ndarray) -> np.ndarray:
     idx = [(i, j) for i in range(n) for j in range(i + 1)]
     ii = np.array([p[0] for p in idx]); jj = np.array([p[1] for p in idx])
     return eri4[ii[:, None], jj[:, None], ii[None, :], jj[None, :]]
+
+
+def coulomb_batch(basis_set: str, fragments, D: np.ndarray, n_source_atoms: int = 0) -> np.ndarray:
+    """mqc_hip_coulomb_batch for fragments of one element sequence: D (m, n, n) -> J (m, n, n)."""
+    ms = [_marshal(basis_set, f) for f in fragments]
+    mols = (capi.Molecule * len(ms))(*[m.mol for m in ms])
+    D = np.ascontiguousarray(D, dtype=np.float64)
+    J = np.zeros_like(D)
+    capi.check(capi.load_library().mqc_hip_coulomb_batch(capi.get_context(), len(ms), mols, C.byref(ms[0].bas),
+                                                         n_source_atoms, capi.dptr(D), capi.dptr(J)))
+    return J

@@ -143,6 +143,30 @@ def test_cross_coulomb_of_a_neighbour_matches_oracle():
         assert g.shape == r.shape and np.max(np.abs(g - r)) < 1e-11
 
 
+def test_coulomb_batch_full_and_cross_modes():
+    """The entry by itself: n_source_atoms = 0 gives the full Coulomb matrix of a full density for every fragment of
+    the batch; n_source_atoms = 3 forms only the (leading | source) quartets and must give the same leading block for a
+    density that lives on the source atoms (cc-pVDZ: d shells, three geometries, block sharing on)."""
+    from tests import stages
+    from tests.helpers import fragment_bohr, oracle_mol, synthetic_density, water_at
+    rng = np.random.default_rng(21)
+    w0 = water_at(rng, [0, 0, 0])
+    frags = [fragment_bohr([8, 1, 1] * 2, np.vstack([w0, water_at(rng, c)])) for c in ([5.4, 0.2, 0.1], [0.3, 5.8, -0.2], [-0.5, 0.4, 6.1])]
+    mols = [oracle_mol("cc-pvdz", f) for f in frags]
+    n = mols[0].nao
+    D = np.stack([synthetic_density(n)] * 3)
+    J = stages.coulomb_batch("cc-pvdz", frags, D, 0)
+    for f in range(3):
+        Jo, _ = so.build_jk_incore(so.eri4(mols[f]), D[f])
+        assert np.max(np.abs(J[f] - Jo)) < 1e-10
+    nk = n // 2
+    Dk = np.zeros_like(D); Dk[:, nk:, nk:] = D[:, nk:, nk:]
+    Jc = stages.coulomb_batch("cc-pvdz", frags, Dk, 3)
+    for f in range(3):
+        Jo, _ = so.build_jk_incore(so.eri4(mols[f]), Dk[f])
+        assert np.max(np.abs(Jc[f][:nk, :nk] - Jo[:nk, :nk])) < 1e-10
+
+
 def test_fmo2_exact_esp_water_trimer_reference_golden():
     """validation_tests_cpu.json 'FMO2 water trimer 6-31g (CPU)' = -227.9705411684: the reference's default FMO2 (exact
     ESP of the near fragments, resppc 2.0) -- nuclei as charges, J[D_K] from the engine's J/K kernel as h_extra."""
