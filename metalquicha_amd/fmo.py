@@ -23,7 +23,10 @@ bookkeeping the reference's Fortran host code does:
   supersystems, all (fragment, neighbour) pairs of a pass in one `mqc_hip_coulomb_batch` call per element sequence, and
   enters the SCF as `h_extra` (ABI 3); the far fragments stay Mulliken charges.
 
-Scope: whole-molecule fragments (no severed bonds, caps or AFO projector), closed shells, Mulliken far field
+* `esp = "none"` is the plain many-body expansion through this driver; `far_field = "ignore"` drops the distant
+  fragments from the field instead of approximating them (:1119-1124).
+
+Scope: whole-molecule fragments (no severed bonds, caps or AFO projector), closed shells, Mulliken or ignored far field
 -- CHELPG charges stay with the reference.
 """
 from __future__ import annotations
@@ -202,7 +205,8 @@ class FmoRun:
 def run_fmo2(system: FragmentedSystem, settings: ScfSettings, expansion: str = "fmo", max_outer: int = 50,
              outer_tol: float = 1.0e-7, rank: int = 0, world: int = 1,
              allreduce: Optional[Callable[[np.ndarray], np.ndarray]] = None, solver: Optional[Solver] = None,
-             esp: str = "ptc", resppc: float = 2.0, coulomb: Optional[Coulomb] = None, level: int = 2) -> FmoRun:
+             esp: str = "ptc", resppc: float = 2.0, coulomb: Optional[Coulomb] = None, level: int = 2,
+             far_field: str = "mulliken") -> FmoRun:
     """FMO2 ("fmo") or electrostatically embedded MBE2 ("mbe") of whole-molecule fragments; the field of the others is
     Mulliken point charges (`esp = "ptc"`) or, for fragments within `resppc`, bare nuclei plus the exact Coulomb
     operator of their electrons (`esp = "exact"`, the reference's FMO default).
@@ -214,8 +218,10 @@ def run_fmo2(system: FragmentedSystem, settings: ScfSettings, expansion: str = "
         raise ValueError("expansion must be 'fmo' or 'mbe'")
     if world > 1 and allreduce is None:
         raise ValueError("several ranks need an allreduce")
-    if esp not in ("ptc", "exact"):
-        raise ValueError("esp must be 'ptc' or 'exact'")
+    if esp not in ("ptc", "exact", "none"):
+        raise ValueError("esp must be 'ptc', 'exact' or 'none'")
+    if far_field not in ("mulliken", "ignore"):
+        raise ValueError("far_field must be 'mulliken' or 'ignore' (CHELPG charges are not built)")
     solve = solver or hip_solver(system, settings)
     cutoff = resppc if esp == "exact" else 0.0                  # effective_resppc, :1032-1045
     exact = esp == "exact" and cutoff != 0.0
@@ -252,7 +258,8 @@ def run_fmo2(system: FragmentedSystem, settings: ScfSettings, expansion: str = "
             inside = set(atoms)
             near = near_of(group)
             near_atoms = set(a for k in near for a in frags[k])
-            out = tuple(a for a in range(n_atoms) if a not in inside)
+            # distant atoms drop out entirely when they are being ignored (:1119-1124)
+            out = tuple(a for a in range(n_atoms) if a not in inside and (a in near_atoms or far_field != "ignore"))
             w = np.array([float(z_all[a]) if a in near_atoms else q_all[a] for a in out])
             jobs.append(EmbeddedJob(atoms, out, w, None))
             for k in near:
@@ -264,7 +271,7 @@ def run_fmo2(system: FragmentedSystem, settings: ScfSettings, expansion: str = "
 
     def monomer_pass(bare: bool):
         nonlocal total_iters
-        jobs = [EmbeddedJob(frags[i]) for i in mine] if bare else embedded_jobs([[i] for i in mine])
+        jobs = [EmbeddedJob(frags[i]) for i in mine] if (bare or esp == "none") else embedded_jobs([[i] for i in mine])
         res = solve(jobs)
         new_e = np.zeros(nfrag); new_i = np.zeros(nfrag); new_q = np.zeros(n_atoms)
         for i, r in zip(mine, res):
@@ -290,6 +297,8 @@ def run_fmo2(system: FragmentedSystem, settings: ScfSettings, expansion: str = "
     monomer_pass(True)
     e_prev = float(np.sum(e_int))
     converged, outer_done = False, 0
+    if esp == "none":                                       # no field: the bare pass is the answer (:1523-1527)
+        converged, outer_done, max_outer = True, 1, 0
     for outer in range(1, max_outer + 1):
         monomer_pass(False)
         e_sum = float(np.sum(e_int))
@@ -306,7 +315,8 @@ def run_fmo2(system: FragmentedSystem, settings: ScfSettings, expansion: str = "
     level = min(level, nfrag)
     terms = [t for size in range(2, level + 1) for t in itertools.combinations(range(nfrag), size)]
     my_terms = [t for k, t in enumerate(terms) if k % world == rank]
-    jobs = embedded_jobs([list(t) for t in my_terms])
+    jobs = ([EmbeddedJob(tuple(a for m in t for a in frags[m])) for t in my_terms] if esp == "none"
+            else embedded_jobs([list(t) for t in my_terms]))
     res = solve(jobs) if jobs else []
     value = np.zeros(len(terms)); resp = np.zeros(len(terms))
     index = {t: k for k, t in enumerate(terms)}

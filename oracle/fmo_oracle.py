@@ -61,7 +61,7 @@ def near_fragments(z, xyz, frags, group, resppc):
 def run_fmo2(make_mol: Callable[[Sequence[int]], "so.OracleMol"], z: np.ndarray, xyz: np.ndarray,
              fragments: Sequence[Sequence[int]], expansion: str = "fmo", max_outer: int = 50, outer_tol: float = 1e-7,
              scf_max_iter: int = 100, e_tol: float = 1e-9, d_tol: float = 1e-7, esp: str = "ptc",
-             resppc: float = 2.0, level: int = 2) -> FmoOracleResult:
+             resppc: float = 2.0, level: int = 2, far_field: str = "mulliken") -> FmoOracleResult:
     """make_mol(atom indices) -> OracleMol of those atoms; z (n_atoms,), xyz (n_atoms, 3) Bohr."""
     n_atoms, nfrag = len(z), len(fragments)
     frags = [list(map(int, f)) for f in fragments]
@@ -74,8 +74,10 @@ def run_fmo2(make_mol: Callable[[Sequence[int]], "so.OracleMol"], z: np.ndarray,
         inside = [a for g in group for a in frags[g]]
         near = near_fragments(z, xyz, frags, group, cutoff) if (esp == "exact" and cutoff != 0.0) else []
         near_atoms = set(a for k in near for a in frags[k])
-        out = [a for a in range(n_atoms) if a not in inside]
-        if not out:
+        if esp == "none":
+            return None
+        out = [a for a in range(n_atoms) if a not in inside and (a in near_atoms or far_field != "ignore")]
+        if not out and not near:
             return None
         w = np.array([float(z[a]) if a in near_atoms else q_all[a] for a in out])
         u = so.point_charge_potential(mol, xyz[out], w)
@@ -98,6 +100,8 @@ def run_fmo2(make_mol: Callable[[Sequence[int]], "so.OracleMol"], z: np.ndarray,
     state[:] = [solve(i, q_all, True) for i in range(nfrag)]
     e_prev = sum(s[1] for s in state)
     converged, outer_done = False, 0
+    if esp == "none":
+        converged, outer_done, max_outer = True, 1, 0
     for outer in range(1, max_outer + 1):
         for i in range(nfrag):
             q_all[frags[i]] = state[i][3]

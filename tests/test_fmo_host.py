@@ -44,6 +44,30 @@ def test_level_three_telescopes_to_the_supermolecule():
         assert sorted(run.pair_corrections) == [(0, 1), (0, 1, 2), (0, 2), (1, 2)]
 
 
+def test_no_field_and_ignored_far_field():
+    """esp = "none" is the plain MBE(2); a point-charge field whose distant fragments are ignored is no field at all
+    (check_fmo.f90 separated_case: ignored == bare to 1e-12); with an exact near field and an ignored far one the
+    driver still equals the oracle."""
+    system = w3_system()
+    make = oracle_make_mol(system, "6-31g")
+    st = ScfSettings(basis_set="6-31g")
+    solver, cc = oracle_fmo_solver(system, "6-31g"), oracle_cross_coulomb(system, "6-31g")
+    e1 = [so.run_rhf(make(f), 10, e_tol=1e-9, d_tol=1e-7).energy for f in FRAGS]
+    plain = sum(e1)
+    for i in range(3):
+        for j in range(i + 1, 3):
+            plain += so.run_rhf(make(FRAGS[i] + FRAGS[j]), 20, e_tol=1e-9, d_tol=1e-7).energy - e1[i] - e1[j]
+    bare = fmo.run_fmo2(system, st, expansion="mbe", esp="none", solver=solver)
+    assert bare.converged and bare.outer_iterations == 1 and abs(bare.energy - plain) < 1e-11
+    ignored = fmo.run_fmo2(system, st, expansion="fmo", esp="ptc", far_field="ignore", solver=solver)
+    assert abs(ignored.energy - bare.energy) < 1e-12 and ignored.response_sum == 0.0
+    assert abs(_oracle("mbe", esp="none").energy - plain) < 1e-11
+    ref = _oracle("fmo", esp="exact", resppc=1.5, far_field="ignore")
+    run = fmo.run_fmo2(system, st, expansion="fmo", esp="exact", resppc=1.5, far_field="ignore", solver=solver, coulomb=cc)
+    assert abs(run.energy - ref.energy) < 1e-11
+    assert abs(run.energy - _oracle("fmo", esp="exact", resppc=1.5).energy) > 1e-7      # the far charges do matter
+
+
 def test_near_fragment_cutoff():
     system = w3_system()
     assert fmo.near_fragments(system, [0], 2.0) == [1, 2]          # O-O 5.8 A / 3.04 A = 1.91
