@@ -205,10 +205,11 @@ int mqc_hip_jk_incore(mqc_hip_context *ctx, const mqc_hip_molecule_t *mol, const
 /* J[D] for MANY fragments of ONE topology (same elements and basis, n geometries, n densities) in single launches:
  * the batched form of local_coulomb (backends/libcint/mqc_libcint_fmo.f90:1337-1406), where the FMO driver needs the
  * Coulomb operator of a neighbour's density over the supersystem fragment + neighbour for every (fragment, neighbour)
- * pair of a pass.  D and J are [n][n_ao*n_ao] row-major, contiguous; in-core exact ERIs (n_ao <= 116).
+ * pair of a pass.  D and J are [n][n_ao*n_ao] row-major, contiguous; in-core exact ERIs (n_ao <= 116) for the full matrix.
  * n_source_atoms > 0 says that only the LAST n_source_atoms atoms carry density and only the block of J over the
  * other (leading) atoms is wanted -- exactly local_coulomb's use -- so only the shell quartets (leading pair | source
- * pair) are formed; the rest of J is then not meaningful.  0 = the full Coulomb matrix of the full density. */
+ * pair) are formed -- contracted with the density on the fly by the direct-path digest kernels (Schwarz bound 1e-12,
+ * no integral tensor, n_ao <= 256); the rest of J is then not meaningful.  0 = the full Coulomb matrix of the full density. */
 int mqc_hip_coulomb_batch(mqc_hip_context *ctx, int64_t n_fragments, const mqc_hip_molecule_t *mols,
                           const mqc_hip_basis_t *orbital, int32_t n_source_atoms, const double *D, double *J);
 

@@ -1399,7 +1399,6 @@ int mqc_hip_coulomb_batch(mqc_hip_context* ctx, int64_t nfrag, const mqc_hip_mol
     std::string err;
     int rc = build_topology(mols[0], *bas, topo, err);
     if (rc != MQC_HIP_OK) return fail(rc, err);
-    if (!incore_supported(topo.nao)) return fail(MQC_HIP_ERR_UNSUPPORTED, "fragment too large for the in-core ERI path");
     if (n_source_atoms < 0 || n_source_atoms >= topo.natoms) return fail(MQC_HIP_ERR_VALIDATION, "coulomb batch: n_source_atoms must be within 0 .. n_atoms - 1");
     const bool cross = n_source_atoms > 0;
     if (cross) {
@@ -1427,19 +1426,25 @@ int mqc_hip_coulomb_batch(mqc_hip_context* ctx, int64_t nfrag, const mqc_hip_mol
     if (rc != MQC_HIP_OK) return rc;
     const int n = topo.nao;
     const size_t nn = (size_t)n * n, np = (size_t)topo.npair;
-    // chunks sized to the free HBM: the packed tensor of every fragment of a chunk is resident at once
-    const size_t per_frag = sizeof(double) * (per_fragment_main_doubles(n, topo.natoms) + np * np);
+    // full mode: in-core (the packed tensor of every fragment of a chunk resident at once, chunks sized to the free HBM).
+    // cross mode: the direct digest over the filtered lists -- no tensor at all, the few (leading | source) quartets
+    // are contracted with the density as they are formed (Schwarz screening at 1e-12)
+    static const bool cross_incore = [] { const char* e = std::getenv("MQC_HIP_COULOMB_CROSS_INCORE"); return e && e[0] == '1'; }();
+    const bool direct = cross && !cross_incore;
+    if (!direct && !incore_supported(topo.nao)) return fail(MQC_HIP_ERR_UNSUPPORTED, "fragment too large for the in-core ERI path");
+    if (topo.nao > 256) return fail(MQC_HIP_ERR_UNSUPPORTED, "fragment too large (n_ao <= 256)");
+    const size_t per_frag = sizeof(double) * (per_fragment_main_doubles(n, topo.natoms) + (direct ? 4 * nn : np * np));
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     free_b += ctx->pool_main.capacity() + ctx->pool_eri.capacity();
-    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(nfrag, (int64_t)((double)free_b * 0.7 / (double)per_frag)));
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(nfrag, 16384), (int64_t)((double)free_b * 0.7 / (double)per_frag)));
     Slot sl0{0, ctx->stream, &ctx->pool_main, &ctx->pool_eri, &ctx->pool_misc, &ctx->pool_gridw, &ctx->pool_df,
              ctx->ev0, ctx->ev1, ctx->ev2, ctx->ev3, ctx->evq0, ctx->evq1, nullptr, ctx->evs[0][0], ctx->evs[0][1]};
     std::vector<double> hx;
     for (int64_t start = 0; start < nfrag; start += chunk) {
         const int nf = (int)std::min<int64_t>(chunk, nfrag - start);
         BatchView bv{};
-        rc = carve_batch(ctx, sl0, topo, td, nf, true, bv);
+        rc = carve_batch(ctx, sl0, topo, td, nf, !direct, bv);
         if (rc != MQC_HIP_OK) return rc;
         bv.nocc = std::max(1, topo.nelec / 2); bv.exx = 1.0; bv.Vxc = nullptr; bv.xc = XcSpec(); bv.xc.ncomp = 0;
         bv.naux = 0; bv.unit = ctx->d_unit;
@@ -1448,11 +1453,16 @@ int mqc_hip_coulomb_batch(mqc_hip_context* ctx, int64_t nfrag, const mqc_hip_mol
         HIP_CHECK_RET(hipMemcpyAsync(bv.xyz, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice, ctx->stream));
         HIP_CHECK_RET(hipMemsetAsync(bv.istate, 0, sizeof(int) * (size_t)nf * 4, ctx->stream));
         HIP_CHECK_RET(hipMemsetAsync(bv.eri_count, 0, sizeof(unsigned long long), ctx->stream));
-        // a restricted list leaves most of the tensor untouched: those blocks must read as zero
-        if (cross) HIP_CHECK_RET(hipMemsetAsync(bv.eri, 0, sizeof(double) * (size_t)nf * np * np, ctx->stream));
-        launch_eri(bv, topo, 0.0, ctx->stream, hx.data());
         HIP_CHECK_RET(hipMemcpyAsync(bv.D, D + (size_t)start * nn, sizeof(double) * nn * nf, hipMemcpyHostToDevice, ctx->stream));
-        launch_jk_incore(bv, false, ctx->stream);
+        if (direct) {
+            launch_direct_setup(bv, topo, ctx->stream);
+            launch_jk_direct(bv, topo, 1.0e-12, false, ctx->stream);
+        } else {
+            // a restricted list leaves most of the tensor untouched: those blocks must read as zero
+            if (cross) HIP_CHECK_RET(hipMemsetAsync(bv.eri, 0, sizeof(double) * (size_t)nf * np * np, ctx->stream));
+            launch_eri(bv, topo, 0.0, ctx->stream, hx.data());
+            launch_jk_incore(bv, false, ctx->stream);
+        }
         HIP_CHECK_RET(hipStreamSynchronize(ctx->stream));
         HIP_CHECK_RET(hipGetLastError());
         HIP_CHECK_RET(hipMemcpy(J + (size_t)start * nn, bv.J, sizeof(double) * nn * nf, hipMemcpyDeviceToHost));
