@@ -97,7 +97,8 @@ module mqc_hip_c
    end type
 
    public :: mqc_hip_backend_available, mqc_hip_context_get, mqc_hip_finalize, mqc_hip_last_error, &
-             mqc_hip_abi_version, mqc_hip_default_options, mqc_hip_scf_run, mqc_hip_scf_run_batch
+             mqc_hip_abi_version, mqc_hip_default_options, mqc_hip_scf_run, mqc_hip_scf_run_batch, &
+             mqc_hip_coulomb_batch
 
    interface
       function mqc_hip_backend_available() bind(C, name="mqc_hip_backend_available") result(r)
@@ -147,6 +148,19 @@ module mqc_hip_c
          type(c_ptr), value :: auxes
          type(mqc_hip_scf_options_t), intent(in) :: opts
          type(mqc_hip_scf_result_t), intent(inout) :: res(*)
+         integer(c_int) :: r
+      end function
+      !! J[D] for many fragments of one topology; n_source_atoms > 0: only the (leading | source) block (local_coulomb)
+      function mqc_hip_coulomb_batch(ctx, n, mols, orbital, n_source_atoms, d, j) &
+         bind(C, name="mqc_hip_coulomb_batch") result(r)
+         import :: c_int, c_int32_t, c_int64_t, c_ptr, c_double, mqc_hip_molecule_t, mqc_hip_basis_t
+         type(c_ptr), value :: ctx
+         integer(c_int64_t), value :: n
+         type(mqc_hip_molecule_t), intent(in) :: mols(*)
+         type(mqc_hip_basis_t), intent(in) :: orbital
+         integer(c_int32_t), value :: n_source_atoms
+         real(c_double), intent(in) :: d(*)
+         real(c_double), intent(inout) :: j(*)
          integer(c_int) :: r
       end function
    end interface
