@@ -44,7 +44,7 @@ from .methods import FragmentGroup, ScfSettings
 @dataclass
 class EmbeddedJob:
     atoms: Tuple[int, ...]                   # atoms of the fragment / pair, in basis order
-    field_atoms: Tuple[int, ...] = ()        # outside atoms that act as point charges (empty = none)
+    field_atoms: Sequence[int] = ()          # outside atoms that act as point charges (empty = none)
     field_charges: Optional[np.ndarray] = None   # their weights: Mulliken charge (far) or bare nuclear charge (near)
     h_extra: Optional[np.ndarray] = None     # (n, n): the near fragments' exact Coulomb operator, or None
 
@@ -164,7 +164,7 @@ def hip_solver(system: FragmentedSystem, settings: ScfSettings) -> Solver:
             xyz = np.stack([coords[list(jobs[k].atoms)] for k in ks])
             g = FragmentGroup(np.array(zseq, dtype=np.int32), xyz, np.zeros(len(ks), dtype=np.int32))
             if npc:
-                g.point_charge_xyz = np.stack([coords[list(jobs[k].field_atoms)] for k in ks])
+                g.point_charge_xyz = np.stack([coords[np.asarray(jobs[k].field_atoms, dtype=np.int64)] for k in ks])
                 g.point_charges = np.stack([np.asarray(jobs[k].field_charges, dtype=np.float64) for k in ks])
             if hx:
                 g.h_extra = np.stack([jobs[k].h_extra for k in ks])
@@ -182,7 +182,7 @@ def hip_solver(system: FragmentedSystem, settings: ScfSettings) -> Solver:
                 r.e_total = float(rec["e_total"][pos]); r.e_embedding = float(rec["e_embedding"][pos])
                 r.iterations = int(rec["iterations"][pos])
                 r.density = ex["density"][pos]; r.charges = ex["mulliken_charges"][pos]
-                r.u = ex["embedding_matrix"][pos] if (jobs[k].field_atoms or jobs[k].h_extra is not None) else None
+                r.u = ex["embedding_matrix"][pos] if (len(jobs[k].field_atoms) or jobs[k].h_extra is not None) else None
         return out
 
     return solve
@@ -255,12 +255,15 @@ def run_fmo2(system: FragmentedSystem, settings: ScfSettings, expansion: str = "
         jobs, requests, owner = [], [], []
         for g, group in enumerate(groups):
             atoms = tuple(a for m in group for a in frags[m])
-            inside = set(atoms)
+            outside = np.ones(n_atoms, dtype=bool); outside[list(atoms)] = False
             near = near_of(group)
-            near_atoms = set(a for k in near for a in frags[k])
-            # distant atoms drop out entirely when they are being ignored (:1119-1124)
-            out = tuple(a for a in range(n_atoms) if a not in inside and (a in near_atoms or far_field != "ignore"))
-            w = np.array([float(z_all[a]) if a in near_atoms else q_all[a] for a in out])
+            is_near = np.zeros(n_atoms, dtype=bool)
+            for k in near:
+                is_near[list(frags[k])] = True
+            if far_field == "ignore":                  # distant atoms drop out entirely when they are being ignored (:1119-1124)
+                outside &= is_near
+            out = np.nonzero(outside)[0]
+            w = np.where(is_near[out], z_all[out].astype(np.float64), q_all[out])
             jobs.append(EmbeddedJob(atoms, out, w, None))
             for k in near:
                 requests.append((atoms, frags[k], dens[k])); owner.append(g)

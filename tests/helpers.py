@@ -127,7 +127,7 @@ def oracle_fmo_solver(system, basis, e_tol=1e-9, d_tol=1e-7, max_iter=100):
         out = []
         for job in jobs:
             mol = make(job.atoms)
-            u = so.point_charge_potential(mol, xyz[list(job.field_atoms)], job.field_charges) if job.field_atoms else None
+            u = so.point_charge_potential(mol, xyz[list(job.field_atoms)], job.field_charges) if len(job.field_atoms) else None
             if job.h_extra is not None:
                 u = job.h_extra if u is None else u + job.h_extra
             r = so.run_rhf(mol, int(np.sum(z[list(job.atoms)])), max_iter=max_iter, e_tol=e_tol, d_tol=d_tol, guess="gwh", h_extra=u)
