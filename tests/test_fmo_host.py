@@ -68,6 +68,18 @@ def test_no_field_and_ignored_far_field():
     assert abs(run.energy - _oracle("fmo", esp="exact", resppc=1.5).energy) > 1e-7      # the far charges do matter
 
 
+def test_product_solver_fails_loudly_without_a_device():
+    """No CPU fallback behind the embedded callers either: without a HIP device the default solver raises."""
+    import pytest
+    from metalquicha_amd import capi
+    if capi.load_library().mqc_hip_backend_available():
+        pytest.skip("a HIP device is present")
+    with pytest.raises(capi.HipBackendError):
+        fmo.run_fmo2(w3_system(), ScfSettings(basis_set="6-31g"))
+    with pytest.raises(capi.HipBackendError):
+        fmo.hip_cross_coulomb(w3_system(), ScfSettings(basis_set="6-31g"))([([0, 1, 2], [3, 4, 5], np.zeros((13, 13)))])
+
+
 def test_near_fragment_cutoff():
     system = w3_system()
     assert fmo.near_fragments(system, [0], 2.0) == [1, 2]          # O-O 5.8 A / 3.04 A = 1.91
