@@ -311,6 +311,14 @@ def run_fmo2(system: FragmentedSystem, settings: ScfSettings, expansion: str = "
             break
         e_prev = e_sum
     mono = e_total.copy() if expansion == "mbe" else e_int.copy()
+    if world > 1:
+        failed = float(share(np.array([float(len(errors))]))[0])
+    else:
+        failed = float(len(errors))
+    if failed:
+        # a fragment without a density cannot field the pair phase: the total is not trustworthy (run_fmo2, :489-494)
+        return FmoRun(float("nan"), mono, 0.0, 0.0, outer_done, False, q_all.copy(), {}, total_iters,
+                      errors or ["a fragment SCF failed on another rank"])
 
     # every n-mer from pairs up to the level, one bag of independent tasks = ONE batch call (calculate_polymers,
     # :1566-1689): value_S = e_internal + e_resp; dE_S = value_S - sum of dE_T over the proper non-empty subsets T

@@ -80,6 +80,19 @@ def test_product_solver_fails_loudly_without_a_device():
         fmo.hip_cross_coulomb(w3_system(), ScfSettings(basis_set="6-31g"))([([0, 1, 2], [3, 4, 5], np.zeros((13, 13)))])
 
 
+def test_failed_fragment_stops_before_the_pair_phase():
+    """run_fmo2 refuses a total when a fragment SCF failed (mqc_libcint_fmo.f90:489-494): errors out, energy NaN."""
+    system = w3_system()
+    good = oracle_fmo_solver(system, "6-31g")
+
+    def bad(jobs):
+        out = good(jobs)
+        out[0].error = "made to fail"
+        return out
+    run = fmo.run_fmo2(system, ScfSettings(basis_set="6-31g"), solver=bad)
+    assert not run.converged and np.isnan(run.energy) and "made to fail" in run.errors[0]
+
+
 def test_near_fragment_cutoff():
     system = w3_system()
     assert fmo.near_fragments(system, [0], 2.0) == [1, 2]          # O-O 5.8 A / 3.04 A = 1.91
