@@ -127,7 +127,8 @@ def hip_cross_coulomb(system: FragmentedSystem, settings: ScfSettings) -> Coulom
             by_key.setdefault((tuple(int(v) for v in z_all[list(atoms) + list(other)]), int(d_other.shape[0]), len(other)), []).append(r)
         lib = capi.load_library()
         ctx = capi.get_context(settings.device_rank)
-        for (zseq, nk, n_src), rs in by_key.items():
+        pieces = [(key, ks[lo:lo + 16384]) for key, ks in by_key.items() for lo in range(0, len(ks), 16384)]   # bounds the host arrays
+        for (zseq, nk, n_src), rs in pieces:
             z = np.array(zseq, dtype=np.int32)
             fb = _flat_basis_z(settings.basis_set, z)
             n, m, na = fb.nao, len(rs), len(z)
