@@ -273,10 +273,23 @@ def run_fmo2(system: FragmentedSystem, settings: ScfSettings, expansion: str = "
                 jobs[g].h_extra = j if jobs[g].h_extra is None else jobs[g].h_extra + j
         return jobs
 
+    def any_failure() -> bool:
+        # every rank must leave together: the count of failed SCFs is shared like the energies
+        return bool(float(share(np.array([float(len(errors))]))[0]))
+
+    def refused(outer_done: int, why: Optional[str] = None) -> FmoRun:
+        # the reference returns an error and no energy (run_fmo2 :489-494, calculate_monomers :1560-1563,
+        # calculate_polymers' early returns); here: NaN, not converged, and the reason on every rank
+        mono_now = e_total.copy() if expansion == "mbe" else e_int.copy()
+        if why:
+            errors.append(why)
+        return FmoRun(float("nan"), mono_now, 0.0, 0.0, outer_done, False, q_all.copy(), {}, total_iters,
+                      errors or ["an SCF failed on another rank"])
+
     def monomer_pass(bare: bool):
         nonlocal total_iters
-        jobs = [EmbeddedJob(frags[i]) for i in mine] if (bare or esp == "none") else embedded_jobs([[i] for i in mine])
-        res = solve(jobs)
+        monomer_jobs = [EmbeddedJob(frags[i]) for i in mine] if (bare or esp == "none") else embedded_jobs([[i] for i in mine])
+        res = solve(monomer_jobs)
         new_e = np.zeros(nfrag); new_i = np.zeros(nfrag); new_q = np.zeros(n_atoms)
         for i, r in zip(mine, res):
             if r.error:
@@ -299,27 +312,30 @@ def run_fmo2(system: FragmentedSystem, settings: ScfSettings, expansion: str = "
                 nao[i] = int(sizes[i]); dens[i] = flat[off[i]:off[i + 1]].reshape(sizes[i], sizes[i])
 
     monomer_pass(True)
+    if any_failure():
+        # a fragment without a density cannot field the next pass or the pair phase (solve_fragment's error return)
+        return refused(0)
     e_prev = float(np.sum(e_int))
     converged, outer_done = False, 0
+    change = 0.0
     if esp == "none":                                       # no field: the bare pass is the answer (:1523-1527)
         converged, outer_done, max_outer = True, 1, 0
     for outer in range(1, max_outer + 1):
         monomer_pass(False)
+        if any_failure():
+            return refused(outer)
         e_sum = float(np.sum(e_int))
         outer_done = outer
-        if abs(e_sum - e_prev) < outer_tol:
+        change = abs(e_sum - e_prev)
+        if change < outer_tol:
             converged = True
             break
         e_prev = e_sum
+    if not converged:
+        # calculate_monomers :1560-1563: an outer loop that has not settled is an error, not a total
+        return refused(outer_done, "fmo: the outer SCF did not settle in %d passes; the monomer sum was still moving by %.3e Hartree"
+                       % (max_outer, change))
     mono = e_total.copy() if expansion == "mbe" else e_int.copy()
-    if world > 1:
-        failed = float(share(np.array([float(len(errors))]))[0])
-    else:
-        failed = float(len(errors))
-    if failed:
-        # a fragment without a density cannot field the pair phase: the total is not trustworthy (run_fmo2, :489-494)
-        return FmoRun(float("nan"), mono, 0.0, 0.0, outer_done, False, q_all.copy(), {}, total_iters,
-                      errors or ["a fragment SCF failed on another rank"])
 
     # every n-mer from pairs up to the level, one bag of independent tasks = ONE batch call (calculate_polymers,
     # :1566-1689): value_S = e_internal + e_resp; dE_S = value_S - sum of dE_T over the proper non-empty subsets T
@@ -327,9 +343,9 @@ def run_fmo2(system: FragmentedSystem, settings: ScfSettings, expansion: str = "
     level = min(level, nfrag)
     terms = [t for size in range(2, level + 1) for t in itertools.combinations(range(nfrag), size)]
     my_terms = [t for k, t in enumerate(terms) if k % world == rank]
-    jobs = ([EmbeddedJob(tuple(a for m in t for a in frags[m])) for t in my_terms] if esp == "none"
-            else embedded_jobs([list(t) for t in my_terms]))
-    res = solve(jobs) if jobs else []
+    nmer_jobs = ([EmbeddedJob(tuple(a for m in t for a in frags[m])) for t in my_terms] if esp == "none"
+                 else embedded_jobs([list(t) for t in my_terms]))
+    res = solve(nmer_jobs) if nmer_jobs else []
     value = np.zeros(len(terms)); resp = np.zeros(len(terms))
     index = {t: k for k, t in enumerate(terms)}
     for members, r in zip(my_terms, res):
@@ -346,6 +362,10 @@ def run_fmo2(system: FragmentedSystem, settings: ScfSettings, expansion: str = "
             e_resp = float(np.sum((r.density - d_split) * r.u))
         value[index[members]] = e_internal + e_resp
         resp[index[members]] = e_resp
+    if any_failure():
+        # a failed n-mer would enter as value 0 and shift the total by a whole pair energy: no total instead
+        # (calculate_polymers returns on nmer_term's error, :1652-1653), and every rank learns of it
+        return refused(outer_done)
     value = share(value); resp = share(resp)
     corr: Dict[Tuple[int, ...], float] = {(i,): float(mono[i]) for i in range(nfrag)}
     for members in terms:                                   # ordered by size: every subset is final before its supersets

@@ -175,3 +175,94 @@ def test_two_rank_gloo_fmo_equals_serial(tmp_path):
                          capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("ok") == 2
+
+
+def _thread_ranks(world, body):
+    """Runs body(rank, allreduce) on `world` threads with an element-wise SUM all-reduce between them (the exchange
+    run_fmo2 needs, without a process group)."""
+    import threading
+    barrier = threading.Barrier(world)
+    slots = [None] * world
+    out = [None] * world
+
+    def make_allreduce(rank):
+        def allreduce(a):
+            slots[rank] = np.array(a, dtype=np.float64, copy=True)
+            barrier.wait()
+            total = sum(slots[r] for r in range(world))
+            barrier.wait()
+            return total
+        return allreduce
+
+    def run(rank):
+        try:
+            out[rank] = body(rank, make_allreduce(rank))
+        except BaseException as e:      # a rank that dies must not leave the other at the barrier forever
+            out[rank] = e
+            barrier.abort()
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    return out
+
+
+def test_failed_pair_on_one_rank_refuses_the_total_on_every_rank():
+    """A pair SCF that fails on rank 1 of 2 must not enter the total as a zero (that would shift it by a whole pair
+    energy): every rank returns no energy, not converged, and an error -- calculate_polymers returns on nmer_term's
+    error (mqc_libcint_fmo.f90:1652-1653)."""
+    system = w3_system()
+    good = oracle_fmo_solver(system, "6-31g")
+
+    def body(rank, allreduce):
+        def solver(jobs):
+            out = good(jobs)
+            if rank == 1:
+                for job, r in zip(jobs, out):
+                    if len(job.atoms) == 6:
+                        r.error = "pair made to fail"
+            return out
+        return fmo.run_fmo2(system, ScfSettings(basis_set="6-31g"), expansion="fmo", rank=rank, world=2,
+                            allreduce=allreduce, solver=solver)
+    runs = _thread_ranks(2, body)
+    for rank, run in enumerate(runs):
+        assert isinstance(run, fmo.FmoRun), run
+        assert np.isnan(run.energy) and not run.converged and run.errors, (rank, run)
+    assert "pair made to fail" in runs[1].errors[0]
+    serial = fmo.run_fmo2(system, ScfSettings(basis_set="6-31g"), expansion="fmo", solver=good)
+    assert serial.converged and np.isfinite(serial.energy)
+
+
+def test_failed_monomer_in_exact_esp_mode_is_refused_not_a_crash():
+    """esp = "exact": a monomer that fails in the bare pass leaves no density; the next pass must not be built from it
+    (it used to dereference None in the Coulomb requests)."""
+    system = w3_system()
+    good = oracle_fmo_solver(system, "6-31g")
+    calls = []
+
+    def solver(jobs):
+        out = good(jobs)
+        calls.append(len(jobs))
+        if len(calls) == 1:
+            out[1].error = "bare pass made to fail"
+        return out
+    run = fmo.run_fmo2(system, ScfSettings(basis_set="6-31g"), expansion="fmo", esp="exact", solver=solver,
+                       coulomb=oracle_cross_coulomb(system, "6-31g"))
+    assert np.isnan(run.energy) and not run.converged and "bare pass made to fail" in run.errors[0]
+    assert calls == [3]                                  # nothing after the failed pass was attempted
+
+
+def test_outer_loop_that_does_not_settle_is_an_error():
+    """calculate_monomers (mqc_libcint_fmo.f90:1560-1563): max_outer passes without settling -> error, no pair phase."""
+    system = w3_system()
+    calls = []
+    good = oracle_fmo_solver(system, "6-31g")
+
+    def solver(jobs):
+        calls.append(len(jobs))
+        return good(jobs)
+    run = fmo.run_fmo2(system, ScfSettings(basis_set="6-31g"), expansion="fmo", max_outer=1, outer_tol=1e-14, solver=solver)
+    assert np.isnan(run.energy) and not run.converged
+    assert "did not settle in 1 passes" in run.errors[-1]
+    assert calls == [3, 3]                               # bare pass + one embedded pass, no n-mer batch
