@@ -4,10 +4,13 @@
 !!
 !! Exports exactly what hf_run / dft_run import (src/methods/mqc_method_hf.F90:197-216,
 !! mqc_method_dft.F90:223):  run_cuest_scf(settings, fragment, result, want_gradient) and
-!! cuest_backend_available().  Basis-file parsing and error_t stay on this side; the engine gets
+!! cuest_backend_available() -- plus run_cuest_scf_batch(settings, fragments(:), results(:), want_gradient),
+!! the same call for MANY fragments at once (SURVEY.md section 8f item 4; used by the batched worker loop of
+!! fortran/mqc_hip_node_worker.f90).  Basis-file parsing and error_t stay on this side; the engine gets
 !! plain arrays through fortran/mqc_hip_c.f90.  It uses metalquicha's own modules and is built inside
-!! metalquicha's tree (INTEGRATION.md); fortran/check_bridge.sh compiles it here against interface
-!! stubs of those modules (fortran/stubs/, declarations only) so that it is type-checked in this repo.
+!! metalquicha's tree (INTEGRATION.md); fortran/check_bridge.sh compiles it here against stand-ins
+!! of those modules (fortran/stubs/) and RUNS it: fortran/check_bridge.f90 reproduces the reference's
+!! check_rhf energy through this file on a GPU box.
 !!
 !! What it does, step by step, is run_cuest_scf's own sequence (backends/cuest/backend/mqc_cuest_driver.f90:37-276):
 !! element symbols -> load_basis(orbital) [+ load_basis(auxiliary) when density_fitting] -> context ->
@@ -15,8 +18,12 @@
 !! The flattened shells are cached per (basis name, element sequence): the reference re-builds
 !! molecular_basis_type for every fragment from a cached JSON tree (:82-88); an MBE job sees two or three
 !! distinct element sequences, so after the first monomer and the first dimer nothing is parsed again.
+!! The cache is least-recently-used over CACHE_SLOTS entries and NEVER evicts an entry the call in flight points
+!! at (each call pins what it uses; a batch that needs more distinct entries than there are slots is cut into
+!! sub-batches).
 module mqc_cuest_bridge
    use, intrinsic :: iso_c_binding
+   use, intrinsic :: iso_fortran_env, only: int64
    use pic_types, only: dp
    use mqc_cuest_iface, only: cuest_scf_settings_t
    use mqc_physical_fragment, only: physical_fragment_t
@@ -31,7 +38,10 @@ module mqc_cuest_bridge
    private
 
    public :: run_cuest_scf
+   public :: run_cuest_scf_batch
    public :: cuest_backend_available
+   public :: hip_device_visible
+   public :: bridge_basis_cache_misses
 
    !> One flattened basis: the arrays an mqc_hip_basis_t points into
    type :: flat_basis_t
@@ -43,16 +53,34 @@ module mqc_cuest_bridge
       integer :: n_ao = 0
    end type flat_basis_t
 
-   integer, parameter :: CACHE_SLOTS = 8
+   integer, parameter :: CACHE_SLOTS = 32
    type(flat_basis_t), target, save :: cache(CACHE_SLOTS)
-   integer, save :: cache_next = 1
+   integer(int64), save :: last_used(CACHE_SLOTS) = 0_int64      !! LRU clock value of the slot's last hit
+   logical, save :: pinned(CACHE_SLOTS) = .false.                !! in use by the call in flight: not evictable
+   integer(int64), save :: lru_clock = 0_int64
+   integer, save :: cache_misses = 0
 
 contains
 
-   logical function cuest_backend_available() result(available)
-      !! .true. when a HIP device is visible to this process
-      available = mqc_hip_backend_available() /= 0
+   pure function cuest_backend_available() result(available)
+      !! .true. -- this build has the GPU backend.  Same signature and meaning as the reference's
+      !! (backends/cuest/backend/mqc_cuest_bridge.f90:20-30: "a property of the binary that linked"): it is asked by
+      !! the deck reader on every rank, coordinator included (src/io/mqc_json_config_reader.f90:1149), so it must not
+      !! depend on a device being visible to the asking process.  A rank without a device gets the engine's
+      !! "no HIP device" error from run_cuest_scf itself.
+      logical :: available
+      available = .true.
    end function cuest_backend_available
+
+   logical function hip_device_visible() result(visible)
+      !! Whether a HIP device is visible to THIS process right now (not part of the reference interface)
+      visible = mqc_hip_backend_available() /= 0
+   end function hip_device_visible
+
+   integer function bridge_basis_cache_misses() result(n)
+      !! How many times a basis file had to be parsed and flattened (diagnostics and fortran/check_bridge.f90)
+      n = cache_misses
+   end function bridge_basis_cache_misses
 
    subroutine run_cuest_scf(settings, fragment, result, want_gradient)
       type(cuest_scf_settings_t), intent(in) :: settings
@@ -61,7 +89,6 @@ contains
       logical, intent(in), optional :: want_gradient
 
       type(error_t) :: error
-      type(flat_basis_t), pointer :: orb_flat, aux_flat
       type(c_ptr) :: ctx
       type(mqc_hip_molecule_t) :: mol
       type(mqc_hip_basis_t), target :: orb, aux
@@ -71,40 +98,238 @@ contains
       integer(c_int8_t), allocatable, target :: ghost(:)
       real(c_double), allocatable, target :: xyz(:), eps(:), grad(:)
       logical :: need_gradient
-      integer :: rc, i
+      integer :: rc, orb_slot, aux_slot
 
       need_gradient = .false.
       if (present(want_gradient)) need_gradient = want_gradient
 
+      pinned = .false.
       ! ---- basis sets: same loader, same refusal of Cartesian sets (mqc_cuest_driver.f90:299-344)
-      call flat_basis(settings%basis_set, fragment, "orbital", orb_flat, error)
+      call flat_basis(settings%basis_set, fragment, "orbital", orb_slot, error)
       if (error%has_error()) then
          call fail(result, ERROR_VALIDATION, error%get_message()); return
       end if
-      call point_at(orb_flat, fragment%n_atoms, orb)
-      aux_flat => null()
+      call point_at(cache(orb_slot), fragment%n_atoms, orb)
       if (settings%density_fitting) then
-         call flat_basis(settings%aux_basis_set, fragment, "auxiliary", aux_flat, error)
+         call flat_basis(settings%aux_basis_set, fragment, "auxiliary", aux_slot, error)     ! cannot evict orb_slot: pinned
          if (error%has_error()) then
+            pinned = .false.
             call fail(result, ERROR_VALIDATION, error%get_message()); return
          end if
-         call point_at(aux_flat, fragment%n_atoms, aux)
+         call point_at(cache(aux_slot), fragment%n_atoms, aux)
       end if
 
-      allocate (z(fragment%n_atoms), xyz(3*fragment%n_atoms))
-      z = fragment%element_numbers
-      xyz = reshape(fragment%coordinates, [3*fragment%n_atoms])        ! (3,n) column-major == atom-major
+      allocate (z(fragment%n_atoms), xyz(3*fragment%n_atoms), ghost(fragment%n_atoms))
+      call flatten_fragment(fragment, z, xyz, ghost, mol)
+
+      call map_options(settings, need_gradient, opts, error)
+      if (error%has_error()) then
+         pinned = .false.
+         call fail(result, ERROR_VALIDATION, error%get_message()); return
+      end if
+
+      ! ---- context (process-wide singleton; device = device_rank mod device_count) and the run
+      rc = mqc_hip_context_get(int(settings%device_rank, c_int32_t), ctx)
+      if (rc /= MQC_HIP_OK) then
+         pinned = .false.
+         call fail(result, ERROR_GENERIC, c_message(mqc_hip_last_error())); return
+      end if
+      allocate (eps(max(cache(orb_slot)%n_ao, 1)))
+      call blank_result(res)
+      res%orbital_energies = c_loc(eps)
+      if (need_gradient) then
+         allocate (grad(3*fragment%n_atoms))
+         grad = 0.0_c_double
+         res%gradient = c_loc(grad)
+      end if
+      if (settings%density_fitting) then
+         rc = mqc_hip_scf_run(ctx, mol, orb, c_loc(aux), opts, res)
+      else
+         rc = mqc_hip_scf_run(ctx, mol, orb, c_null_ptr, opts, res)
+      end if
+      pinned = .false.
+      if (need_gradient) then
+         call unpack_result(rc, res, fragment%n_atoms, need_gradient, result, grad)
+      else
+         call unpack_result(rc, res, fragment%n_atoms, need_gradient, result)
+      end if
+   end subroutine run_cuest_scf
+
+   subroutine run_cuest_scf_batch(settings, fragments, results, want_gradient)
+      !! run_cuest_scf for many fragments in ONE engine call (mqc_hip_scf_run_batch): the engine groups them by
+      !! topology and advances each group through every SCF stage in single launches.  A fragment that fails is
+      !! reported in its own result (has_error, error) and does not fail the others -- what a worker gets today
+      !! from calling do_fragment_work once per fragment
+      !! (src/fragmentation/mbe/mqc_mbe_mpi_fragment_distribution_scheme.F90:156-238).
+      type(cuest_scf_settings_t), intent(in) :: settings
+      type(physical_fragment_t), intent(in) :: fragments(:)
+      type(calculation_result_t), intent(inout) :: results(:)
+      logical, intent(in), optional :: want_gradient
+
+      logical :: need_gradient
+      integer :: n, first, last, i
+      integer, allocatable :: orb_slot(:), aux_slot(:)
+      type(error_t) :: error
+      integer :: needed
+
+      need_gradient = .false.
+      if (present(want_gradient)) need_gradient = want_gradient
+      n = size(fragments)
+      if (size(results) < n) then
+         do i = 1, size(results)
+            call fail(results(i), ERROR_VALIDATION, "run_cuest_scf_batch: fewer results than fragments")
+         end do
+         return
+      end if
+      allocate (orb_slot(n), aux_slot(n))
+      orb_slot = 0; aux_slot = 0
+
+      ! Sub-batches: as many consecutive fragments as the cache can pin at once (each distinct (basis, element
+      ! sequence) takes one slot; an MBE list needs two or three, so in practice this loop runs once)
+      first = 1
+      do while (first <= n)
+         pinned = .false.
+         last = first - 1
+         do i = first, n
+            needed = merge(2, 1, settings%density_fitting)
+            if (count(.not. pinned) < needed) exit          ! might need new slots and none could be evicted
+            call flat_basis(settings%basis_set, fragments(i), "orbital", orb_slot(i), error)
+            if (.not. error%has_error() .and. settings%density_fitting) &
+               call flat_basis(settings%aux_basis_set, fragments(i), "auxiliary", aux_slot(i), error)
+            if (error%has_error()) then
+               call fail(results(i), ERROR_VALIDATION, error%get_message())
+               orb_slot(i) = 0                              ! left out of the engine call
+            end if
+            last = i
+         end do
+         if (last < first) then
+            call fail(results(first), ERROR_GENERIC, "run_cuest_scf_batch: basis cache exhausted")
+            last = first
+         else
+            call run_sub_batch(settings, fragments(first:last), results(first:last), orb_slot(first:last), &
+                               aux_slot(first:last), need_gradient)
+         end if
+         first = last + 1
+      end do
+      pinned = .false.
+   end subroutine run_cuest_scf_batch
+
+   subroutine run_sub_batch(settings, fragments, results, orb_slot, aux_slot, need_gradient)
+      type(cuest_scf_settings_t), intent(in) :: settings
+      type(physical_fragment_t), intent(in) :: fragments(:)
+      type(calculation_result_t), intent(inout) :: results(:)
+      integer, intent(in) :: orb_slot(:), aux_slot(:)
+      logical, intent(in) :: need_gradient
+
+      type(c_ptr) :: ctx
+      type(mqc_hip_scf_options_t) :: opts
+      type(error_t) :: error
+      type(mqc_hip_molecule_t), allocatable :: mols(:)
+      type(mqc_hip_basis_t), allocatable, target :: orbs(:), auxes(:)
+      type(mqc_hip_scf_result_t), allocatable :: res(:)
+      integer(c_int32_t), allocatable, target :: z(:)
+      integer(c_int8_t), allocatable, target :: ghost(:)
+      real(c_double), allocatable, target :: xyz(:), eps(:), grad(:)
+      integer, allocatable :: which(:), atom_off(:), eps_off(:)
+      integer :: n, m, i, k, rc, natoms_total, eps_total
+
+      n = size(fragments)
+      allocate (which(n))
+      m = 0
+      do i = 1, n
+         if (orb_slot(i) > 0) then
+            m = m + 1; which(m) = i
+         end if
+      end do
+      if (m == 0) return
+
+      call map_options(settings, need_gradient, opts, error)
+      if (error%has_error()) then
+         do k = 1, m
+            call fail(results(which(k)), ERROR_VALIDATION, error%get_message())
+         end do
+         return
+      end if
+      rc = mqc_hip_context_get(int(settings%device_rank, c_int32_t), ctx)
+      if (rc /= MQC_HIP_OK) then
+         do k = 1, m
+            call fail(results(which(k)), ERROR_GENERIC, c_message(mqc_hip_last_error()))
+         end do
+         return
+      end if
+
+      allocate (atom_off(m + 1), eps_off(m + 1))
+      atom_off(1) = 0; eps_off(1) = 0
+      do k = 1, m
+         atom_off(k + 1) = atom_off(k) + fragments(which(k))%n_atoms
+         eps_off(k + 1) = eps_off(k) + max(cache(orb_slot(which(k)))%n_ao, 1)
+      end do
+      natoms_total = atom_off(m + 1); eps_total = eps_off(m + 1)
+      allocate (mols(m), orbs(m), auxes(m), res(m))
+      allocate (z(natoms_total), xyz(3*natoms_total), ghost(natoms_total), eps(eps_total))
+      if (need_gradient) then
+         allocate (grad(3*natoms_total))
+         grad = 0.0_c_double
+      end if
+      do k = 1, m
+         i = which(k)
+         call flatten_fragment(fragments(i), z(atom_off(k) + 1:atom_off(k + 1)), xyz(3*atom_off(k) + 1:3*atom_off(k + 1)), &
+                               ghost(atom_off(k) + 1:atom_off(k + 1)), mols(k))
+         call point_at(cache(orb_slot(i)), fragments(i)%n_atoms, orbs(k))
+         if (settings%density_fitting) call point_at(cache(aux_slot(i)), fragments(i)%n_atoms, auxes(k))
+         call blank_result(res(k))
+         res(k)%orbital_energies = c_loc(eps(eps_off(k) + 1))
+         if (need_gradient) res(k)%gradient = c_loc(grad(3*atom_off(k) + 1))
+      end do
+
+      if (settings%density_fitting) then
+         rc = mqc_hip_scf_run_batch(ctx, int(m, c_int64_t), mols, orbs, c_loc(auxes), opts, res)
+      else
+         rc = mqc_hip_scf_run_batch(ctx, int(m, c_int64_t), mols, orbs, c_null_ptr, opts, res)
+      end if
+      ! per-fragment failures are in res(k); a call-level failure that left a fragment without its own message
+      ! (device lost, out of memory) is that fragment's error too
+      do k = 1, m
+         i = which(k)
+         if (need_gradient) then
+            call unpack_result(merge(rc, MQC_HIP_OK, res(k)%has_error == 0 .and. res(k)%scf_status == MQC_HIP_SCF_NOT_RUN), &
+                               res(k), fragments(i)%n_atoms, need_gradient, results(i), &
+                               grad(3*atom_off(k) + 1:3*atom_off(k + 1)))
+         else
+            call unpack_result(merge(rc, MQC_HIP_OK, res(k)%has_error == 0 .and. res(k)%scf_status == MQC_HIP_SCF_NOT_RUN), &
+                               res(k), fragments(i)%n_atoms, need_gradient, results(i))
+         end if
+      end do
+   end subroutine run_sub_batch
+
+   subroutine flatten_fragment(fragment, z, xyz, ghost, mol)
+      !! physical_fragment_t -> mqc_hip_molecule_t over caller-owned arrays (which must outlive the engine call)
+      type(physical_fragment_t), intent(in) :: fragment
+      integer(c_int32_t), intent(out), target, contiguous :: z(:)
+      real(c_double), intent(out), target, contiguous :: xyz(:)
+      integer(c_int8_t), intent(out), target, contiguous :: ghost(:)
+      type(mqc_hip_molecule_t), intent(out) :: mol
+      z = fragment%element_numbers(1:fragment%n_atoms)
+      xyz = reshape(fragment%coordinates(:, 1:fragment%n_atoms), [3*fragment%n_atoms])   ! (3,n) column-major == atom-major
       mol%n_atoms = fragment%n_atoms; mol%atomic_numbers = c_loc(z); mol%xyz = c_loc(xyz)
       mol%charge = fragment%charge; mol%multiplicity = fragment%multiplicity; mol%nelec = fragment%nelec
       mol%ghost = c_null_ptr
       mol%n_point_charges = 0; mol%point_charge_xyz = c_null_ptr; mol%point_charges = c_null_ptr
       mol%h_extra = c_null_ptr
+      ghost = 0_c_int8_t
       if (allocated(fragment%is_ghost)) then
-         allocate (ghost(fragment%n_atoms))
-         ghost = merge(1_c_int8_t, 0_c_int8_t, fragment%is_ghost)
+         ghost = merge(1_c_int8_t, 0_c_int8_t, fragment%is_ghost(1:fragment%n_atoms))
          mol%ghost = c_loc(ghost)
       end if
+   end subroutine flatten_fragment
 
+   subroutine map_options(settings, need_gradient, opts, error)
+      !! cuest_scf_settings_t -> mqc_hip_scf_options_t (the fields run_cuest_scf acts on, mqc_cuest_driver.f90:93-135)
+      type(cuest_scf_settings_t), intent(in) :: settings
+      logical, intent(in) :: need_gradient
+      type(mqc_hip_scf_options_t), intent(out) :: opts
+      type(error_t), intent(out) :: error
+      integer :: i
       call mqc_hip_default_options(opts)
       do i = 1, min(31, len_trim(settings%functional))
          opts%functional(i) = settings%functional(i:i)
@@ -122,34 +347,35 @@ contains
       case ("sac"); opts%guess = MQC_HIP_GUESS_SAC
       case default
          ! refused rather than replaced by another guess, as the cuEST driver does (:104-121)
-         call fail(result, ERROR_VALIDATION, "initial guess '"//trim(settings%guess)// &
-                   "' is not available on the HIP backend"); return
+         call error%set(ERROR_VALIDATION, "initial guess '"//trim(settings%guess)// &
+                        "' is not available on the HIP backend")
+         return
       end select
       opts%unrestricted = merge(1, 0, settings%unrestricted)
       opts%want_gradient = merge(1, 0, need_gradient)
       opts%allow_crap_scf = merge(1, 0, settings%allow_crap_scf)
       opts%verbose = merge(1, 0, settings%verbose)
+   end subroutine map_options
 
-      ! ---- context (process-wide singleton; device = device_rank mod device_count) and the run
-      rc = mqc_hip_context_get(int(settings%device_rank, c_int32_t), ctx)
-      if (rc /= MQC_HIP_OK) then
-         call fail(result, ERROR_GENERIC, c_message(mqc_hip_last_error())); return
-      end if
-      allocate (eps(max(orb_flat%n_ao, 1)))
-      res%orbital_energies = c_loc(eps); res%density = c_null_ptr
+   subroutine blank_result(res)
+      type(mqc_hip_scf_result_t), intent(out) :: res
+      res%orbital_energies = c_null_ptr; res%density = c_null_ptr
       res%orbital_energies_beta = c_null_ptr
       res%gradient = c_null_ptr
       res%embedding_matrix = c_null_ptr; res%mulliken_charges = c_null_ptr
-      if (need_gradient) then
-         allocate (grad(3*fragment%n_atoms))
-         grad = 0.0_c_double
-         res%gradient = c_loc(grad)
-      end if
-      if (settings%density_fitting) then
-         rc = mqc_hip_scf_run(ctx, mol, orb, c_loc(aux), opts, res)
-      else
-         rc = mqc_hip_scf_run(ctx, mol, orb, c_null_ptr, opts, res)
-      end if
+      res%has_error = 0; res%scf_status = MQC_HIP_SCF_NOT_RUN; res%iterations = 0
+      res%has_dipole = 0; res%has_gradient = 0; res%has_orbitals = 0
+      res%message = c_null_char
+   end subroutine blank_result
+
+   subroutine unpack_result(rc, res, n_atoms, need_gradient, result, grad)
+      !! what run_cuest_scf writes into calculation_result_t (mqc_cuest_driver.f90:211-275)
+      integer, intent(in) :: rc
+      type(mqc_hip_scf_result_t), intent(in) :: res
+      integer, intent(in) :: n_atoms
+      logical, intent(in) :: need_gradient
+      type(calculation_result_t), intent(inout) :: result
+      real(c_double), intent(in), optional :: grad(:)
 
       result%scf_iterations = res%iterations
       if (res%scf_status == MQC_HIP_SCF_CONVERGED) result%scf_status = SCF_CONVERGED
@@ -173,38 +399,43 @@ contains
          result%dipole = res%dipole
          result%has_dipole = .true.
       end if
-      if (need_gradient .and. res%has_gradient /= 0) then
+      if (need_gradient .and. res%has_gradient /= 0 .and. present(grad)) then
          if (allocated(result%gradient)) deallocate (result%gradient)
-         allocate (result%gradient(3, fragment%n_atoms))
-         result%gradient = reshape(grad, [3, fragment%n_atoms])
+         allocate (result%gradient(3, n_atoms))
+         result%gradient = reshape(grad(1:3*n_atoms), [3, n_atoms])
          result%has_gradient = .true.
       end if
-   end subroutine run_cuest_scf
+   end subroutine unpack_result
 
-   subroutine flat_basis(basis_name, fragment, role, flat, error)
-      !! load_basis (mqc_cuest_driver.f90:299-344) + flattening, cached per (name, element sequence)
+   subroutine flat_basis(basis_name, fragment, role, slot, error)
+      !! load_basis (mqc_cuest_driver.f90:299-344) + flattening, cached per (name, element sequence).  The slot
+      !! returned is PINNED until the caller clears `pinned`; a miss takes the least recently used unpinned slot.
       character(len=*), intent(in) :: basis_name
       type(physical_fragment_t), intent(in) :: fragment
       character(len=*), intent(in) :: role
-      type(flat_basis_t), pointer, intent(out) :: flat
+      integer, intent(out) :: slot
       type(error_t), intent(out) :: error
 
       type(molecular_basis_type) :: basis
+      type(flat_basis_t), pointer :: flat
       character(len=:), allocatable :: path
       character(len=2), allocatable :: symbols(:)
-      integer :: slot, iatom, ish, nsh, nprim, off
+      integer :: s, iatom, ish, nsh, nprim, off
 
-      flat => null()
+      slot = 0
       if (len_trim(basis_name) == 0) then
          call error%set(ERROR_VALIDATION, "No basis set specified")
          return
       end if
-      do slot = 1, CACHE_SLOTS
-         if (.not. allocated(cache(slot)%z)) cycle
-         if (trim(cache(slot)%name) /= trim(basis_name)) cycle
-         if (size(cache(slot)%z) /= fragment%n_atoms) cycle
-         if (any(cache(slot)%z /= fragment%element_numbers(1:fragment%n_atoms))) cycle
-         flat => cache(slot)
+      lru_clock = lru_clock + 1_int64
+      do s = 1, CACHE_SLOTS
+         if (.not. allocated(cache(s)%z)) cycle
+         if (trim(cache(s)%name) /= trim(basis_name)) cycle
+         if (size(cache(s)%z) /= fragment%n_atoms) cycle
+         if (any(cache(s)%z /= fragment%element_numbers(1:fragment%n_atoms))) cycle
+         slot = s
+         last_used(s) = lru_clock
+         pinned(s) = .true.
          return
       end do
 
@@ -236,8 +467,23 @@ contains
          end do
       end do
 
-      slot = cache_next
-      cache_next = mod(cache_next, CACHE_SLOTS) + 1
+      ! victim: an empty slot, else the least recently used one that the call in flight does not point at
+      do s = 1, CACHE_SLOTS
+         if (pinned(s)) cycle
+         if (.not. allocated(cache(s)%z)) then
+            slot = s; exit
+         end if
+         if (slot == 0) then
+            slot = s
+         else if (last_used(s) < last_used(slot)) then
+            slot = s
+         end if
+      end do
+      if (slot == 0) then
+         call error%set(ERROR_GENERIC, "basis cache: every slot is in use by the call in flight")
+         return
+      end if
+      cache_misses = cache_misses + 1
       flat => cache(slot)
       if (allocated(flat%z)) deallocate (flat%z, flat%nshell_per_atom, flat%shell_l, flat%shell_nprim, flat%exps, flat%coefs)
       flat%name = basis_name
@@ -258,11 +504,13 @@ contains
          end do
       end do
       call basis%destroy()
+      last_used(slot) = lru_clock
+      pinned(slot) = .true.
    end subroutine flat_basis
 
    subroutine point_at(flat, n_atoms, pod)
       !! the POD of include/mqc_hip.h over a cached flattened basis
-      type(flat_basis_t), pointer, intent(in) :: flat
+      type(flat_basis_t), intent(in), target :: flat
       integer, intent(in) :: n_atoms
       type(mqc_hip_basis_t), intent(out) :: pod
       pod%spherical = 1; pod%n_atoms = n_atoms; pod%n_shells = size(flat%shell_l)

@@ -1,7 +1,10 @@
-!! Interface stubs of the metalquicha modules fortran/mqc_hip_bridge.f90 uses -- DECLARATIONS ONLY, so that the
-!! bridge can be type-checked with flang inside this repository (fortran/check_bridge.sh).  They restate the
-!! names, kinds and argument lists of the reference's public entities and nothing of their implementation;
-!! inside metalquicha's tree the bridge compiles against the real modules and these files are not used.
+!! Stand-ins of the metalquicha modules fortran/mqc_hip_bridge.f90 uses, so that the bridge can be compiled with flang
+!! AND RUN inside this repository (fortran/check_bridge.sh).  They restate the names, kinds and argument lists of the
+!! reference's public entities and nothing of their implementation; the one stand-in that does work is the basis
+!! reader, which reads this repository's own flat text files (fortran/make_flat_basis.py writes them from
+!! metalquicha_amd/basis_data/*.json: one shell per contraction row, SP shells split, raw coefficients -- what
+!! build_molecular_basis_json delivers) instead of Basis Set Exchange JSON.
+!! Inside metalquicha's tree the bridge compiles against the real modules and these files are not used.
 !!   pic_types                dp                                   (pic library, fpm.toml:29)
 !!   mqc_error                error_t, ERROR_*                     src/utils/mqc_error.f90:12-44
 !!   mqc_cgto                 cgto_type, atomic_basis_type, molecular_basis_type   src/basis/mqc_cgto.f90:24-74
@@ -82,28 +85,88 @@ contains
 end module mqc_cgto
 
 module mqc_basis_utils
-   use mqc_error, only: error_t
+   use mqc_error, only: error_t, ERROR_IO
    implicit none
 contains
    subroutine find_basis_file(basis_name, filename, error)
+      !! <name>.flat in $MQC_FLAT_BASIS_PATH (default: fortran/_build/basis next to the working directory)
       character(len=*), intent(in) :: basis_name
       character(len=:), allocatable, intent(out) :: filename
       type(error_t), intent(out) :: error
-      filename = trim(basis_name)//".json"
+      character(len=1024) :: dir
+      integer :: length, status
+      logical :: there
+      call get_environment_variable("MQC_FLAT_BASIS_PATH", dir, length, status)
+      if (status /= 0 .or. length == 0) then
+         dir = "_build/basis"; length = len_trim(dir)
+      end if
+      filename = dir(1:length)//"/"//trim(basis_name)//".flat"
+      inquire (file=filename, exist=there)
+      if (.not. there) call error%set(ERROR_IO, "basis set file not found: "//filename)
    end subroutine
 end module mqc_basis_utils
 
 module mqc_json_basis_reader
-   use mqc_error, only: error_t
-   use mqc_cgto, only: molecular_basis_type
+   use pic_types, only: dp
+   use mqc_error, only: error_t, ERROR_PARSE
+   use mqc_cgto, only: molecular_basis_type, atomic_basis_type
    implicit none
+   integer, save :: stub_reader_calls = 0        !! how many times a file was read (fortran/check_bridge.f90 watches it)
 contains
    subroutine build_molecular_basis_json(json_path, element_symbols, mol_basis, error)
+      !! Flat-file stand-in of the reference's reader (src/basis/mqc_json_basis_reader.f90:332): same arguments, same
+      !! result type.  File: "nelements", then per element "symbol nshells", per shell "l nprim" and nprim lines
+      !! "exponent coefficient".  An element the file lacks comes back with nshells = 0, as the reference does.
       character(len=*), intent(in) :: json_path
       character(len=*), intent(in) :: element_symbols(:)
       type(molecular_basis_type), intent(out) :: mol_basis
       type(error_t), intent(out) :: error
+      type(atomic_basis_type), allocatable :: table(:)
+      integer :: unit, ios, nel, ie, ish, ip, ia
+      character(len=2) :: sym
+      stub_reader_calls = stub_reader_calls + 1
+      open (newunit=unit, file=json_path, status="old", action="read", iostat=ios)
+      if (ios /= 0) then
+         call error%set(ERROR_PARSE, "cannot open "//json_path); return
+      end if
+      read (unit, *, iostat=ios) nel
+      if (ios /= 0) then
+         call error%set(ERROR_PARSE, "bad header in "//json_path); close (unit); return
+      end if
+      allocate (table(nel))
+      do ie = 1, nel
+         read (unit, *, iostat=ios) sym, table(ie)%nshells
+         if (ios /= 0) then
+            call error%set(ERROR_PARSE, "bad element record in "//json_path); close (unit); return
+         end if
+         table(ie)%element = trim(sym)
+         allocate (table(ie)%shells(table(ie)%nshells))
+         do ish = 1, table(ie)%nshells
+            read (unit, *, iostat=ios) table(ie)%shells(ish)%ang_mom, table(ie)%shells(ish)%nfunc
+            if (ios /= 0) then
+               call error%set(ERROR_PARSE, "bad shell record in "//json_path); close (unit); return
+            end if
+            allocate (table(ie)%shells(ish)%exponents(table(ie)%shells(ish)%nfunc), &
+                      table(ie)%shells(ish)%coefficients(table(ie)%shells(ish)%nfunc))
+            do ip = 1, table(ie)%shells(ish)%nfunc
+               read (unit, *, iostat=ios) table(ie)%shells(ish)%exponents(ip), table(ie)%shells(ish)%coefficients(ip)
+               if (ios /= 0) then
+                  call error%set(ERROR_PARSE, "bad primitive record in "//json_path); close (unit); return
+               end if
+            end do
+         end do
+      end do
+      close (unit)
       allocate (mol_basis%elements(size(element_symbols)))
+      mol_basis%nelements = size(element_symbols)
+      do ia = 1, size(element_symbols)
+         do ie = 1, nel
+            if (trim(table(ie)%element) == trim(element_symbols(ia))) then
+               mol_basis%elements(ia) = table(ie)
+               exit
+            end if
+         end do
+      end do
    end subroutine
 end module mqc_json_basis_reader
 
@@ -113,8 +176,9 @@ contains
    pure function element_number_to_symbol(atomic_number) result(symbol)
       integer, intent(in) :: atomic_number
       character(len=2) :: symbol
+      character(len=2), parameter :: table(10) = ["H ", "He", "Li", "Be", "B ", "C ", "N ", "O ", "F ", "Ne"]
       symbol = "X "
-      if (atomic_number == 1) symbol = "H "
+      if (atomic_number >= 1 .and. atomic_number <= 10) symbol = table(atomic_number)
    end function
 end module mqc_elements
 

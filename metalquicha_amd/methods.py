@@ -265,7 +265,7 @@ def run_hip_scf(settings: ScfSettings, fragment: PhysicalFragment, result: Optio
         if grad is not None and r.has_gradient and not r.has_error:
             result.gradient = grad.T.copy()              # (3, n_atoms) like result%gradient
             result.has_gradient = True
-        if result.has_energy and int(r.n_alpha) != int(r.n_beta) or settings.unrestricted:
+        if result.has_energy and (int(r.n_alpha) != int(r.n_beta) or settings.unrestricted):
             result.orbital_energies_beta = epsb[: int(r.n_mo)].copy()
         return result
     except (capi.HipBackendError, BasisError) as e:

@@ -61,14 +61,21 @@ def near_fragments(z, xyz, frags, group, resppc):
 def run_fmo2(make_mol: Callable[[Sequence[int]], "so.OracleMol"], z: np.ndarray, xyz: np.ndarray,
              fragments: Sequence[Sequence[int]], expansion: str = "fmo", max_outer: int = 50, outer_tol: float = 1e-7,
              scf_max_iter: int = 100, e_tol: float = 1e-9, d_tol: float = 1e-7, esp: str = "ptc",
-             resppc: float = 2.0, level: int = 2, far_field: str = "mulliken") -> FmoOracleResult:
-    """make_mol(atom indices) -> OracleMol of those atoms; z (n_atoms,), xyz (n_atoms, 3) Bohr."""
+             resppc: float = 2.0, level: int = 2, far_field: str = "mulliken",
+             scf_extra: Callable[[Sequence[int], "so.OracleMol"], dict] = None) -> FmoOracleResult:
+    """make_mol(atom indices) -> OracleMol of those atoms; z (n_atoms,), xyz (n_atoms, 3) Bohr.
+
+    scf_extra(atom indices, mol) -> extra keyword arguments of so.run_rhf for that fragment / n-mer (`aux` for a
+    density-fitted run, `xc` for a Kohn-Sham one).  The reference's driver itself calls run_libcint_rhf without them
+    (inner_scf :1950-1999): this is the same driver around the density-fitted Kohn-Sham SCF the cuEST path runs, the
+    form BASELINE.json's configs[4] ("FMO-2 DF-RKS") names."""
     n_atoms, nfrag = len(z), len(fragments)
     frags = [list(map(int, f)) for f in fragments]
     mols = [make_mol(f) for f in frags]
     nelec = [int(sum(z[f])) for f in frags]
     cutoff = 0.0 if esp == "ptc" else resppc          # effective_resppc
     state: list = []
+    extra = scf_extra or (lambda atoms, mol: {})
 
     def field_of(mol, group, q_all):
         inside = [a for g in group for a in frags[g]]
@@ -91,7 +98,8 @@ def run_fmo2(make_mol: Callable[[Sequence[int]], "so.OracleMol"], z: np.ndarray,
 
     def solve(i, q_all, bare):
         u = None if bare else field_of(mols[i], [i], q_all)
-        r = so.run_rhf(mols[i], nelec[i], max_iter=scf_max_iter, e_tol=e_tol, d_tol=d_tol, guess="gwh", h_extra=u)
+        r = so.run_rhf(mols[i], nelec[i], max_iter=scf_max_iter, e_tol=e_tol, d_tol=d_tol, guess="gwh", h_extra=u,
+                       **extra(frags[i], mols[i]))
         S, _, _ = so.int1e(mols[i])
         e_int = r.energy - (float(np.sum(r.D * u)) if u is not None else 0.0)
         return r.energy, e_int, r.D, so.mulliken_charges(mols[i], r.D, S)
@@ -124,7 +132,8 @@ def run_fmo2(make_mol: Callable[[Sequence[int]], "so.OracleMol"], z: np.ndarray,
             atoms = [a for m in members for a in frags[m]]
             mol = make_mol(atoms)
             u = field_of(mol, list(members), q_all)
-            r = so.run_rhf(mol, sum(nelec[m] for m in members), max_iter=scf_max_iter, e_tol=e_tol, d_tol=d_tol, guess="gwh", h_extra=u)
+            r = so.run_rhf(mol, sum(nelec[m] for m in members), max_iter=scf_max_iter, e_tol=e_tol, d_tol=d_tol, guess="gwh", h_extra=u,
+                           **extra(atoms, mol))
             e_internal, e_resp = r.energy, 0.0
             if u is not None and expansion != "mbe":
                 d_split = np.zeros_like(r.D)

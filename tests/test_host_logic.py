@@ -234,18 +234,45 @@ def test_two_rank_gloo_rehearsal_of_the_energy_reduction(tmp_path):
 
 
 def test_fortran_drop_in_bridge_compiles_and_runs():
-    """fortran/mqc_hip_bridge.f90 (module mqc_cuest_bridge: run_cuest_scf, cuest_backend_available) type-checked with
-    flang against interface stubs of the metalquicha modules it uses, linked with libmqc_hip.so and called once with
-    density_fitting and want_gradient set (the auxiliary basis goes through the same loader as the orbital one)."""
+    """fortran/mqc_hip_bridge.f90 (module mqc_cuest_bridge: run_cuest_scf, run_cuest_scf_batch,
+    cuest_backend_available) and fortran/mqc_hip_node_worker.f90 compiled with flang against stand-ins of the
+    metalquicha modules they use, linked with libmqc_hip.so and RUN.  Without a GPU the engine has no fallback, so the
+    programs must report the "no HIP device" error per fragment; on a GPU box the same executables produce energies
+    (tests/test_gpu_fortran.py)."""
     flang = "/opt/rocm/lib/llvm/bin/flang"
     if not os.path.isfile(flang):
         pytest.skip("no flang in this image")
     out = subprocess.run(["bash", os.path.join(ROOT, "fortran", "check_bridge.sh")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "has_error T has_energy F" in out.stdout
-    assert "has no entry for element" in out.stdout        # the stub reader hands back no shells: error_t path exercised
+    assert "backend available (property of the binary) T" in out.stdout       # pure, like the reference's
+    from metalquicha_amd import capi
+    if not capi.load_library().mqc_hip_backend_available():
+        assert "CHECK PASS no device: the call fails loudly" in out.stdout
+        assert "SUMMARY no_device failures 0" in out.stdout
+    env = dict(os.environ, MQC_FLAT_BASIS_PATH=os.path.join(ROOT, "fortran", "_build", "basis"))
+    nw = subprocess.run([os.path.join(ROOT, "fortran", "_build", "check_node_worker")], capture_output=True, text=True, env=env, timeout=300)
+    assert nw.returncode == 0, nw.stdout + nw.stderr
+    assert "CHECK PASS every task has exactly one result" in nw.stdout and "SUMMARY failures 0" in nw.stdout
     src = open(os.path.join(ROOT, "fortran", "mqc_hip_bridge.f90")).read()
     assert "c_loc(aux)" in src and "settings%aux_basis_set" in src
+    assert "pure function cuest_backend_available" in src                     # mqc_cuest_bridge.f90:20
+
+
+def test_node_worker_patch_applies_to_the_reference_file(tmp_path):
+    """fortran/patches/node_worker_batch.patch is a unified diff against the reference's distribution scheme; where the
+    reference tree is present (this container, not the GPU box) it must apply cleanly to a scratch copy."""
+    import shutil
+    ref = "/root/reference/src/fragmentation/mbe/mqc_mbe_mpi_fragment_distribution_scheme.F90"
+    patch = os.path.join(ROOT, "fortran", "patches", "node_worker_batch.patch")
+    assert os.path.isfile(patch)
+    if not os.path.isfile(ref) or shutil.which("patch") is None:
+        pytest.skip("no reference tree (or no patch tool) here")
+    work = tmp_path / "scheme.F90"
+    shutil.copyfile(ref, work)
+    out = subprocess.run(["patch", "--no-backup-if-mismatch", str(work), patch], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    text = work.read_text()
+    assert "fragment_batch_t" in text and "outstanding_fifo_t" in text and "run_cuest_scf_batch" not in open(ref).read()
 
 
 def test_fortran_iso_c_binding_module_links():

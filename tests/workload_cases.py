@@ -1,0 +1,65 @@
+"""Inputs and oracle recipes of tests/test_gpu_workloads.py, importable without a GPU so that
+tests/golden/record_oracle_fixtures.py can run the oracle side on the CPU and write tests/golden/oracle_fixtures.json."""
+import numpy as np
+
+from metalquicha_amd import mbe
+from metalquicha_amd.methods import ScfSettings
+
+AUX = "mqc-even-tempered-jkfit"
+
+# ---- configs[4] at reduced size: FMO-2, density-fitted B3LYP, (H2O)8 / cc-pVDZ ------------------------------------------
+FMO_DF_RKS_KEY = "cc-pvdz|b3lyp|df:%s|grid3|fmo2|ptc|mulliken|1e-9|1e-7|gwh|outer 1e-7" % AUX
+
+
+def fmo_df_rks_system():
+    return mbe.water_cluster(2, seed=11)
+
+
+def fmo_df_rks_settings():
+    return ScfSettings(basis_set="cc-pvdz", functional="b3lyp", density_fitting=True, aux_basis_set=AUX,
+                       energy_tol=1e-9, density_tol=1e-7, guess="gwh")
+
+
+def fmo_df_rks_oracle():
+    from oracle import fmo_oracle, xc_oracle
+    from tests.helpers import oracle_make_mol
+    system = fmo_df_rks_system()
+    make, make_aux = oracle_make_mol(system, "cc-pvdz"), oracle_make_mol(system, AUX)
+    cache = {}
+
+    def extra(atoms, mol):
+        # the grid, the fitted tensor's ingredients and the functional object of a fragment do not change between passes
+        key = tuple(atoms)
+        if key not in cache:
+            cache[key] = (make_aux(atoms), xc_oracle.XCOracle(mol, "b3lyp", 3))
+        aux, xc = cache[key]
+        return {"aux": aux, "xc": xc}
+    frags = [list(map(int, m)) for m in system.monomers]
+    r = fmo_oracle.run_fmo2(make, np.asarray(system.element_numbers), np.ascontiguousarray(system.coordinates.T), frags,
+                            expansion="fmo", scf_extra=extra)
+    return {"energy": float(r.energy), "iterations": int(r.outer_iterations), "converged": bool(r.converged),
+            "monomer_energy": [float(v) for v in r.monomer_energy], "response_sum": float(r.response_sum),
+            "charges": [float(v) for v in r.charges]}
+
+
+# ---- configs[3] at reduced size: GMBE(2), B3LYP / def2-TZVP, (H2O)3 -----------------------------------------------------
+GMBE_KEY = "def2-tzvp|b3lyp|grid3|1e-9|1e-7|gwh"
+
+
+def gmbe_system():
+    """The first three waters of a 2 x 2 x 2 cluster at 2.9 Angstrom spacing, fragments = molecules."""
+    full = mbe.water_cluster(2, spacing=2.9, seed=7)
+    keep = [int(a) for m in full.monomers[:3] for a in m]
+    return mbe.FragmentedSystem(np.asarray(full.element_numbers)[keep], np.ascontiguousarray(full.coordinates[:, keep]),
+                                [np.arange(3 * k, 3 * k + 3) for k in range(3)])
+
+
+def gmbe_settings():
+    return ScfSettings(basis_set="def2-tzvp", functional="b3lyp", energy_tol=1e-9, density_tol=1e-7, guess="gwh")
+
+
+def gmbe_fragment_oracle(frag):
+    from oracle import scf_oracle as so, xc_oracle
+    from tests.helpers import oracle_mol, scf_record
+    mol = oracle_mol("def2-tzvp", frag)
+    return scf_record(so.run_rhf(mol, int(frag.nelec), 100, 1e-9, 1e-7, xc=xc_oracle.XCOracle(mol, "b3lyp", 3)))
