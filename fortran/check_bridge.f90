@@ -1,6 +1,6 @@
 !! Runs the drop-in bridge (fortran/mqc_hip_bridge.f90, module mqc_cuest_bridge) from the Fortran side, the way
 !! hf_run / dft_run call it, and checks what comes back:
-!!   1. H2O / STO-3G at the geometry of the reference's validation/check_rhf.f90:112-116 -> -74.9658162796 (+- 1e-9),
+!!   1. H2O / STO-3G (the inline table of check_rhf.f90:149-177) at the geometry of the reference's validation/check_rhf.f90:112-116 -> -74.9658162796 (+- 1e-9),
 !!      the golden of validation/check_rhf.f90:142;
 !!   2. the same call again: served from the bridge's shell cache (the basis reader is not called, no cache miss),
 !!      same energy;
@@ -33,7 +33,7 @@ program check_bridge
    print "(a,l1)", "backend available (property of the binary) ", cuest_backend_available()
    print "(a,l1)", "device visible ", hip_device_visible()
    call make_water(water, 0.0_dp, [0.0_dp, 0.0_dp, 0.0_dp])
-   settings%basis_set = "sto-3g"
+   settings%basis_set = "sto-3g-check_rhf"     ! the eight-digit STO-3G written inline in validation/check_rhf.f90:149-177
    settings%guess = "gwh"
    settings%energy_tol = 1.0e-10_dp; settings%density_tol = 1.0e-8_dp
 

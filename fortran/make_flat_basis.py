@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 
 from metalquicha_amd import basis      # noqa: E402
 
-DEFAULT = ["sto-3g", "cc-pvdz", "6-31g", "def2-svp", "mqc-even-tempered-jkfit"]
+DEFAULT = ["sto-3g", "sto-3g-check_rhf", "cc-pvdz", "6-31g", "def2-svp", "mqc-even-tempered-jkfit"]
 
 
 def write_flat(name: str, out_dir: str):

@@ -1377,6 +1377,316 @@ static bool xc_tile_dispatch(const BatchView& bv, int oa, hipStream_t s)
     return true;
 }
 
+// ------------------------------------------------------------------ the pipelined quadrature kernel (n <= 64)
+// The tile kernel above parks three of its four waves at a barrier while ONE wave evaluates the functional -- 47 % of a
+// workgroup's timeline (profiles/r02_xc_phase_stamps.txt).  Here a workgroup is EIGHT waves with specialised roles and
+// TWO slab buffers, and the tiles move through a software pipeline:
+//     waves 0..5  workers:     S1 slab(t+1) -> buffer B    S2 X = D chi, rho, grad rho of t+1     S3 A += a chi^T of tile t
+//     wave  6     exchange:    S1 / S2 the exchange components of the functional on tile t (lane = point)
+//     wave  7     correlation: S1 / S2 the correlation components of tile t; both leave partial v_rho, v_sigma in LDS
+// so that the long dual-number instruction streams run UNDER the workers' slab and MFMA phases instead of in front of
+// three idle waves.  Three barriers per tile instead of five.  The coefficient vector a = w v_rho / 2 chi + 2 w v_sigma
+// grad rho . grad chi is not stored: in S3 a wave owns the pair (row tile mt, half kh of the tile's points), forms its
+// A-operand fragments from the slab on the fly and feeds them to the MFMAs of all column tiles nt -- one pass over the
+// slab less and one barrier less.  Same arithmetic as xc_tile_kernel (mqc_libcint_xc.F90:796-927); the summation order
+// inside rho and A differs only through the halves' atomic adds.
+// Conditions (else the tile kernel runs): radial cache filled with 32-point tiles, s/p/d shells, restricted, LDS fits.
+constexpr int XP_NW = 8, XP_WORK = 6, XP_PT = 32;
+
+__host__ __device__ __forceinline__ bool xc_is_exchange(int id) { return id == XC_LDA_X || id == XC_GGA_X_B88 || id == XC_GGA_X_PBE; }
+
+__device__ __forceinline__ Dual eval_component(int id, Dual R, Dual R13, Dual S)
+{
+    switch (id) {
+        case XC_LDA_X: return f_lda_x(R, R13);
+        case XC_LDA_C_VWN: return f_vwn(R, R13, 0.0310907, -0.10498, 3.72744, 12.9352);
+        case XC_LDA_C_VWN_RPA: return f_vwn(R, R13, 0.0310907, -0.409286, 13.0720, 42.7198);
+        case XC_GGA_X_B88: return f_b88(R, R13, S);
+        case XC_GGA_C_LYP: return f_lyp(R, R13, S);
+        case XC_GGA_X_PBE: return f_pbe_x(R, R13, S);
+        case XC_GGA_C_PBE: return f_pbe_c(R, R13, S);
+        default: return mk(0.0);
+    }
+}
+
+template <bool GGA, int NTC>
+__global__ void __launch_bounds__(64 * XP_NW, 1) xc_pipe_kernel(BatchView bv, int only_active)
+{
+    extern __shared__ double lds[];
+    const int f = blockIdx.y;
+    if ((only_active & 1) && bv.istate[4 * f] == ST_DONE) return;
+    constexpr int PT = XP_PT, RS = PT + 1, PT16 = PT / 16, NTHR = 64 * XP_NW, NWT = 64 * XP_WORK;
+    constexpr int NP = 16 * NTC, ARR = GGA ? 4 : 1, SL = ARR * NP * RS;
+    constexpr int NJOB = NTC * PT16, DJ = (NJOB + XP_WORK - 1) / XP_WORK, DK = 4 * NTC;      // X jobs, jobs per worker, k-steps
+    constexpr int NPAIR = 2 * NTC;                                                         // (row tile, point half) pairs of S3
+    const int n = bv.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lo = lane & 15, hi = lane >> 4;
+    const bool worker = wave < XP_WORK;
+    const TopologyDev& tp = bv.topo;
+    const GridDev& gd = bv.grid;
+    double* slab0 = lds;                                      // two slabs: [ARR][NP][RS] = chi, (gx, gy, gz)
+    double* red = lds + 2 * SL;                               // [2][PT][4] rho, grad rho / 2 sums
+    double* fc = red + 8 * PT;                                // [2][PT][8] c0x, t2x, rx, ry, rz, c0c, t2c, -
+    double* axyz = fc + 16 * PT;                              // [64][3]
+    double* pxyz = axyz + 3 * 64;                             // [2][PT][3]
+    int* sdesc = (int*)(pxyz + 6 * PT);                       // [nshell] ao | l << 12 | atom << 16
+    double* radl = pxyz + 6 * PT + ((((size_t)(tp.nshell + 1) / 2) + 1) & ~(size_t)1);     // [nshell][2][PT], 16-byte aligned
+    const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
+    const double* __restrict__ D = bv.D + (size_t)f * n * n;
+    const double* __restrict__ wts = gd.weights + (size_t)f * gd.npts;
+    const double* __restrict__ radf = gd.rad + (size_t)f * ((size_t)(gd.npts + PT - 1) / PT) * tp.nshell * 2 * PT;
+
+    for (int idx = tid; idx < 2 * SL + 24 * PT; idx += NTHR) lds[idx] = 0.0;      // rows n..NP-1 of both slabs stay zero
+    for (int sh = tid; sh < tp.nshell; sh += NTHR) sdesc[sh] = tp.sh_aoff[sh] | (tp.sh_l[sh] << 12) | (tp.sh_atom[sh] << 16);
+    for (int idx = tid; idx < 3 * tp.natoms; idx += NTHR) axyz[idx] = xyz[idx];
+    const int ntile = (gd.npts + PT - 1) / PT;
+    const int stride = (int)gridDim.x;
+    auto load_points = [&](int tile, int b, int q) {
+        const int g = tile * PT + q;
+        double x = 0.0, y = 0.0, z = 0.0;
+        if (g < gd.npts) {
+            const int oa = gd.pt_atom[g], it = gd.pt_tmpl[g];
+            x = xyz[3 * oa] + gd.tmpl_xyz[3 * it]; y = xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1]; z = xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2];
+        }
+        double* pp = pxyz + 3 * (b * PT + q);
+        pp[0] = x; pp[1] = y; pp[2] = z;
+    };
+    const int rad_bytes = tp.nshell * 2 * PT * 8;
+    auto stage_radial = [&](int tile) {       // workers: the tile's radial block HBM -> LDS by LDS-DMA (no registers)
+        if (tile >= ntile) return;
+        const char* src = (const char*)(radf + (size_t)tile * tp.nshell * 2 * PT);
+        for (int c = wave; c * 1024 < rad_bytes; c += XP_WORK) {
+            const int off = c * 1024 + lane * 16;
+            if (off < rad_bytes)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off),
+                                                 (__attribute__((address_space(3))) void*)((char*)radl + c * 1024), 16, 0, 0);
+        }
+    };
+    auto slab = [&](int tile, int b) {        // workers: (shell, point) items, point fastest
+        double* chi = slab0 + (size_t)b * SL;
+        double* gx = chi + NP * RS; double* gy = gx + (GGA ? NP * RS : 0); double* gz = gy + (GGA ? NP * RS : 0);
+        const int g0 = tile * PT;
+        for (int idx = tid; idx < tp.nshell * PT; idx += NWT) {
+            const int sh = idx / PT, p = idx - sh * PT;
+            const int sd = sdesc[sh];
+            const int ao = sd & 0xfff, l = (sd >> 12) & 0xf, at = sd >> 16;
+            const double* pp = pxyz + 3 * (b * PT + p);
+            const double dx = pp[0] - axyz[3 * at], dy = pp[1] - axyz[3 * at + 1], dz = pp[2] - axyz[3 * at + 2];
+            const bool in = g0 + p < gd.npts;
+            const double* r0 = radl + (size_t)sh * 2 * PT + p;
+            emit_shell<GGA, false>(l, ao, dx, dy, dz, in ? r0[0] : 0.0, in ? r0[PT] : 0.0, chi, gx, gy, gz, RS, p, bv.c2s);
+        }
+    };
+    // density fragments of this worker's X jobs, resident for the whole kernel
+    double dfrag[DJ][DK];
+#pragma unroll
+    for (int j = 0; j < DJ; ++j) {
+        const int job = wave + XP_WORK * j, mt = job / PT16;
+#pragma unroll
+        for (int ks = 0; ks < DK; ++ks) {
+            const int mu = 16 * mt + lo, nu = 4 * ks + hi;
+            dfrag[j][ks] = (worker && job < NJOB && mu < n && nu < n) ? D[(size_t)mu * n + nu] : 0.0;
+        }
+    }
+    auto density = [&](int b) {               // workers: X = D chi of the slab in buffer b, rho and grad rho into red[b]
+        const double* chi = slab0 + (size_t)b * SL;
+        const double* gx = chi + NP * RS; const double* gy = gx + (GGA ? NP * RS : 0); const double* gz = gy + (GGA ? NP * RS : 0);
+#pragma unroll
+        for (int jj = 0; jj < DJ; ++jj) {
+            const int job = wave + XP_WORK * jj;
+            if (job >= NJOB) break;
+            const int mt = job / PT16, pt = job - mt * PT16;
+            v4f64 xacc = (v4f64){0.0, 0.0, 0.0, 0.0};
+            double bw[DK];
+#pragma unroll
+            for (int ks = 0; ks < DK; ++ks) bw[ks] = chi[(4 * ks + hi) * RS + 16 * pt + lo];
+#pragma unroll
+            for (int ks = 0; ks < DK; ++ks) xacc = __builtin_amdgcn_mfma_f64_16x16x4f64(dfrag[jj][ks], bw[ks], xacc, 0, 0, 0);
+            double rho = 0.0, rx = 0.0, ry = 0.0, rz = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = (16 * mt + hi + 4 * r) * RS + 16 * pt + lo;
+                const double x = xacc[r];
+                rho += x * chi[o];
+                if (GGA) { rx += x * gx[o]; ry += x * gy[o]; rz += x * gz[o]; }
+            }
+            rho += __shfl_xor(rho, 16, 64); rho += __shfl_xor(rho, 32, 64);
+            if (GGA) {
+                rx += __shfl_xor(rx, 16, 64); rx += __shfl_xor(rx, 32, 64);
+                ry += __shfl_xor(ry, 16, 64); ry += __shfl_xor(ry, 32, 64);
+                rz += __shfl_xor(rz, 16, 64); rz += __shfl_xor(rz, 32, 64);
+            }
+            if (hi == 0) {
+                double* rp = red + 4 * (b * PT + 16 * pt + lo);
+                atomicAdd(&rp[0], rho);
+                if (GGA) { atomicAdd(&rp[1], rx); atomicAdd(&rp[2], ry); atomicAdd(&rp[3], rz); }
+            }
+        }
+    };
+    v4f64 vacc[NTC];
+#pragma unroll
+    for (int j = 0; j < NTC; ++j) vacc[j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    double e_acc = 0.0, n_acc = 0.0;
+    // which components this functional wave runs, and in which half of the tile's two overlapped phases
+    const bool xwave = wave == XP_WORK, cwave = wave == XP_WORK + 1;
+    int mine[6], nmine = 0;
+    if (xwave || cwave)
+        for (int k = 0; k < bv.xc.ncomp; ++k)
+            if (xc_is_exchange(bv.xc.id[k]) == xwave) mine[nmine++] = k;
+    const int first_half = (nmine + 1) / 2;
+
+    // ---- prologue: tile 0 through slab and density
+    int tile = blockIdx.x;
+    if (tid < PT) load_points(tile, 0, tid);
+    if (worker) stage_radial(tile);
+    __syncthreads();
+    if (worker) slab(tile, 0);
+    __syncthreads();
+    if (worker) {
+        density(0);
+        stage_radial(tile + stride);
+        if (wave == 0 && lane < PT) load_points(tile + stride, 1, lane);
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (; tile < ntile; tile += stride, cur ^= 1) {
+        const int nxt = cur ^ 1, next = tile + stride;
+        const bool has_next = next < ntile;
+        const int s0 = tile * PT;
+        // ---- S1: slab of the next tile | functional, first half
+        Dual R = mk(0.0), S = mk(0.0), R13 = mk(0.0);
+        double fx = 0.0, vr = 0.0, vs = 0.0, rho = 0.0, rx = 0.0, ry = 0.0, rz = 0.0, w = 0.0;
+        bool live = false;
+        if (worker) {
+            if (has_next) slab(next, nxt);
+        } else if (lane < PT) {
+            const double* rp = red + 4 * (cur * PT + lane);
+            rho = rp[0]; rx = 2.0 * rp[1]; ry = 2.0 * rp[2]; rz = 2.0 * rp[3];
+            w = (s0 + lane < gd.npts) ? wts[s0 + lane] : 0.0;
+            live = rho > XC_DENS_THRESHOLD;
+            if (live) {
+                R = {rho, 1.0, 0.0};
+                S = {fmax(GGA ? rx * rx + ry * ry + rz * rz : 0.0, 1.0e-40), 0.0, 1.0};
+                R13 = dcbrt(R);
+                for (int k = 0; k < first_half; ++k) {
+                    const Dual d = eval_component(bv.xc.id[mine[k]], R, R13, S);
+                    const double wk = bv.xc.w[mine[k]];
+                    fx += wk * d.v; vr += wk * d.r; vs += wk * d.s;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- S2: densities of the next tile | functional, second half -> partial coefficients
+        if (worker) {
+            if (has_next) {
+                density(nxt);
+                stage_radial(next + stride);
+                if (wave == 0 && lane < PT) load_points(next + stride, cur, lane);
+            }
+        } else if (lane < PT) {
+            if (cwave) { double* rp = red + 4 * (cur * PT + lane); rp[0] = 0.0; rp[1] = 0.0; rp[2] = 0.0; rp[3] = 0.0; }
+            if (live)
+                for (int k = first_half; k < nmine; ++k) {
+                    const Dual d = eval_component(bv.xc.id[mine[k]], R, R13, S);
+                    const double wk = bv.xc.w[mine[k]];
+                    fx += wk * d.v; vr += wk * d.r; vs += wk * d.s;
+                }
+            e_acc += w * fx;
+            double* cp = fc + 8 * (cur * PT + lane);
+            if (xwave) {
+                n_acc += w * rho;
+                cp[0] = 0.5 * w * vr; cp[1] = 2.0 * w * vs; cp[2] = rx; cp[3] = ry; cp[4] = rz;
+            } else {
+                cp[5] = 0.5 * w * vr; cp[6] = 2.0 * w * vs;
+            }
+        }
+        __syncthreads();
+        // ---- S3: A += a chi^T of the current tile; wave = (row tile mt, half kh of the points), a formed on the fly
+        if (wave < NPAIR) {
+            const int mt = wave >> 1, kh = wave & 1;
+            const double* chi = slab0 + (size_t)cur * SL;
+            const double* gx = chi + NP * RS; const double* gy = gx + (GGA ? NP * RS : 0); const double* gz = gy + (GGA ? NP * RS : 0);
+            double av[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int p = 16 * kh + 4 * ks + hi;
+                const double* cp = fc + 8 * (cur * PT + p);
+                const int o = (16 * mt + lo) * RS + p;
+                double a = (cp[0] + cp[5]) * chi[o];
+                if (GGA) {
+                    const double t2 = cp[1] + cp[6];
+                    a += t2 * (cp[2] * gx[o] + cp[3] * gy[o] + cp[4] * gz[o]);
+                }
+                av[ks] = a;
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTC; ++nt) {
+                const double* __restrict__ br = chi + (size_t)(16 * nt + lo) * RS + 16 * kh + hi;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) vacc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], br[4 * ks], vacc[nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // flush: lane holds A[mu = 16 mt + hi + 4 r][nu = 16 nt + lo] of its (mt, kh) pair
+    double* Vx = bv.Vxc + (size_t)f * n * n;
+    if (wave < NPAIR) {
+        const int mt = wave >> 1;
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mu = 16 * mt + hi + 4 * r, nu = 16 * nt + lo;
+                const double v = vacc[nt][r];
+                if (mu < n && nu < n && v != 0.0) atomicAdd(&Vx[mu * n + nu], v);
+            }
+    }
+    if (!worker) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { e_acc += __shfl_down(e_acc, off, 64); n_acc += __shfl_down(n_acc, off, 64); }
+        if (lane == 0) {
+            atomicAdd(&bv.scal[(size_t)f * 8 + 5], e_acc);
+            if (xwave) atomicAdd(&bv.scal[(size_t)f * 8 + 6], n_acc);
+        }
+    }
+}
+
+template <bool GGA, int NTC>
+static bool xc_pipe_launch(const BatchView& bv, int oa, hipStream_t s)
+{
+    constexpr int PT = XP_PT;
+    const size_t sl = (size_t)(GGA ? 4 : 1) * 16 * NTC * (PT + 1);
+    const size_t doubles = 2 * sl + 24 * PT + 3 * 64 + 6 * PT + (((((size_t)bv.topo.nshell + 1) / 2) + 1) & ~(size_t)1) + (size_t)bv.topo.nshell * 2 * PT;
+    const size_t lds = sizeof(double) * doubles;
+    if (lds > (size_t)160 * 1024 - 256) return false;
+    auto kern = xc_pipe_kernel<GGA, NTC>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int ntiles = (bv.grid.npts + PT - 1) / PT;
+    int gx = (2048 + bv.nfrag - 1) / bv.nfrag;        // one workgroup per CU: ~8 rounds of 256 over the batch, many tiles each
+    if (gx > ntiles) gx = ntiles;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(kern, dim3(gx, bv.nfrag), dim3(64 * XP_NW), lds, s, bv, oa);
+    return true;
+}
+
+// n <= 64, restricted, s/p/d shells, radial cache at 32-point tiles: the pipelined kernel (MQC_HIP_XC_PIPE=0: off)
+template <bool GGA>
+static bool xc_pipe_dispatch(const BatchView& bv, int oa, hipStream_t s)
+{
+    static const bool on = [] { const char* e = std::getenv("MQC_HIP_XC_PIPE"); return !(e && e[0] == '0'); }();
+    if (!on || bv.uhf || bv.n > 64 || bv.topo.lmax > 2 || !bv.grid.rad || bv.grid.rad_pt != XP_PT) return false;
+    bool has_x = false, has_c = false;
+    for (int k = 0; k < bv.xc.ncomp; ++k) { if (xc_is_exchange(bv.xc.id[k])) has_x = true; else has_c = true; }
+    if (!has_x) return false;             // the exchange wave also carries the gradient and the electron count
+    (void)has_c;
+    const int nt = (bv.n + 15) / 16;
+    if (nt == 1) return xc_pipe_launch<GGA, 1>(bv, oa, s);
+    if (nt == 2) return xc_pipe_launch<GGA, 2>(bv, oa, s);
+    if (nt == 3) return xc_pipe_launch<GGA, 3>(bv, oa, s);
+    return xc_pipe_launch<GGA, 4>(bv, oa, s);
+}
+
 __global__ void xc_reset_kernel(BatchView bv)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1564,6 +1874,7 @@ void launch_xc(const BatchView& bv, bool only_active, hipStream_t s)
     (void)probed;
     // MQC_HIP_XC_V1=1: the round-1 kernels (wave-private MFMA kernel for n <= 48, VALU kernel above), kept for A/B runs
     static const bool v1 = [] { const char* e = std::getenv("MQC_HIP_XC_V1"); return e && e[0] == '1'; }();
+    if (!v1 && (gga ? xc_pipe_dispatch<true>(bv, oa, s) : xc_pipe_dispatch<false>(bv, oa, s))) return;
     if (!v1 && (gga ? xc_tile_dispatch<true>(bv, oa, s) : xc_tile_dispatch<false>(bv, oa, s))) {
 #if XC_STAMPS
         (void)hipStreamSynchronize(s);
