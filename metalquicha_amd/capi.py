@@ -14,7 +14,8 @@ import os
 
 import numpy as np
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmqc_hip.so")
+# MQC_HIP_LIBRARY: another build of the SAME library (instrumented A/B builds under profiling); never a different backend
+LIB_PATH = os.environ.get("MQC_HIP_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmqc_hip.so")
 
 MQC_HIP_OK = 0
 ERR_VALIDATION, ERR_GENERIC, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_DEVICE = 1, 2, 3, 4, 5

@@ -581,7 +581,20 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         // the quadrature's shadow and their HIP-event times (the bench's per-stage figures) stop meaning anything
         static const bool xc_side = [] { const char* e = std::getenv("MQC_HIP_XC_SIDE_STREAM"); return e && e[0] == '1'; }();
         const bool xc_on_side = xc.ncomp > 0 && xc_side;
+        // Small batches are latency-bound: the host round trip after every iteration (one int back, ~50 us) costs as
+        // much as the kernels.  They run BLOCKS of iterations between two reads of the counter -- finished fragments
+        // drop out of every kernel by themselves (state machine), so an iteration enqueued past convergence is three
+        // empty launches.  Large batches keep one read per iteration (MQC_HIP_SCF_SYNC_BLOCK overrides: 1 = always).
+        static const int sync_block_env = [] { const char* e = std::getenv("MQC_HIP_SCF_SYNC_BLOCK"); return e ? std::atoi(e) : 0; }();
+        const bool blocked = sync_block_env != 1 && nf <= 256;
+        int blocks_done = 0;
         while (remaining > 0 && guard < opts.max_iter + 2) {
+          int block_len = 1;
+          if (blocked) block_len = sync_block_env > 1 ? sync_block_env : (blocks_done == 0 ? 8 : 4);
+          if (block_len > opts.max_iter + 2 - guard) block_len = opts.max_iter + 2 - guard;
+          ++blocks_done;
+          for (int bi = 0; bi < block_len; ++bi) {
+            const bool last_of_block = bi + 1 == block_len;
             if (xc_on_side) {
                 HIP_CHECK_RET(hipEventRecord(ctx->evo[sl.id & 1][0], s));
                 HIP_CHECK_RET(hipStreamWaitEvent(sxc, ctx->evo[sl.id & 1][0], 0));
@@ -636,33 +649,35 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
             HIP_CHECK_RET(hipEventRecord(sl.s0, s));
             launch_scf_step(bv, s);
             HIP_CHECK_RET(hipEventRecord(sl.s1, s));
+            if (!last_of_block) { ++guard; continue; }
             HIP_CHECK_RET(hipMemcpyAsync(sl.h_counter, bv.counters, sizeof(int), hipMemcpyDeviceToHost, s));
             HIP_CHECK_RET(hipStreamSynchronize(s));
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, sl.s0, sl.s1);
-            sx->stats.scf_step_seconds += ms * 1e-3;
+            sx->stats.scf_step_seconds += ms * 1e-3 * block_len;
             (void)hipEventElapsedTime(&ms, sl.e0, sl.e1);
             if (use_df) {
-                sx->stats.df_bytes += (double)remaining * 8.0 * (double)naux * (double)n * (double)n;
-                sx->stats.df_flops += (double)remaining * 4.0 * (double)naux * (double)n * (double)n * (1.0 + (xc.exx != 0.0 ? (double)nocc : 0.0));
+                sx->stats.df_bytes += (double)remaining * 8.0 * (double)naux * (double)n * (double)n * block_len;
+                sx->stats.df_flops += (double)remaining * 4.0 * (double)naux * (double)n * (double)n * (1.0 + (xc.exx != 0.0 ? (double)nocc : 0.0)) * block_len;
             }
             const double launch_bytes = use_df ? (double)remaining * 2.0 * (double)naux * (double)np * 8.0
                                                : (double)remaining * (double)np * (double)np * 8.0 * (uhf ? 2.0 : 1.0);
-            sx->stats.fock_kernel_seconds += ms * 1e-3;
-            sx->stats.fock_bytes += launch_bytes;
-            sx->stats.fock_launches += 1;
+            sx->stats.fock_kernel_seconds += ms * 1e-3 * block_len;
+            sx->stats.fock_bytes += launch_bytes * block_len;
+            sx->stats.fock_launches += block_len;
             if (launch_bytes >= 1073741824.0) {
                 sx->stats.fock_big_launches += 1; sx->stats.fock_big_seconds += ms * 1e-3; sx->stats.fock_big_bytes += launch_bytes;
             }
             if (xc.ncomp > 0) {
                 float mx = 0.f;
                 (void)hipEventElapsedTime(&mx, sl.e2, sl.e3);
-                sx->stats.xc_kernel_seconds += mx * 1e-3;
-                sx->stats.xc_points += (double)remaining * grid.npts;
-                sx->stats.xc_flops += (double)remaining * grid.npts * (xc.gga ? 8.0 : 4.0) * (double)n * (double)n;
+                sx->stats.xc_kernel_seconds += mx * 1e-3 * block_len;
+                sx->stats.xc_points += (double)remaining * grid.npts * block_len;
+                sx->stats.xc_flops += (double)remaining * grid.npts * (xc.gga ? 8.0 : 4.0) * (double)n * (double)n * block_len;
             }
             remaining = sl.h_counter[0];
             ++guard;
+          }
         }
         if ((rc = stage_check("SCF loop")) != MQC_HIP_OK) return rc;
         const double t4 = now_s();

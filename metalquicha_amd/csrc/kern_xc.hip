@@ -164,18 +164,24 @@ __device__ __forceinline__ void eval_functional(const XcSpec& xc, double rho, do
     f = 0.0; vr = 0.0; vs = 0.0;
     if (!(rho > XC_DENS_THRESHOLD) || k0 >= xc.ncomp) return;
     const Dual R = {rho, 1.0, 0.0};
-    const Dual S = {fmax(sigma, 1.0e-40), 0.0, 1.0};
-    const Dual R13 = dcbrt(R);          // every component needs rho^(1/3): formed once
+    const Dual S_all = {fmax(sigma, 1.0e-40), 0.0, 1.0};
+    const Dual R13_all = dcbrt(R);          // every component needs rho^(1/3): formed once
     for (int k = k0; k < xc.ncomp; k += kstep) {
         Dual d;
+        // The cases are pure functions of loop invariants: left alone, the compiler hoists ALL SEVEN functionals out of the
+        // loop (speculative execution) and the loop only selects among the results -- every tile paid for PBE, VWN5 and
+        // the rest whatever the functional was.  An opaque copy of rho per iteration keeps the switch a real branch.
+        double rv = R.v, cv = R13_all.v, cr = R13_all.r, sv = S_all.v;
+        asm volatile("" : "+v"(rv), "+v"(cv), "+v"(cr), "+v"(sv));
+        const Dual Rk = {rv, 1.0, 0.0}, R13 = {cv, cr, 0.0}, S = {sv, 0.0, 1.0};
         switch (xc.id[k]) {
-            case XC_LDA_X: d = f_lda_x(R, R13); break;
-            case XC_LDA_C_VWN: d = f_vwn(R, R13, 0.0310907, -0.10498, 3.72744, 12.9352); break;
-            case XC_LDA_C_VWN_RPA: d = f_vwn(R, R13, 0.0310907, -0.409286, 13.0720, 42.7198); break;
-            case XC_GGA_X_B88: d = f_b88(R, R13, S); break;
-            case XC_GGA_C_LYP: d = f_lyp(R, R13, S); break;
-            case XC_GGA_X_PBE: d = f_pbe_x(R, R13, S); break;
-            case XC_GGA_C_PBE: d = f_pbe_c(R, R13, S); break;
+            case XC_LDA_X: d = f_lda_x(Rk, R13); break;
+            case XC_LDA_C_VWN: d = f_vwn(Rk, R13, 0.0310907, -0.10498, 3.72744, 12.9352); break;
+            case XC_LDA_C_VWN_RPA: d = f_vwn(Rk, R13, 0.0310907, -0.409286, 13.0720, 42.7198); break;
+            case XC_GGA_X_B88: d = f_b88(Rk, R13, S); break;
+            case XC_GGA_C_LYP: d = f_lyp(Rk, R13, S); break;
+            case XC_GGA_X_PBE: d = f_pbe_x(Rk, R13, S); break;
+            case XC_GGA_C_PBE: d = f_pbe_c(Rk, R13, S); break;
             default: d = mk(0.0);
         }
         f += xc.w[k] * d.v; vr += xc.w[k] * d.r; vs += xc.w[k] * d.s;
@@ -264,16 +270,20 @@ __device__ __forceinline__ void eval_functional_pol(const XcSpec& xc, double ra_
     f = 0.0;
     for (int i = 0; i < 5; ++i) dv[i] = 0.0;
     if (!(ra_in + rb_in > XC_DENS_THRESHOLD)) return;
-    const D5 ra = var5(fmax(ra_in, XC_SPIN_FLOOR), 0), rb = var5(fmax(rb_in, XC_SPIN_FLOOR), 1);
+    const D5 ra_all = var5(fmax(ra_in, XC_SPIN_FLOOR), 0), rb_all = var5(fmax(rb_in, XC_SPIN_FLOOR), 1);
     const D5 Saa = var5(fmax(saa, 1.0e-40), 2), Sab = var5(sab, 3), Sbb = var5(fmax(sbb, 1.0e-40), 4);
-    const D5 rho = ra + rb;
-    const D5 r13 = cbrt5(rho);
-    const D5 z = (ra - rb) / rho;
+    const D5 rho_all = ra_all + rb_all;
+    const D5 r13_all = cbrt5(rho_all);
+    const D5 z = (ra_all - rb_all) / rho_all;
     const D5 opz13 = cbrt5(1.0 + z), omz13 = cbrt5(1.0 - z);
-    const D5 rs = 0.6203504908994001 / r13;
-    const D5 sig = Saa + 2.0 * Sab + Sbb;
+    const D5 rs_all = 0.6203504908994001 / r13_all;
+    const D5 sig_all = Saa + 2.0 * Sab + Sbb;
     for (int k = 0; k < xc.ncomp; ++k) {
         D5 d;
+        // opaque per iteration, so that the cases stay behind their branch instead of being hoisted out of the loop
+        // all seven at once (see eval_functional)
+        D5 rho = rho_all, ra = ra_all, rb = rb_all, r13 = r13_all, rs = rs_all, sig = sig_all;
+        asm volatile("" : "+v"(rho.v), "+v"(ra.v), "+v"(rb.v), "+v"(r13.v), "+v"(rs.v), "+v"(sig.v));
         switch (xc.id[k]) {
             case XC_LDA_X:
                 d = -0.7385587663820224 * 1.2599210498948732 * (ra * cbrt5(ra) + rb * cbrt5(rb));
@@ -1392,6 +1402,14 @@ static bool xc_tile_dispatch(const BatchView& bv, int oa, hipStream_t s)
 // inside rho and A differs only through the halves' atomic adds.
 // Conditions (else the tile kernel runs): radial cache filled with 32-point tiles, s/p/d shells, restricted, LDS fits.
 constexpr int XP_NW = 8, XP_WORK = 6, XP_PT = 32;
+#if XC_STAMPS
+__device__ unsigned long long g_xp_stamps[24];      // [role: worker, exchange, correlation][S1 work, wait, S2 work, wait, S3 work, wait] + prologue
+#define XP_ST_DECL unsigned long long xp_t = __builtin_amdgcn_s_memtime(), xp_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+#define XP_ST(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); xp_acc[k] += t_ - xp_t; xp_t = t_; }
+#else
+#define XP_ST_DECL
+#define XP_ST(k)
+#endif
 
 __host__ __device__ __forceinline__ bool xc_is_exchange(int id) { return id == XC_LDA_X || id == XC_GGA_X_B88 || id == XC_GGA_X_PBE; }
 
@@ -1419,7 +1437,7 @@ __global__ void __launch_bounds__(64 * XP_NW, 1) xc_pipe_kernel(BatchView bv, in
     constexpr int NP = 16 * NTC, ARR = GGA ? 4 : 1, SL = ARR * NP * RS;
     constexpr int NJOB = NTC * PT16, DJ = (NJOB + XP_WORK - 1) / XP_WORK, DK = 4 * NTC;      // X jobs, jobs per worker, k-steps
     constexpr int NPAIR = 2 * NTC;                                                         // (row tile, point half) pairs of S3
-    const int n = bv.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = bv.n, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lo = lane & 15, hi = lane >> 4;
     const bool worker = wave < XP_WORK;
     const TopologyDev& tp = bv.topo;
@@ -1429,8 +1447,10 @@ __global__ void __launch_bounds__(64 * XP_NW, 1) xc_pipe_kernel(BatchView bv, in
     double* fc = red + 8 * PT;                                // [2][PT][8] c0x, t2x, rx, ry, rz, c0c, t2c, -
     double* axyz = fc + 16 * PT;                              // [64][3]
     double* pxyz = axyz + 3 * 64;                             // [2][PT][3]
-    int* sdesc = (int*)(pxyz + 6 * PT);                       // [nshell] ao | l << 12 | atom << 16
-    double* radl = pxyz + 6 * PT + ((((size_t)(tp.nshell + 1) / 2) + 1) & ~(size_t)1);     // [nshell][2][PT], 16-byte aligned
+    double* xcw = pxyz + 6 * PT;                              // [8] weights of the functional's components
+    int* xcid = (int*)(xcw + 8);                              // [8] their ids (4 doubles)
+    int* sdesc = (int*)(xcw + 12);                            // [nshell] ao | l << 12 | atom << 16
+    double* radl = xcw + 12 + ((((size_t)(tp.nshell + 1) / 2) + 1) & ~(size_t)1);          // [nshell][2][PT], 16-byte aligned
     const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
     const double* __restrict__ D = bv.D + (size_t)f * n * n;
     const double* __restrict__ wts = gd.weights + (size_t)f * gd.npts;
@@ -1439,6 +1459,9 @@ __global__ void __launch_bounds__(64 * XP_NW, 1) xc_pipe_kernel(BatchView bv, in
     for (int idx = tid; idx < 2 * SL + 24 * PT; idx += NTHR) lds[idx] = 0.0;      // rows n..NP-1 of both slabs stay zero
     for (int sh = tid; sh < tp.nshell; sh += NTHR) sdesc[sh] = tp.sh_aoff[sh] | (tp.sh_l[sh] << 12) | (tp.sh_atom[sh] << 16);
     for (int idx = tid; idx < 3 * tp.natoms; idx += NTHR) axyz[idx] = xyz[idx];
+    // the functional's component table moves to LDS once: the kernel-argument segment it comes from is host-coherent
+    // memory, and a scalar load from it inside the tile loop (rolled loop over the components) cost microseconds per tile
+    if (tid < 6) { xcid[tid] = tid < bv.xc.ncomp ? bv.xc.id[tid] : 0; xcw[tid] = tid < bv.xc.ncomp ? bv.xc.w[tid] : 0.0; }
     const int ntile = (gd.npts + PT - 1) / PT;
     const int stride = (int)gridDim.x;
     auto load_points = [&](int tile, int b, int q) {
@@ -1527,14 +1550,34 @@ __global__ void __launch_bounds__(64 * XP_NW, 1) xc_pipe_kernel(BatchView bv, in
 #pragma unroll
     for (int j = 0; j < NTC; ++j) vacc[j] = (v4f64){0.0, 0.0, 0.0, 0.0};
     double e_acc = 0.0, n_acc = 0.0;
-    // which components this functional wave runs, and in which half of the tile's two overlapped phases
+    // which components this functional wave runs, and in which half of the tile's two overlapped phases.  Everything
+    // here is wave-uniform (scalar loads of the kernel argument with a uniform index): a per-lane index into bv.xc made
+    // the compiler fetch the ids through VECTOR loads from the kernel-argument segment -- host-coherent memory, several
+    // microseconds per access, once per component and tile (profiles/r03_xc_pipe_stamps.txt, first build)
     const bool xwave = wave == XP_WORK, cwave = wave == XP_WORK + 1;
-    int mine[6], nmine = 0;
-    if (xwave || cwave)
-        for (int k = 0; k < bv.xc.ncomp; ++k)
-            if (xc_is_exchange(bv.xc.id[k]) == xwave) mine[nmine++] = k;
+    const int ncomp = bv.xc.ncomp;
+    int nmine = 0;
+    for (int k = 0; k < ncomp; ++k) nmine += (xc_is_exchange(bv.xc.id[k]) == xwave) ? 1 : 0;      // once, before the tile loop
     const int first_half = (nmine + 1) / 2;
+    auto run_components = [&](bool second, Dual R, Dual R13, Dual S, double& fx, double& vr, double& vs) {
+        int cnt = 0;
+#pragma unroll 1
+        for (int k = 0; k < ncomp; ++k) {
+            const int id = __builtin_amdgcn_readfirstlane(xcid[k]);
+            if (xc_is_exchange(id) != xwave) continue;
+            const bool in_second = cnt >= first_half;
+            ++cnt;
+            if (in_second != second) continue;
+            double rv = R.v, cv = R13.v, cr = R13.r, sv = S.v;
+            asm volatile("" : "+v"(rv), "+v"(cv), "+v"(cr), "+v"(sv));      // opaque per iteration: see eval_functional
+            const Dual Rk = {rv, 1.0, 0.0}, R13k = {cv, cr, 0.0}, Sk = {sv, 0.0, 1.0};
+            const Dual d = eval_component(id, Rk, R13k, Sk);
+            const double wk = xcw[k];
+            fx += wk * d.v; vr += wk * d.r; vs += wk * d.s;
+        }
+    };
 
+    XP_ST_DECL
     // ---- prologue: tile 0 through slab and density
     int tile = blockIdx.x;
     if (tid < PT) load_points(tile, 0, tid);
@@ -1548,6 +1591,9 @@ __global__ void __launch_bounds__(64 * XP_NW, 1) xc_pipe_kernel(BatchView bv, in
         if (wave == 0 && lane < PT) load_points(tile + stride, 1, lane);
     }
     __syncthreads();
+    XP_ST(6)
+    // the functional waves fetch the quadrature weights of a tile one tile ahead
+    double w_next = (!worker && lane < PT && tile * PT + lane < gd.npts) ? wts[tile * PT + lane] : 0.0;
 
     int cur = 0;
     for (; tile < ntile; tile += stride, cur ^= 1) {
@@ -1563,35 +1609,38 @@ __global__ void __launch_bounds__(64 * XP_NW, 1) xc_pipe_kernel(BatchView bv, in
         } else if (lane < PT) {
             const double* rp = red + 4 * (cur * PT + lane);
             rho = rp[0]; rx = 2.0 * rp[1]; ry = 2.0 * rp[2]; rz = 2.0 * rp[3];
-            w = (s0 + lane < gd.npts) ? wts[s0 + lane] : 0.0;
-            live = rho > XC_DENS_THRESHOLD;
+            w = w_next;
+            w_next = (has_next && next * PT + lane < gd.npts) ? wts[next * PT + lane] : 0.0;
+            live = rho > XC_DENS_THRESHOLD && !(g_xc_probe & 32);
             if (live) {
                 R = {rho, 1.0, 0.0};
                 S = {fmax(GGA ? rx * rx + ry * ry + rz * rz : 0.0, 1.0e-40), 0.0, 1.0};
                 R13 = dcbrt(R);
-                for (int k = 0; k < first_half; ++k) {
-                    const Dual d = eval_component(bv.xc.id[mine[k]], R, R13, S);
-                    const double wk = bv.xc.w[mine[k]];
-                    fx += wk * d.v; vr += wk * d.r; vs += wk * d.s;
-                }
+                if (!(g_xc_probe & 16)) run_components(false, R, R13, S, fx, vr, vs);
             }
         }
+        XP_ST(0)
         __syncthreads();
+        XP_ST(1)
         // ---- S2: densities of the next tile | functional, second half -> partial coefficients
         if (worker) {
             if (has_next) {
-                density(nxt);
                 stage_radial(next + stride);
-                if (wave == 0 && lane < PT) load_points(next + stride, cur, lane);
+                double px = 0.0, py = 0.0, pz = 0.0;
+                const bool pts = wave == XP_WORK - 1 && lane < PT;
+                if (pts) {        // issued before the MFMA job, stored after it: the dependent global loads ride under it
+                    const int g = (next + stride) * PT + lane;
+                    if (g < gd.npts) {
+                        const int oa = gd.pt_atom[g], it = gd.pt_tmpl[g];
+                        px = xyz[3 * oa] + gd.tmpl_xyz[3 * it]; py = xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1]; pz = xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2];
+                    }
+                }
+                density(nxt);
+                if (pts) { double* pp = pxyz + 3 * (cur * PT + lane); pp[0] = px; pp[1] = py; pp[2] = pz; }
             }
         } else if (lane < PT) {
             if (cwave) { double* rp = red + 4 * (cur * PT + lane); rp[0] = 0.0; rp[1] = 0.0; rp[2] = 0.0; rp[3] = 0.0; }
-            if (live)
-                for (int k = first_half; k < nmine; ++k) {
-                    const Dual d = eval_component(bv.xc.id[mine[k]], R, R13, S);
-                    const double wk = bv.xc.w[mine[k]];
-                    fx += wk * d.v; vr += wk * d.r; vs += wk * d.s;
-                }
+            if (live && !(g_xc_probe & 16)) run_components(true, R, R13, S, fx, vr, vs);
             e_acc += w * fx;
             double* cp = fc + 8 * (cur * PT + lane);
             if (xwave) {
@@ -1601,7 +1650,9 @@ __global__ void __launch_bounds__(64 * XP_NW, 1) xc_pipe_kernel(BatchView bv, in
                 cp[5] = 0.5 * w * vr; cp[6] = 2.0 * w * vs;
             }
         }
+        XP_ST(2)
         __syncthreads();
+        XP_ST(3)
         // ---- S3: A += a chi^T of the current tile; wave = (row tile mt, half kh of the points), a formed on the fly
         if (wave < NPAIR) {
             const int mt = wave >> 1, kh = wave & 1;
@@ -1627,8 +1678,17 @@ __global__ void __launch_bounds__(64 * XP_NW, 1) xc_pipe_kernel(BatchView bv, in
                 for (int ks = 0; ks < 4; ++ks) vacc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], br[4 * ks], vacc[nt], 0, 0, 0);
             }
         }
+        XP_ST(4)
         __syncthreads();
+        XP_ST(5)
     }
+#if XC_STAMPS
+    if (lane == 0) {
+        const int role = worker ? 0 : (xwave ? 1 : 2);
+        for (int k = 0; k < 6; ++k) atomicAdd(&g_xp_stamps[6 * role + k], xp_acc[k]);
+        atomicAdd(&g_xp_stamps[18], xp_acc[6]);
+    }
+#endif
     // flush: lane holds A[mu = 16 mt + hi + 4 r][nu = 16 nt + lo] of its (mt, kh) pair
     double* Vx = bv.Vxc + (size_t)f * n * n;
     if (wave < NPAIR) {
@@ -1657,7 +1717,7 @@ static bool xc_pipe_launch(const BatchView& bv, int oa, hipStream_t s)
 {
     constexpr int PT = XP_PT;
     const size_t sl = (size_t)(GGA ? 4 : 1) * 16 * NTC * (PT + 1);
-    const size_t doubles = 2 * sl + 24 * PT + 3 * 64 + 6 * PT + (((((size_t)bv.topo.nshell + 1) / 2) + 1) & ~(size_t)1) + (size_t)bv.topo.nshell * 2 * PT;
+    const size_t doubles = 2 * sl + 24 * PT + 3 * 64 + 6 * PT + 12 + (((((size_t)bv.topo.nshell + 1) / 2) + 1) & ~(size_t)1) + (size_t)bv.topo.nshell * 2 * PT;
     const size_t lds = sizeof(double) * doubles;
     if (lds > (size_t)160 * 1024 - 256) return false;
     auto kern = xc_pipe_kernel<GGA, NTC>;
@@ -1667,6 +1727,15 @@ static bool xc_pipe_launch(const BatchView& bv, int oa, hipStream_t s)
     if (gx > ntiles) gx = ntiles;
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL(kern, dim3(gx, bv.nfrag), dim3(64 * XP_NW), lds, s, bv, oa);
+#if XC_STAMPS
+    (void)hipStreamSynchronize(s);
+    unsigned long long h[24];
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_xp_stamps), sizeof(h));
+    const char* role[3] = {"workers (6 waves)", "exchange wave", "correlation wave"};
+    for (int r = 0; r < 3; ++r)
+        std::fprintf(stderr, "xc pipe stamps n=%d nfrag=%d %s: S1 %llu wait %llu | S2 %llu wait %llu | S3 %llu wait %llu\n", bv.n, bv.nfrag, role[r],
+                     h[6 * r], h[6 * r + 1], h[6 * r + 2], h[6 * r + 3], h[6 * r + 4], h[6 * r + 5]);
+#endif
     return true;
 }
 
