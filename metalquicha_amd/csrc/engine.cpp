@@ -401,7 +401,9 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
     const int rad_pt = xc_tile_points(n);
     const size_t rad_tiles = xc.ncomp > 0 ? ((size_t)grid.npts + rad_pt - 1) / rad_pt : 0;
     const size_t rad_doubles = (xc.ncomp > 0 && rad_cache_on && !uhf_mem) ? rad_tiles * topo.shells.size() * 2 * rad_pt : 0;
-    const size_t per_frag = sizeof(double) * (per_fragment_main_doubles(n, topo.natoms, uhf_mem, npc, hx) + two_e + (xc.ncomp > 0 ? (size_t)n * n * (uhf_mem ? 2 : 1) + grid.npts : 0) + rad_doubles);
+    // point buffer of the split quadrature (n <= 64, s/p/d shells, 32-point tiles): 4 doubles per padded grid point
+    const size_t pt4_doubles = (rad_doubles && n <= 64 && topo.lmax <= 2 && rad_pt == 32) ? rad_tiles * rad_pt * 4 : 0;
+    const size_t per_frag = sizeof(double) * (per_fragment_main_doubles(n, topo.natoms, uhf_mem, npc, hx) + two_e + (xc.ncomp > 0 ? (size_t)n * n * (uhf_mem ? 2 : 1) + grid.npts : 0) + rad_doubles + pt4_doubles);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     free_b += ctx->pool_main.capacity() + ctx->pool_eri.capacity() + ctx->pool_df.capacity() + ctx->pool_gridw.capacity()
@@ -472,12 +474,14 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         bv.nocc = nocc; bv.exx = xc.exx; bv.e_tol = opts.energy_tol; bv.d_tol = opts.density_tol;
         bv.xc = xc; bv.grid = grid; bv.Vxc = nullptr;
         if (xc.ncomp > 0) {
-            char* gw = (char*)sl.gridw->ensure(sizeof(double) * (size_t)nf * ((size_t)grid.npts + (size_t)n * n * (uhf ? 2 : 1) + rad_doubles) + 1024);
+            char* gw = (char*)sl.gridw->ensure(sizeof(double) * (size_t)nf * ((size_t)grid.npts + (size_t)n * n * (uhf ? 2 : 1) + rad_doubles + pt4_doubles) + 2048);
             if (!gw) return fail(MQC_HIP_ERR_DEVICE, "out of device memory (grid weights)");
             bv.grid.weights = (double*)gw;
             bv.Vxc = (double*)(gw + ((sizeof(double) * (size_t)nf * grid.npts + 255) & ~size_t(255)));
             bv.grid.rad = nullptr; bv.grid.rad_pt = rad_pt;
             if (rad_doubles) bv.grid.rad = (double*)((char*)bv.Vxc + ((sizeof(double) * (size_t)nf * n * n * (uhf ? 2 : 1) + 255) & ~size_t(255)));
+            bv.grid.pt4 = nullptr;
+            if (pt4_doubles) bv.grid.pt4 = (double*)((char*)bv.grid.rad + ((sizeof(double) * (size_t)nf * rad_doubles + 255) & ~size_t(255)));
         }
         bv.max_iter = opts.max_iter; bv.diis_size = opts.use_diis ? opts.diis_size : 0;
         job.hx.resize((size_t)nf * topo.natoms * 3);

@@ -104,6 +104,9 @@ struct GridDev {
     // contracted shell at every grid point, formed ONCE per SCF (the geometry is fixed) instead of in every iteration
     double* rad = nullptr;              // [nfrag][ntiles][nshell][2][rad_pt] or nullptr
     int rad_pt = 0;
+    // four numbers per (padded) grid point between the kernels of the split quadrature (kern_xc.hip): rho and grad rho / 2
+    // out of the density kernel, overwritten by w v_rho / 2 and 2 w v_sigma grad rho in the functional kernel
+    double* pt4 = nullptr;              // [nfrag][ntiles * rad_pt][4] or nullptr
 };
 
 struct TopologyDev {

@@ -1739,11 +1739,12 @@ static bool xc_pipe_launch(const BatchView& bv, int oa, hipStream_t s)
     return true;
 }
 
-// n <= 64, restricted, s/p/d shells, radial cache at 32-point tiles: the pipelined kernel (MQC_HIP_XC_PIPE=0: off)
+// n <= 64, restricted, s/p/d shells, radial cache at 32-point tiles: the pipelined kernel (measured level with the tile
+// kernel once the functional's cases stayed behind their branch; kept for A/B runs, MQC_HIP_XC_PIPE=1 turns it on)
 template <bool GGA>
 static bool xc_pipe_dispatch(const BatchView& bv, int oa, hipStream_t s)
 {
-    static const bool on = [] { const char* e = std::getenv("MQC_HIP_XC_PIPE"); return !(e && e[0] == '0'); }();
+    static const bool on = [] { const char* e = std::getenv("MQC_HIP_XC_PIPE"); return e && e[0] == '1'; }();
     if (!on || bv.uhf || bv.n > 64 || bv.topo.lmax > 2 || !bv.grid.rad || bv.grid.rad_pt != XP_PT) return false;
     bool has_x = false, has_c = false;
     for (int k = 0; k < bv.xc.ncomp; ++k) { if (xc_is_exchange(bv.xc.id[k])) has_x = true; else has_c = true; }
@@ -1754,6 +1755,415 @@ static bool xc_pipe_dispatch(const BatchView& bv, int oa, hipStream_t s)
     if (nt == 2) return xc_pipe_launch<GGA, 2>(bv, oa, s);
     if (nt == 3) return xc_pipe_launch<GGA, 3>(bv, oa, s);
     return xc_pipe_launch<GGA, 4>(bv, oa, s);
+}
+
+// ------------------------------------------------------------------ the split quadrature (n <= 64): three kernels
+// One tile kernel has to hold the slab, the density fragments, the A accumulators AND the functional's dual-number
+// stream: 230-256 registers and 50-125 KB of LDS, so eight waves per CU, and every phase is exposed latency (MFMA pipe
+// 17 % busy, profiles/r02_pmc_summary.json).  Cut at the two points where only four numbers per grid point cross:
+//   xc_density_kernel     slab -> X = D chi on the matrix cores -> rho, grad rho / 2 per point   -> pt4[f][point][4]
+//   xc_functional_kernel  one THREAD per point, all 64 lanes of every wave busy: f, v_rho, v_sigma -> E_xc, N_e and the
+//                         coefficients (w v_rho / 2, 2 w v_sigma grad rho) over the same four numbers
+//   xc_potential_kernel   slab again, but only chi and a = c0 chi + c . grad chi are kept (25 KB of LDS at n = 48) ->
+//                         A += a chi^T on the matrix cores, accumulators resident across the workgroup's tiles
+// Each kernel needs a fraction of the registers and LDS (three to five workgroups per CU), no wave ever waits for a
+// single-wave phase, and the functional runs at full width.  Price: the slab's angular part is formed twice and the
+// radial cache is read twice.  Same arithmetic as the tile kernel (mqc_libcint_xc.F90:796-927).
+constexpr int XS_PT = 32, XS_NT = 256, XS_SI = 4;      // tile points, threads, slab items per thread prefetched
+
+// value and a = c0 chi + c . grad chi of one shell at one point (l <= 2), from its radial value and derivative factor
+template <bool GGA>
+__device__ __forceinline__ void emit_shell_a(int l, int ao, double dx, double dy, double dz, double rad, double drad,
+                                             double c0, double c1, double c2, double c3,
+                                             double* __restrict__ chi, double* __restrict__ av, int ptp, int p)
+{
+    const double cd = GGA ? (c1 * dx + c2 * dy + c3 * dz) * drad : 0.0;        // c . r  R'/r
+    if (l == 0) {
+        chi[ao * ptp + p] = rad;
+        av[ao * ptp + p] = c0 * rad + cd;
+    } else if (l == 1) {
+        const double vx = dx * rad, vy = dy * rad, vz = dz * rad;
+        chi[ao * ptp + p] = vx; chi[(ao + 1) * ptp + p] = vy; chi[(ao + 2) * ptp + p] = vz;
+        av[ao * ptp + p] = c0 * vx + (GGA ? c1 * rad + dx * cd : 0.0);
+        av[(ao + 1) * ptp + p] = c0 * vy + (GGA ? c2 * rad + dy * cd : 0.0);
+        av[(ao + 2) * ptp + p] = c0 * vz + (GGA ? c3 * rad + dz * cd : 0.0);
+    } else {
+        const double cv[6] = {dx * dx, dx * dy, dx * dz, dy * dy, dy * dz, dz * dz};
+        const double cgx[6] = {2.0 * dx, dy, dz, 0.0, 0.0, 0.0};
+        const double cgy[6] = {0.0, dx, 0.0, 2.0 * dy, dz, 0.0};
+        const double cgz[6] = {0.0, 0.0, dx, 0.0, dy, 2.0 * dz};
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            double v = 0.0, g = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const double w = c2s_coef<2>(nullptr, m, k);
+                v += w * cv[k];
+                if (GGA) g += w * (c1 * cgx[k] + c2 * cgy[k] + c3 * cgz[k]);
+            }
+            chi[(ao + m) * ptp + p] = v * rad;
+            av[(ao + m) * ptp + p] = c0 * v * rad + (GGA ? g * rad + v * cd : 0.0);
+        }
+    }
+}
+
+template <bool GGA, int NTC>
+__global__ void __launch_bounds__(XS_NT, NTC >= 4 ? 2 : 3) xc_density_kernel(BatchView bv, int only_active)
+{
+    extern __shared__ double lds[];
+    const int f = blockIdx.y;
+    if ((only_active & 1) && bv.istate[4 * f] == ST_DONE) return;
+    constexpr int PT = XS_PT, RS = PT + 1, NP = 16 * NTC, ARR = GGA ? 4 : 1, SL = ARR * NP * RS, HK = 2 * NTC;   // HK: k-steps of half the functions
+    const int n = bv.n, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lo = lane & 15, hi = lane >> 4;
+    const TopologyDev& tp = bv.topo;
+    const GridDev& gd = bv.grid;
+    double* chi = lds;
+    double* gx = chi + NP * RS; double* gy = gx + (GGA ? NP * RS : 0); double* gz = gy + (GGA ? NP * RS : 0);
+    double* red = lds + SL;                                   // [PT][4]
+    double* pxyz = red + 4 * PT;                              // [2][PT][3]
+    double* axyz = pxyz + 6 * PT;                             // [natoms][3]
+    int* sdesc = (int*)(axyz + ((3 * tp.natoms + 1) & ~1));   // [nshell]
+    const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
+    const double* __restrict__ D = bv.D + (size_t)f * n * n;
+    const int ntile = (gd.npts + PT - 1) / PT;
+    const double* __restrict__ radf = gd.rad + (size_t)f * ntile * tp.nshell * 2 * PT;
+    double* __restrict__ out4 = gd.pt4 + (size_t)f * ntile * PT * 4;
+
+    for (int idx = tid; idx < SL + 4 * PT; idx += XS_NT) lds[idx] = 0.0;          // rows n..NP-1 stay zero
+    for (int sh = tid; sh < tp.nshell; sh += XS_NT) sdesc[sh] = tp.sh_aoff[sh] | (tp.sh_l[sh] << 12) | (tp.sh_atom[sh] << 16);
+    for (int idx = tid; idx < 3 * tp.natoms; idx += XS_NT) axyz[idx] = xyz[idx];
+    // this wave's part of X = D chi: point tile pt, half kh of the functions, every row tile mt -- the B operand
+    // (AO values of its points) is then the same for all its jobs, and rho / grad rho of its 16 points add up in
+    // registers over the row tiles: one reduction per tile and wave
+    const int pt = (wave >> 1) & 1, kh = wave & 1;
+    double dfrag[NTC][HK];
+#pragma unroll
+    for (int mt = 0; mt < NTC; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < HK; ++ks) {
+            const int mu = 16 * mt + lo, nu = 4 * (kh * HK + ks) + hi;
+            dfrag[mt][ks] = (mu < n && nu < n) ? D[(size_t)mu * n + nu] : 0.0;
+        }
+    auto fetch_point = [&](int tile, int q, double& x, double& y, double& z) {
+        const int g = tile * PT + q;
+        x = 0.0; y = 0.0; z = 0.0;
+        if (g < gd.npts) {
+            const int oa = gd.pt_atom[g], it = gd.pt_tmpl[g];
+            x = xyz[3 * oa] + gd.tmpl_xyz[3 * it]; y = xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1]; z = xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2];
+        }
+    };
+    const int stride = (int)gridDim.x;
+    int tile = blockIdx.x;
+    const bool ptthr = tid >= XS_NT - PT;                     // the last PT threads carry the grid points a tile ahead
+    const int q = tid - (XS_NT - PT);
+    double nx = 0.0, ny = 0.0, nz = 0.0;
+    if (ptthr) { fetch_point(tile, q, nx, ny, nz); double* pp = pxyz + 3 * q; pp[0] = nx; pp[1] = ny; pp[2] = nz; }
+    // radial values of this thread's slab items, fetched a TILE AHEAD into registers (issued after the slab, landing
+    // under the MFMA phase): read inside the slab loop every item waited out an HBM round trip
+    const int nitem = tp.nshell * PT;
+    double rv[XS_SI], dv[XS_SI];
+    auto radial_fetch = [&](int t) {
+#pragma unroll
+        for (int k = 0; k < XS_SI; ++k) {
+            const int idx = tid + XS_NT * k;
+            rv[k] = 0.0; dv[k] = 0.0;
+            if (idx < nitem && t < ntile) {
+                const int sh = idx / PT, p = idx - sh * PT;
+                if (t * PT + p < gd.npts) {
+                    const double* r0 = radf + ((size_t)t * tp.nshell + sh) * 2 * PT + p;
+                    rv[k] = r0[0];
+                    if (GGA) dv[k] = r0[PT];
+                }
+            }
+        }
+    };
+    radial_fetch(tile);
+    __syncthreads();
+    int pbuf = 0;
+    for (; tile < ntile; tile += stride, pbuf ^= 1) {
+        if (ptthr) fetch_point(tile + stride, q, nx, ny, nz);       // in flight under the slab
+        // ---- slab: (shell, point) items, point fastest (lanes along the points)
+        {
+            const int g0 = tile * PT;
+#pragma unroll
+            for (int k = 0; k < XS_SI; ++k) {
+                const int idx = tid + XS_NT * k;
+                if (idx < nitem) {
+                    const int sh = idx / PT, p = idx - sh * PT;
+                    const int sd = sdesc[sh];
+                    const int ao = sd & 0xfff, l = (sd >> 12) & 0xf, at = sd >> 16;
+                    const double* pp = pxyz + 3 * (pbuf * PT + p);
+                    const double dx = pp[0] - axyz[3 * at], dy = pp[1] - axyz[3 * at + 1], dz = pp[2] - axyz[3 * at + 2];
+                    emit_shell<GGA, false>(l, ao, dx, dy, dz, rv[k], dv[k], chi, gx, gy, gz, RS, p, bv.c2s);
+                }
+            }
+            const double* __restrict__ radt = radf + (size_t)tile * tp.nshell * 2 * PT;
+            for (int idx = tid + XS_NT * XS_SI; idx < nitem; idx += XS_NT) {        // more than XS_SI items per thread: direct
+                const int sh = idx / PT, p = idx - sh * PT;
+                const int sd = sdesc[sh];
+                const int ao = sd & 0xfff, l = (sd >> 12) & 0xf, at = sd >> 16;
+                const double* pp = pxyz + 3 * (pbuf * PT + p);
+                const double dx = pp[0] - axyz[3 * at], dy = pp[1] - axyz[3 * at + 1], dz = pp[2] - axyz[3 * at + 2];
+                const bool in = g0 + p < gd.npts;
+                const double* r0 = radt + (size_t)sh * 2 * PT + p;
+                emit_shell<GGA, false>(l, ao, dx, dy, dz, in ? r0[0] : 0.0, (GGA && in) ? r0[PT] : 0.0, chi, gx, gy, gz, RS, p, bv.c2s);
+            }
+        }
+        radial_fetch(tile + stride);
+        if (ptthr) { double* pp = pxyz + 3 * ((pbuf ^ 1) * PT + q); pp[0] = nx; pp[1] = ny; pp[2] = nz; }
+        __syncthreads();
+        // ---- X = D chi for this wave's (pt, kh), all row tiles; rho and grad rho of its 16 points
+        {
+            double bw[HK];
+#pragma unroll
+            for (int ks = 0; ks < HK; ++ks) bw[ks] = chi[(4 * (kh * HK + ks) + hi) * RS + 16 * pt + lo];
+            double rho = 0.0, rx = 0.0, ry = 0.0, rz = 0.0;
+            // the row tiles' accumulation chains are independent: issued interleaved (k-step outer), a chain's next MFMA
+            // is NTC instructions behind its predecessor instead of waiting out its latency
+            v4f64 xacc[NTC];
+#pragma unroll
+            for (int mt = 0; mt < NTC; ++mt) xacc[mt] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < HK; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < NTC; ++mt) xacc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(dfrag[mt][ks], bw[ks], xacc[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < NTC; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = (16 * mt + hi + 4 * r) * RS + 16 * pt + lo;
+                    const double x = xacc[mt][r];
+                    rho += x * chi[o];
+                    if (GGA) { rx += x * gx[o]; ry += x * gy[o]; rz += x * gz[o]; }
+                }
+            rho += __shfl_xor(rho, 16, 64); rho += __shfl_xor(rho, 32, 64);
+            if (GGA) {
+                rx += __shfl_xor(rx, 16, 64); rx += __shfl_xor(rx, 32, 64);
+                ry += __shfl_xor(ry, 16, 64); ry += __shfl_xor(ry, 32, 64);
+                rz += __shfl_xor(rz, 16, 64); rz += __shfl_xor(rz, 32, 64);
+            }
+            if (hi == 0) {
+                double* rp = red + 4 * (16 * pt + lo);
+                atomicAdd(&rp[0], rho);
+                if (GGA) { atomicAdd(&rp[1], rx); atomicAdd(&rp[2], ry); atomicAdd(&rp[3], rz); }
+            }
+        }
+        __syncthreads();
+        // ---- the tile's four numbers per point go out (1 KiB, contiguous); the sums start at zero again
+        if (tid < 4 * PT) {
+            out4[(size_t)tile * PT * 4 + tid] = red[tid];
+            red[tid] = 0.0;
+        }
+    }
+}
+
+template <bool GGA>
+__global__ void __launch_bounds__(256) xc_functional_kernel(BatchView bv, int only_active)
+{
+    const int f = blockIdx.y;
+    if ((only_active & 1) && bv.istate[4 * f] == ST_DONE) return;
+    const GridDev& gd = bv.grid;
+    const int npad = ((gd.npts + XS_PT - 1) / XS_PT) * XS_PT;
+    double* __restrict__ v4 = gd.pt4 + (size_t)f * npad * 4;
+    const double* __restrict__ wts = gd.weights + (size_t)f * gd.npts;
+    double e_acc = 0.0, n_acc = 0.0;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npad; p += gridDim.x * blockDim.x) {
+        const double2 a = *(const double2*)(v4 + 4 * (size_t)p), b = *(const double2*)(v4 + 4 * (size_t)p + 2);
+        const double rho = a.x, rx = 2.0 * a.y, ry = 2.0 * b.x, rz = 2.0 * b.y;
+        const double w = p < gd.npts ? wts[p] : 0.0;
+        const double sigma = GGA ? rx * rx + ry * ry + rz * rz : 0.0;
+        double fx, vr, vs;
+        eval_functional(bv.xc, rho, sigma, fx, vr, vs);
+        e_acc += w * fx; n_acc += w * rho;
+        const double t2 = 2.0 * w * vs;
+        *(double2*)(v4 + 4 * (size_t)p) = make_double2(0.5 * w * vr, t2 * rx);
+        *(double2*)(v4 + 4 * (size_t)p + 2) = make_double2(t2 * ry, t2 * rz);
+    }
+    __shared__ double part[2][4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { e_acc += __shfl_down(e_acc, off, 64); n_acc += __shfl_down(n_acc, off, 64); }
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = e_acc; part[1][threadIdx.x >> 6] = n_acc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&bv.scal[(size_t)f * 8 + 5], part[0][0] + part[0][1] + part[0][2] + part[0][3]);
+        atomicAdd(&bv.scal[(size_t)f * 8 + 6], part[1][0] + part[1][1] + part[1][2] + part[1][3]);
+    }
+}
+
+template <bool GGA, int NTC>
+__global__ void __launch_bounds__(XS_NT, NTC >= 4 ? 2 : 3) xc_potential_kernel(BatchView bv, int only_active)
+{
+    extern __shared__ double lds[];
+    const int f = blockIdx.y;
+    if ((only_active & 1) && bv.istate[4 * f] == ST_DONE) return;
+    constexpr int PT = XS_PT, RS = PT + 1, NP = 16 * NTC, SL = 2 * NP * RS;
+    constexpr int NU = 2 * NTC * NTC, JU = (NU + 3) / 4;         // (output tile, half of the points) units, units per wave
+    const int n = bv.n, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lo = lane & 15, hi = lane >> 4;
+    const TopologyDev& tp = bv.topo;
+    const GridDev& gd = bv.grid;
+    double* chi = lds;                                        // [NP][RS]
+    double* av = chi + NP * RS;                               // [NP][RS]  a = c0 chi + c . grad chi
+    double* coef = lds + SL;                                  // [2][PT][4]
+    double* pxyz = coef + 8 * PT;                             // [2][PT][3]
+    double* axyz = pxyz + 6 * PT;                             // [natoms][3]
+    int* sdesc = (int*)(axyz + ((3 * tp.natoms + 1) & ~1));   // [nshell]
+    const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
+    const int ntile = (gd.npts + PT - 1) / PT;
+    const double* __restrict__ radf = gd.rad + (size_t)f * ntile * tp.nshell * 2 * PT;
+    const double* __restrict__ c4 = gd.pt4 + (size_t)f * ntile * PT * 4;
+
+    for (int idx = tid; idx < SL; idx += XS_NT) lds[idx] = 0.0;
+    for (int sh = tid; sh < tp.nshell; sh += XS_NT) sdesc[sh] = tp.sh_aoff[sh] | (tp.sh_l[sh] << 12) | (tp.sh_atom[sh] << 16);
+    for (int idx = tid; idx < 3 * tp.natoms; idx += XS_NT) axyz[idx] = xyz[idx];
+    auto fetch_point = [&](int tile, int q, double& x, double& y, double& z) {
+        const int g = tile * PT + q;
+        x = 0.0; y = 0.0; z = 0.0;
+        if (g < gd.npts) {
+            const int oa = gd.pt_atom[g], it = gd.pt_tmpl[g];
+            x = xyz[3 * oa] + gd.tmpl_xyz[3 * it]; y = xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1]; z = xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2];
+        }
+    };
+    v4f64 vacc[JU];
+#pragma unroll
+    for (int j = 0; j < JU; ++j) vacc[j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    const int stride = (int)gridDim.x;
+    int tile = blockIdx.x;
+    // a tile ahead: threads 0 .. 4 PT - 1 carry the coefficients, the last PT threads the grid points
+    const bool cthr = tid < 4 * PT, ptthr = tid >= XS_NT - PT;
+    const int q = tid - (XS_NT - PT);
+    double cnext = 0.0, nx = 0.0, ny = 0.0, nz = 0.0;
+    if (cthr) coef[tid] = c4[(size_t)tile * PT * 4 + tid];
+    if (ptthr) { fetch_point(tile, q, nx, ny, nz); double* pp = pxyz + 3 * q; pp[0] = nx; pp[1] = ny; pp[2] = nz; }
+    const int nitem = tp.nshell * PT;
+    double rv[XS_SI], dv[XS_SI];
+    auto radial_fetch = [&](int t) {          // this thread's slab items of tile t, a tile ahead (see xc_density_kernel)
+#pragma unroll
+        for (int k = 0; k < XS_SI; ++k) {
+            const int idx = tid + XS_NT * k;
+            rv[k] = 0.0; dv[k] = 0.0;
+            if (idx < nitem && t < ntile) {
+                const int sh = idx / PT, p = idx - sh * PT;
+                if (t * PT + p < gd.npts) {
+                    const double* r0 = radf + ((size_t)t * tp.nshell + sh) * 2 * PT + p;
+                    rv[k] = r0[0];
+                    if (GGA) dv[k] = r0[PT];
+                }
+            }
+        }
+    };
+    radial_fetch(tile);
+    __syncthreads();
+    int buf = 0;
+    for (; tile < ntile; tile += stride, buf ^= 1) {
+        const int next = tile + stride;
+        if (cthr && next < ntile) cnext = c4[(size_t)next * PT * 4 + tid];
+        if (ptthr) fetch_point(next, q, nx, ny, nz);
+        // ---- slab: chi and a of every (shell, point)
+        {
+            const int g0 = tile * PT;
+#pragma unroll
+            for (int k = 0; k < XS_SI; ++k) {
+                const int idx = tid + XS_NT * k;
+                if (idx < nitem) {
+                    const int sh = idx / PT, p = idx - sh * PT;
+                    const int sd = sdesc[sh];
+                    const int ao = sd & 0xfff, l = (sd >> 12) & 0xf, at = sd >> 16;
+                    const double* pp = pxyz + 3 * (buf * PT + p);
+                    const double dx = pp[0] - axyz[3 * at], dy = pp[1] - axyz[3 * at + 1], dz = pp[2] - axyz[3 * at + 2];
+                    const double* cp = coef + 4 * (buf * PT + p);
+                    emit_shell_a<GGA>(l, ao, dx, dy, dz, rv[k], dv[k], cp[0], cp[1], cp[2], cp[3], chi, av, RS, p);
+                }
+            }
+            const double* __restrict__ radt = radf + (size_t)tile * tp.nshell * 2 * PT;
+            for (int idx = tid + XS_NT * XS_SI; idx < nitem; idx += XS_NT) {
+                const int sh = idx / PT, p = idx - sh * PT;
+                const int sd = sdesc[sh];
+                const int ao = sd & 0xfff, l = (sd >> 12) & 0xf, at = sd >> 16;
+                const double* pp = pxyz + 3 * (buf * PT + p);
+                const double dx = pp[0] - axyz[3 * at], dy = pp[1] - axyz[3 * at + 1], dz = pp[2] - axyz[3 * at + 2];
+                const bool in = g0 + p < gd.npts;
+                const double* r0 = radt + (size_t)sh * 2 * PT + p;
+                const double* cp = coef + 4 * (buf * PT + p);
+                emit_shell_a<GGA>(l, ao, dx, dy, dz, in ? r0[0] : 0.0, (GGA && in) ? r0[PT] : 0.0, cp[0], cp[1], cp[2], cp[3], chi, av, RS, p);
+            }
+        }
+        radial_fetch(next);
+        if (cthr) coef[4 * ((buf ^ 1) * PT) + tid] = cnext;
+        if (ptthr) { double* pp = pxyz + 3 * ((buf ^ 1) * PT + q); pp[0] = nx; pp[1] = ny; pp[2] = nz; }
+        __syncthreads();
+        // ---- A += a chi^T: unit = (output tile t = mt NTC + nt, half kh of the tile's points)
+#pragma unroll
+        for (int j = 0; j < JU; ++j) {
+            const int u = wave + 4 * j;
+            if (u < NU) {
+                const int t = u >> 1, kh = u & 1, mt = t / NTC, nt = t - mt * NTC;
+                const double* __restrict__ ar = av + (size_t)(16 * mt + lo) * RS + 16 * kh + hi;
+                const double* __restrict__ br = chi + (size_t)(16 * nt + lo) * RS + 16 * kh + hi;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) vacc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[4 * ks], br[4 * ks], vacc[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    double* Vx = bv.Vxc + (size_t)f * n * n;
+#pragma unroll
+    for (int j = 0; j < JU; ++j) {
+        const int u = wave + 4 * j;
+        if (u < NU) {
+            const int t = u >> 1, mt = t / NTC, nt = t - mt * NTC;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mu = 16 * mt + hi + 4 * r, nu = 16 * nt + lo;
+                const double v = vacc[j][r];
+                if (mu < n && nu < n && v != 0.0) atomicAdd(&Vx[mu * n + nu], v);
+            }
+        }
+    }
+}
+
+template <bool GGA, int NTC>
+static bool xc_split_launch(const BatchView& bv, int oa, hipStream_t s)
+{
+    constexpr int PT = XS_PT;
+    const size_t misc = 6 * PT + (((size_t)3 * bv.topo.natoms + 1) & ~(size_t)1) + ((size_t)bv.topo.nshell + 1) / 2;
+    const size_t lds1 = sizeof(double) * ((size_t)(GGA ? 4 : 1) * 16 * NTC * (PT + 1) + 4 * PT + misc);
+    const size_t lds3 = sizeof(double) * ((size_t)2 * 16 * NTC * (PT + 1) + 8 * PT + misc);
+    if (lds1 > (size_t)160 * 1024 - 256 || lds3 > (size_t)160 * 1024 - 256) return false;
+    auto k1 = xc_density_kernel<GGA, NTC>;
+    auto k3 = xc_potential_kernel<GGA, NTC>;
+    (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    (void)hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+    const int ntiles = (bv.grid.npts + PT - 1) / PT;
+    // density: no state carried from tile to tile, any number of workgroups; ~8 rounds of three per CU over the batch
+    int g1 = (6144 + bv.nfrag - 1) / bv.nfrag;
+    if (g1 > ntiles) g1 = ntiles;
+    if (g1 < 1) g1 = 1;
+    // potential: the accumulators are flushed once per workgroup (n^2 atomics), so a workgroup takes many tiles
+    int g3 = (3072 + bv.nfrag - 1) / bv.nfrag;
+    if (g3 > (ntiles + 15) / 16) g3 = (ntiles + 15) / 16;
+    if (g3 < 1) g3 = 1;
+    const int npad = ntiles * PT;
+    int g2 = (npad + 255) / 256;
+    if (g2 > 64) g2 = 64;
+    hipLaunchKernelGGL(k1, dim3(g1, bv.nfrag), dim3(XS_NT), lds1, s, bv, oa);
+    hipLaunchKernelGGL(xc_functional_kernel<GGA>, dim3(g2, bv.nfrag), dim3(256), 0, s, bv, oa);
+    hipLaunchKernelGGL(k3, dim3(g3, bv.nfrag), dim3(XS_NT), lds3, s, bv, oa);
+    return true;
+}
+
+// n <= 64, restricted, s/p/d shells, radial cache at 32-point tiles, point buffer there (MQC_HIP_XC_SPLIT=0: off)
+template <bool GGA>
+static bool xc_split_dispatch(const BatchView& bv, int oa, hipStream_t s)
+{
+    static const bool on = [] { const char* e = std::getenv("MQC_HIP_XC_SPLIT"); return !(e && e[0] == '0'); }();
+    if (!on || bv.uhf || bv.n > 64 || bv.topo.lmax > 2 || !bv.grid.rad || bv.grid.rad_pt != XS_PT || !bv.grid.pt4) return false;
+    const int nt = (bv.n + 15) / 16;
+    if (nt == 1) return xc_split_launch<GGA, 1>(bv, oa, s);
+    if (nt == 2) return xc_split_launch<GGA, 2>(bv, oa, s);
+    if (nt == 3) return xc_split_launch<GGA, 3>(bv, oa, s);
+    return xc_split_launch<GGA, 4>(bv, oa, s);
 }
 
 __global__ void xc_reset_kernel(BatchView bv)
@@ -1943,6 +2353,7 @@ void launch_xc(const BatchView& bv, bool only_active, hipStream_t s)
     (void)probed;
     // MQC_HIP_XC_V1=1: the round-1 kernels (wave-private MFMA kernel for n <= 48, VALU kernel above), kept for A/B runs
     static const bool v1 = [] { const char* e = std::getenv("MQC_HIP_XC_V1"); return e && e[0] == '1'; }();
+    if (!v1 && (gga ? xc_split_dispatch<true>(bv, oa, s) : xc_split_dispatch<false>(bv, oa, s))) return;
     if (!v1 && (gga ? xc_pipe_dispatch<true>(bv, oa, s) : xc_pipe_dispatch<false>(bv, oa, s))) return;
     if (!v1 && (gga ? xc_tile_dispatch<true>(bv, oa, s) : xc_tile_dispatch<false>(bv, oa, s))) {
 #if XC_STAMPS
