@@ -76,16 +76,22 @@ def parse_args():
 # ---------------------------------------------------------------------------------------------- CPU baseline
 def _cpu_worker(job):
     """One fragment through the oracle in a single-threaded worker process (rank-per-fragment)."""
-    basis, z, coords, nelec, e_tol, d_tol = job
+    basis, z, coords, nelec, e_tol, d_tol = job[:6]
+    functional = job[6] if len(job) > 6 else ""
     from metalquicha_amd.methods import PhysicalFragment
     from oracle import scf_oracle as so
     from tests.helpers import oracle_mol
     frag = PhysicalFragment(np.asarray(z), np.asarray(coords))
-    r = so.run_rhf(oracle_mol(basis, frag), int(nelec), 100, e_tol, d_tol)
+    mol = oracle_mol(basis, frag)
+    xc = None
+    if functional:
+        from oracle import xc_oracle
+        xc = xc_oracle.XCOracle(mol, functional, 3)
+    r = so.run_rhf(mol, int(nelec), 100, e_tol, d_tol, xc=xc)
     return float(r.energy), int(r.iterations)
 
 
-def cpu_baseline(system, terms, basis, gpu_energies, args):
+def cpu_baseline(system, terms, basis, gpu_energies, args, functional="", dimers_per_core=None):
     """P single-threaded worker processes pull fragments from a queue, as the reference's MBE ranks do."""
     import multiprocessing as mp
     from metalquicha_amd import mbe
@@ -95,13 +101,14 @@ def cpu_baseline(system, terms, basis, gpu_energies, args):
     except AttributeError:
         avail = os.cpu_count() or 1
     procs = args.cpu_procs if args.cpu_procs > 0 else max(1, min(avail, 32))
-    dimers = [i for i, t in enumerate(terms) if len(t) == 2][: procs * args.cpu_dimers_per_core]
+    per_core = args.cpu_dimers_per_core if dimers_per_core is None else dimers_per_core
+    dimers = [i for i, t in enumerate(terms) if len(t) == 2][: procs * per_core]
     monos = [i for i, t in enumerate(terms) if len(t) == 1][: max(2, procs // 4)]
     sample = dimers + monos
     jobs = []
     for i in sample:
         frag = mbe.build_fragment(system, terms[i])
-        jobs.append((basis, frag.element_numbers.tolist(), frag.coordinates.tolist(), int(frag.nelec), args.energy_tol, args.density_tol))
+        jobs.append((basis, frag.element_numbers.tolist(), frag.coordinates.tolist(), int(frag.nelec), args.energy_tol, args.density_tol, functional))
     so.build_oracle_lib()
     saved = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
     for k in saved:
@@ -122,22 +129,28 @@ def cpu_baseline(system, terms, basis, gpu_energies, args):
     e_cpu = np.array([o[0] for o in out]); iters = int(sum(o[1] for o in out))
     diff = float(np.max(np.abs(e_cpu - gpu_energies[sample]))) if gpu_energies is not None else None
     return {"value": iters / dt, "unit": "SCF iterations/s", "cores": procs, "kind": "port",
-            "sample": "%d water dimers + %d monomers of the same cluster, RHF/%s, oracle (C McMurchie-Davidson integrals, "
-                      "numpy linear algebra), %d single-threaded worker processes pulling one fragment at a time "
-                      "(the reference's rank-per-fragment scheme), %.1f s" % (len(dimers), len(monos), basis, procs, dt),
+            "sample": "%d water dimers + %d monomers of the same cluster, %s/%s, oracle (C McMurchie-Davidson integrals, "
+                      "numpy linear algebra%s), %d single-threaded worker processes pulling one fragment at a time "
+                      "(the reference's rank-per-fragment scheme), %.1f s" % (len(dimers), len(monos), (functional.upper() or "RHF"), basis,
+                                                                              ", level-3 grid quadrature in 4096-point blocks" if functional else "", procs, dt),
             "seconds": dt, "fragments": len(sample), "host_cores_visible": avail,
             "parity_max_abs_diff": diff, "parity_fragments": len(sample)}
 
 
 def committed_pmc():
-    """Figures from the committed rocprofv3 --pmc passes of THIS command (profiles/r02_pmc_summary.json, written by
-    scripts/pmc_summary.py from separate counter runs): HBM bytes per launch of the J/K kernel, FP64 flop of the
-    integral stage.  None when absent."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")) as f:
-            return json.load(f)
-    except Exception:
-        return None
+    """Figures from the committed rocprofv3 --pmc passes of THIS command (profiles/r03_pmc_summary.json, written by
+    scripts/pmc_summary.py from separate counter runs, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in
+    passes of their own): HBM bytes per launch of the J/K kernel, FP64 flop of the integral stage, MFMA-busy fractions.
+    None when absent."""
+    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+                d["_source"] = "profiles/" + name
+                return d
+        except Exception:
+            continue
+    return None
 
 
 def rigid_motion(system, step, seed=977):
@@ -234,14 +247,41 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed, cold_s = float(tmax[0].item()), float(tmax[1].item())
 
+    # ---- the north star's own workload as a first-class block: the same cluster and MBE-2 term list with B3LYP (XC on
+    # the level-3 pruned grid, 20 % exact exchange from the same in-core tensor): one warm-up + two timed evaluations on
+    # fresh geometries, its own engine statistics (-> its own roofline) -- never part of `value`
+    b3 = None
+    if not args.no_secondary and not args.functional and not args.df:
+        sb = methods.ScfSettings(basis_set=args.basis, functional="b3lyp", guess="gwh", energy_tol=args.energy_tol,
+                                 density_tol=args.density_tol, schwarz_tol=args.schwarz_tol, device_rank=local_rank)
+        _, e_b3_frag, _ = evaluate(system0, sb, terms)       # warm-up on the unmoved cluster: its fragment energies are what the CPU sample is compared with
+        methods.get_stats()
+        b3_systems = [moved(1901 + k) for k in range(2)]
+        barrier()
+        t1 = time.perf_counter()
+        b3_iters = 0.0
+        b3_e = []
+        for sysb in b3_systems:
+            eb, _, itb = evaluate(sysb, sb, terms)
+            b3_e.append(eb); b3_iters += itb
+        barrier()
+        b3_dt = time.perf_counter() - t1
+        b3_st = methods.get_stats()
+        if world > 1:
+            t2 = torch.tensor([b3_dt], dtype=torch.float64)
+            if use_cuda_tensors:
+                t2 = t2.cuda()
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+            b3_dt = float(t2.item())
+        b3 = {"dt": b3_dt, "iters": b3_iters, "stats": b3_st, "energies": b3_e, "frag_energies": e_b3_frag, "steps": len(b3_systems)}
+
     # ---- secondary measurements (never part of `value`): the north star's B3LYP target and the density-fitted path on
     # the same cluster (one warm-up + one timed evaluation each, moved geometry), and the literal drop-in: ONE fragment
     # per mqc_hip_scf_run call, as an unchanged do_fragment_work would drive the engine
     secondary = None
     if not args.no_secondary and not args.functional and not args.df:
         secondary = {}
-        for label, kw in (("b3lyp_exact_eri", dict(functional="b3lyp")),
-                          ("rhf_density_fitted", dict(density_fitting=True)),
+        for label, kw in (("rhf_density_fitted", dict(density_fitting=True)),
                           ("b3lyp_density_fitted", dict(functional="b3lyp", density_fitting=True))):
             s2 = methods.ScfSettings(basis_set=args.basis, guess="gwh", energy_tol=args.energy_tol, density_tol=args.density_tol,
                                      schwarz_tol=args.schwarz_tol, device_rank=local_rank, aux_basis_set="mqc-even-tempered-jkfit", **kw)
@@ -407,6 +447,38 @@ def main():
                                "scf_loop": st.t_fock, "fetch": st.t_scf_step, "total": st.t_total},
             "roofline": roof,
         }
+        if b3 is not None:
+            bs = b3["stats"]
+            # XC stage: the engine's HIP events around its quadrature launches (density, functional and potential
+            # kernels of the split quadrature).  Two flop counts: SURVEY 8d's algorithmic 8 P n^2, and the MFMA flop the
+            # kernels actually issue, 4 P n^2 (X = D chi and A += a chi^T; the GGA contraction uses ONE combined vector a)
+            xc_s = bs.xc_kernel_seconds
+            mfma_tf = (0.5 * bs.xc_flops / xc_s / 1e12) if xc_s > 0 else None
+            pm = committed_pmc() or {}
+            mf = None
+            for kname, v in pm.get("passes", {}).get("sq_b3lyp", {}).get("kernels", {}).items():
+                if kname.startswith("xc_density_kernel") and "mfma_busy_fraction" in v:
+                    mf = {"kernel": kname, "mfma_busy_fraction": v["mfma_busy_fraction"], "mfma_tflops": v.get("mfma_tflops"), "source": pm.get("_source")}
+            line["b3lyp"] = {
+                "workload": "(H2O)%d MBE-2 B3LYP/%s (libxc hyb_gga_xc_b3lyp: 0.08 Slater + 0.72 B88 + 0.19 VWN-RPA + 0.81 LYP, 20 %% exact exchange), "
+                            "level-3 pruned grid, exact in-core ERIs Schwarz-screened at %.0e, %d SCFs, GWH guess, e_tol %.0e d_tol %.0e; fresh rigid motion per evaluation"
+                            % (system0.n_monomers, args.basis, args.schwarz_tol, len(terms), args.energy_tol, args.density_tol),
+                "value": b3["iters"] / b3["dt"], "unit": "SCF iterations/s", "steps": b3["steps"],
+                "mbe2_wall_s": b3["dt"] / b3["steps"], "scf_iterations_per_step": b3["iters"] / b3["steps"],
+                "mbe2_energy_hartree": b3["energies"][-1],
+                "stage_seconds_per_step": {"xc": xc_s / b3["steps"], "jk": bs.fock_kernel_seconds / b3["steps"],
+                                           "eri": bs.eri_kernel_seconds / b3["steps"], "scf_step": bs.scf_step_seconds / b3["steps"]},
+                "roofline": {"bound": "mfma", "kernel": "xc_density_kernel + xc_functional_kernel + xc_potential_kernel (XC stage)",
+                             "achieved": mfma_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": (mfma_tf / FP64_PEAK_TFLOPS) if mfma_tf else None, "traffic": None,
+                             "flops_counted": "MFMA flop issued: 4 P n^2 per launch (P = grid points x active fragments)",
+                             "algorithmic_tflops_8Pn2": (bs.xc_flops / xc_s / 1e12) if xc_s > 0 else None,
+                             "kernel_seconds": xc_s, "points": bs.xc_points, "mfma_counters": mf},
+            }
+            if not args.no_cpu_baseline and world == 1:
+                cb = cpu_baseline(system0, terms, args.basis, b3["frag_energies"], args, functional="b3lyp", dimers_per_core=1)
+                line["b3lyp"]["cpu_baseline"] = cb
+                line["b3lyp"]["parity_max_abs_diff"] = cb["parity_max_abs_diff"]
         line["secondary"] = secondary
         pm_all = committed_pmc()
         if pm_all and "passes" in pm_all:
@@ -419,7 +491,7 @@ def main():
                                 "valu_fp64_tflops": v.get("valu_fp64_tflops"), "peak_tflops": FP64_PEAK_TFLOPS}
                 return None
             line["mfma_counters"] = {"xc": _mf("sq_b3lyp", "xc_tile_kernel"), "df_jk": _mf("sq_df", "df_jk_mfma_kernel"),
-                                     "df_fit": _mf("sq_df", "df_fit_mfma_kernel"), "source": "profiles/r02_pmc_summary.json"}
+                                     "df_fit": _mf("sq_df", "df_fit_mfma_kernel"), "source": pm_all.get("_source")}
         if not args.no_cpu_baseline and world == 1 and not args.functional and not args.df:
             line["cpu_baseline"] = cpu_baseline(system0, terms, args.basis, energies0, args)
             line["parity_max_abs_diff"] = line["cpu_baseline"]["parity_max_abs_diff"]

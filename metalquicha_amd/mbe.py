@@ -20,7 +20,7 @@ from __future__ import annotations
 
 import itertools
 from dataclasses import dataclass
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -174,6 +174,124 @@ def partition_terms(n_terms: int, rank: int, world: int) -> np.ndarray:
     return np.arange(rank, n_terms, world, dtype=np.int64)
 
 
+# ---- cost-aware distribution ----------------------------------------------------------------------------------------
+# The reference sorts fragments largest-first (sort_fragments_by_size, src/fragmentation/common/mqc_frag_utils.f90:312)
+# and lets workers PULL them from a queue (queue_t, src/fragmentation/common/mqc_work_queue.f90:9-58; coordinator
+# ...distribution_scheme.F90:402-758), so a rank that drew heavy fragments simply draws fewer.  Round-robin over the
+# sorted list is only balanced when all terms of an order cost the same; with mixed lists (monomers next to dimers,
+# two basis sets, GMBE intersections) it is not.  Two replacements, both ending in the same single all-reduce:
+#   partition_terms_lpt   static, no communication: longest-processing-time-first over a cost model -- every rank
+#                         computes the same assignment from the same list (makespan <= (4/3 - 1/(3 m)) optimum, and
+#                         max load - mean load <= the largest single cost);
+#   PullQueue             dynamic: an atomic counter on the job's rendezvous store (torch.distributed TCPStore.add);
+#                         ranks draw chunks of the cost-sorted list until it is dry -- the reference's queue without a
+#                         coordinator rank.  Each draw is one engine batch.
+def term_costs(system: "FragmentedSystem", terms: Sequence[Tuple[int, ...]], basis_set: str, functional: str = "",
+               density_fitting: bool = False) -> np.ndarray:
+    """Relative cost of every term from its basis-function count n: the in-core exact-ERI path forms ~n^4 / 8 integrals
+    and streams them every iteration (n^4), density fitting costs ~n^3, the quadrature adds (grid points ~ atoms) x n^2.
+    A model for BALANCING -- only ratios between terms matter."""
+    from .basis import build_flat_basis
+    nao_of_z: Dict[int, int] = {}
+
+    def nao(z: int) -> int:
+        if z not in nao_of_z:
+            fb = build_flat_basis(basis_set, [z])
+            nao_of_z[z] = int(fb.nao)
+        return nao_of_z[z]
+    z_all = np.asarray(system.element_numbers)
+    out = np.zeros(len(terms))
+    for i, t in enumerate(terms):
+        atoms = [int(a) for m in t for a in system.monomers[m]]
+        n = float(sum(nao(int(z_all[a])) for a in atoms))
+        c = n ** 3 if density_fitting else n ** 4 / 64.0
+        if functional:
+            c += 2.0e3 * len(atoms) * n * n        # ~17 k grid points per atom, ~8 n^2 flop each, against ~64 n^4 flop of J/K work per fragment
+        out[i] = c
+    return out
+
+
+def partition_terms_lpt(costs: Sequence[float], rank: int, world: int) -> np.ndarray:
+    """Longest-processing-time-first: terms by decreasing cost, each to the currently least loaded rank (ties: lowest
+    rank).  Deterministic, so every rank derives the same assignment without talking; returns this rank's terms in
+    decreasing cost."""
+    costs = np.asarray(costs, dtype=np.float64)
+    order = np.argsort(-costs, kind="stable")
+    load = np.zeros(world)
+    mine: List[int] = []
+    for i in order:
+        r = int(np.argmin(load))
+        load[r] += costs[i]
+        if r == rank:
+            mine.append(int(i))
+    return np.asarray(mine, dtype=np.int64)
+
+
+def partition_loads(costs: Sequence[float], world: int, scheme: str = "lpt") -> np.ndarray:
+    """Per-rank summed cost under a scheme ("lpt" | "round_robin"): what a balance check looks at."""
+    costs = np.asarray(costs, dtype=np.float64)
+    part = partition_terms_lpt if scheme == "lpt" else (lambda c, r, w: partition_terms(len(c), r, w))
+    return np.array([float(np.sum(costs[part(costs, r, world)])) for r in range(world)])
+
+
+class PullQueue:
+    """Work queue over a shared atomic counter: `draw()` returns the next slice [lo, hi) of a list of n items, or None
+    when it is dry.  `counter_add(k)` must atomically add k to the shared counter and return the NEW value
+    (torch.distributed.TCPStore: lambda k: store.add(key, k)).  Guided chunks: a draw takes remaining / (2 world)
+    items, at least `min_chunk` -- large batches while the list is long (the engine wants batches), small ones at the
+    tail (balance).  Since the counter only says how many items are gone, every rank can replay the chunk boundaries."""
+
+    def __init__(self, n_items: int, world: int, counter_add: Callable[[int], int], min_chunk: int = 1):
+        self.n, self.world, self.add, self.min_chunk = int(n_items), max(1, int(world)), counter_add, max(1, int(min_chunk))
+
+    def chunk_after(self, taken: int) -> int:
+        left = self.n - taken
+        return max(self.min_chunk, -(-left // (2 * self.world))) if left > 0 else 0
+
+    def draw(self) -> Optional[Tuple[int, int]]:
+        """Claims the next slice.  The counter is monotonic and every claim is one atomic add, so the slices of all ranks
+        are disjoint and cover [0, n) whatever chunk sizes the ranks ask for; the size asked for follows the guided
+        schedule at the position this rank last saw."""
+        k = self.chunk_after(getattr(self, "_seen", 0))
+        if k == 0:
+            return None
+        hi = int(self.add(k))
+        lo = hi - k
+        self._seen = hi
+        if lo >= self.n:
+            return None
+        return lo, min(hi, self.n)
+
+
+def run_mbe_pull(system: FragmentedSystem, settings: ScfSettings, terms: List[Tuple[int, ...]], queue: PullQueue,
+                 costs: Optional[Sequence[float]] = None, evaluate: Optional[Callable] = None) -> MbeRun:
+    """One rank's part of an MBE evaluation with a pull queue: draws slices of the cost-sorted term list, each slice ONE
+    engine batch, until the queue is dry.  Energies / iterations are zero-padded over all terms for the one all-reduce
+    that follows (as run_mbe)."""
+    from .methods import run_hip_scf_groups
+    evaluate = evaluate or (lambda groups: run_hip_scf_groups(settings, groups))
+    order = np.argsort(-np.asarray(costs, dtype=np.float64), kind="stable") if costs is not None else np.arange(len(terms))
+    energies = np.zeros(len(terms)); iters = np.zeros(len(terms), dtype=np.int64)
+    errors: List[str] = []
+    owned: List[int] = []
+    while True:
+        sl = queue.draw()
+        if sl is None:
+            break
+        idx = order[sl[0]:sl[1]]
+        groups, positions = build_fragment_groups(system, [terms[i] for i in idx])
+        recs = evaluate(groups)
+        for pos, rec in zip(positions, recs):
+            tix = idx[pos]
+            ok = rec["has_error"] == 0
+            energies[tix[ok]] = rec["e_total"][ok]
+            iters[tix[ok]] = rec["iterations"][ok]
+            for k in np.nonzero(~ok)[0]:
+                errors.append("term %s: %s" % (terms[tix[k]], bytes(rec["message"][k]).split(b"\0", 1)[0].decode(errors="replace")))
+        owned.extend(int(i) for i in idx)
+    return MbeRun(terms, energies, iters, np.asarray(owned, dtype=np.int64), errors, None)
+
+
 @dataclass
 class MbeRun:
     terms: List[Tuple[int, ...]]
@@ -235,10 +353,13 @@ def build_fragment_groups(system: FragmentedSystem, term_list: Sequence[Tuple[in
 
 def run_mbe(system: FragmentedSystem, settings: ScfSettings, level: int = 2,
             cutoffs: Optional[Dict[int, float]] = None, rank: int = 0, world: int = 1,
-            terms: Optional[List[Tuple[int, ...]]] = None, want_gradient: bool = False) -> MbeRun:
+            terms: Optional[List[Tuple[int, ...]]] = None, want_gradient: bool = False,
+            costs: Optional[Sequence[float]] = None) -> MbeRun:
+    """`costs` (one per term, e.g. term_costs(...)): the static partition is longest-processing-time-first over them
+    instead of round-robin -- for lists whose terms of one order do not cost the same."""
     from .methods import run_hip_scf_groups
     terms = terms if terms is not None else generate_mbe_term_list(system, level, cutoffs)
-    owned = partition_terms(len(terms), rank, world)
+    owned = partition_terms(len(terms), rank, world) if costs is None else partition_terms_lpt(costs, rank, world)
     groups, positions = build_fragment_groups(system, [terms[i] for i in owned])
     owned_arr = np.asarray(owned)
     energies = np.zeros(len(terms))
