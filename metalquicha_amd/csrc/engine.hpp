@@ -151,6 +151,11 @@ struct BatchView {      // plain pointers handed to kernels
     const double* pc;             // [nfrag][npc][4] = x, y, z, q
     double* U;                    // [nfrag][n*n] embedding operator -sum_g q_g/|r - R_g| + h_extra (part of H), or nullptr
     const double* Hx;             // [nfrag][n*n] the caller's h_extra matrices, or nullptr
+    // far field of the point charges (kern_int1e.hip, set by launch_int1e for large fields only): per atom the squared
+    // distance beyond which every primitive pair on that atom sees a charge through the asymptotic Boys function, and
+    // per (fragment, atom) the sums  sum_far q d^{tuv}(1/|A - C|), t + u + v <= 4, in hidx order
+    const double* pc_far_r2;      // [natoms] or nullptr
+    const double* pc_far_tab;     // [nfrag][natoms][35] or nullptr
     int slot;                     // 0/1: which pipeline slot (stream, pools, launcher scratch) this batch view lives in
     XcSpec xc;                    // ncomp == 0: no XC term
     GridDev grid;

@@ -8,8 +8,59 @@
 // Cost is O(n_pairs * n_atoms) per fragment and is paid once; the kernel is not a hot spot.
 #include "engine.hpp"
 #include "md_integrals.hpp"
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
 
 namespace mqc {
+
+// Far field of an embedding with many point charges (FMO / EE-MBE: ~1500 per fragment at 512 fragments).  For a shell
+// pair on ONE atom every primitive product sits on that atom, and a charge at distance R with p_min R^2 > 42 is in the
+// asymptotic branch of the Boys function for every primitive pair: R_tuv(p, A - C) = (1/2) sqrt(pi/p) d^{tuv}(1/|A - C|)
+// to exp(-42).  The p-independent sums over those charges are formed ONCE per (fragment, atom) by pc_far_table_kernel;
+// int1e_block then loops over the near charges only for such pairs -- it used to evaluate one Boys function per
+// (primitive pair, charge): 81 x 1530 for an oxygen s-s pair (int1e_kernel<0,0>: 388 ms per launch at 512 fragments,
+// profiles/r02_af...).  Pairs on two atoms keep the direct sum.
+constexpr int PC_FAR_LMAX = 4;                 // s, p, d pairs (f pairs keep the direct sum)
+constexpr int PC_FAR_NT = nherm(PC_FAR_LMAX);  // 35
+constexpr int PC_FAR_MIN = 64;                 // fields smaller than this are summed directly
+
+__global__ void __launch_bounds__(256) pc_far_table_kernel(BatchView bv, const double* __restrict__ far_r2, double* __restrict__ tab)
+{
+    const int a = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const TopologyDev& tp = bv.topo;
+    const double* xyz = bv.xyz + ((size_t)f * tp.natoms + a) * 3;
+    const double ax = xyz[0], ay = xyz[1], az = xyz[2], r2far = far_r2[a];
+    const double* pc = bv.pc + (size_t)f * bv.npc * 4;
+    double acc[PC_FAR_NT];
+#pragma unroll
+    for (int k = 0; k < PC_FAR_NT; ++k) acc[k] = 0.0;
+    for (int g = tid; g < bv.npc; g += 256) {
+        const double X = ax - pc[4 * g], Y = ay - pc[4 * g + 1], Z = az - pc[4 * g + 2], q = pc[4 * g + 3];
+        const double r2 = X * X + Y * Y + Z * Z;
+        if (!(r2 > r2far) || q == 0.0) continue;
+        // seeds of the Hermite recursion in the far limit: (-1)^n (2n - 1)!! / R^(2n+1)
+        const double inv = 1.0 / sqrt(r2), inv2 = inv * inv;
+        double F[PC_FAR_LMAX + 1];
+        F[0] = inv;
+#pragma unroll
+        for (int n = 1; n <= PC_FAR_LMAX; ++n) F[n] = -(2 * n - 1) * F[n - 1] * inv2;
+        double G[PC_FAR_NT];
+        HermiteLevel<PC_FAR_LMAX, 0>::run(F, X, Y, Z, G);
+#pragma unroll
+        for (int k = 0; k < PC_FAR_NT; ++k) acc[k] += q * G[k];
+    }
+    __shared__ double part[4][PC_FAR_NT];
+#pragma unroll
+    for (int k = 0; k < PC_FAR_NT; ++k) {
+        double v = acc[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((tid & 63) == 0) part[tid >> 6][k] = v;
+    }
+    __syncthreads();
+    if (tid < PC_FAR_NT) tab[((size_t)f * tp.natoms + a) * PC_FAR_NT + tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+}
 
 template <int LA, int LB>
 __device__ void int1e_block(const BatchView& bv, int f, int A, int B)
@@ -27,6 +78,9 @@ __device__ void int1e_block(const BatchView& bv, int f, int A, int B)
     for (int i = 0; i < NCA * NCB; ++i) { sc[i] = 0.0; tc[i] = 0.0; vc[i] = 0.0; uc[i] = 0.0; }
     const int npc = bv.npc;
     const double* pc = bv.pc + (size_t)f * npc * 4;
+    const bool use_far = L <= PC_FAR_LMAX && atA == atB && npc > 0 && bv.pc_far_tab != nullptr;
+    const double far_r2 = use_far ? bv.pc_far_r2[atA] : 0.0;
+    const double* far_tab = use_far ? bv.pc_far_tab + ((size_t)f * tp.natoms + atA) * PC_FAR_NT : nullptr;
     const int npa = tp.sh_nprim[A], npb = tp.sh_nprim[B];
     const double* ea = tp.exps + tp.sh_poff[A]; const double* ca = tp.coefs + tp.sh_poff[A];
     const double* eb = tp.exps + tp.sh_poff[B]; const double* cb = tp.coefs + tp.sh_poff[B];
@@ -70,6 +124,12 @@ __device__ void int1e_block(const BatchView& bv, int f, int A, int B)
                 const double* ctr = ext ? pc + 4 * (at - tp.natoms) : xyz + 3 * at;
                 const double zq = ext ? ctr[3] : tp.zeff[at];
                 if (zq == 0.0) continue;
+                if (ext && use_far) {
+                    // same-centre pair (P = A for every primitive pair): a charge beyond the atom's far radius is in the
+                    // asymptotic branch of the Boys function for ALL of them and sits in the per-atom table instead
+                    const double fx = ax - ctr[0], fy = ay - ctr[1], fz = az - ctr[2];
+                    if (fx * fx + fy * fy + fz * fz > far_r2) continue;
+                }
                 double R[nherm(L)];
                 hermite_r<L>(p, px - ctr[0], py - ctr[1], pz - ctr[2], bv.boys, R);
                 const double pref = -zq * 2.0 * M_PI * ip_ * kab;
@@ -97,6 +157,36 @@ __device__ void int1e_block(const BatchView& bv, int f, int A, int B)
                                 ++k;
                             }
                     }
+            }
+            if constexpr (L <= PC_FAR_LMAX) {
+                if (use_far) {
+                    // the far charges of this centre, all at once: R_tuv -> (1/2) sqrt(pi/p) d^{tuv}(1/|A - C|) for
+                    // p R^2 > 42 (error below exp(-42)), and the sum over the charges does not depend on p
+                    const double pref = -2.0 * M_PI * ip_ * kab * 0.886226925452758014 * sqrt(ip_);
+                    int k = 0;
+#pragma unroll
+                    for (int i0 = LA; i0 >= 0; --i0)
+#pragma unroll
+                        for (int i1 = LA - i0; i1 >= 0; --i1) {
+                            const int i2 = LA - i0 - i1;
+#pragma unroll
+                            for (int j0 = LB; j0 >= 0; --j0)
+#pragma unroll
+                                for (int j1 = LB - j0; j1 >= 0; --j1) {
+                                    const int j2 = LB - j0 - j1;
+                                    double v = 0.0;
+#pragma unroll
+                                    for (int t = 0; t <= i0 + j0; ++t)
+#pragma unroll
+                                        for (int u = 0; u <= i1 + j1; ++u)
+#pragma unroll
+                                            for (int w = 0; w <= i2 + j2; ++w)
+                                                v += ex.get(i0, j0, t) * ey.get(i1, j1, u) * ez.get(i2, j2, w) * far_tab[hidx(t, u, w)];
+                                    uc[k] += pref * v;
+                                    ++k;
+                                }
+                        }
+                }
             }
         }
     // cart -> sph (s and p carry their factor in the coefficients; l >= 2 uses the table)
@@ -281,9 +371,32 @@ void launch_dipole(const BatchView& bv, const Topology& topo, hipStream_t s, boo
 #undef DIP_CASE
 }
 
-void launch_int1e(const BatchView& bv, const Topology& topo, hipStream_t s)
+void launch_int1e(const BatchView& bv_in, const Topology& topo, hipStream_t s)
 {
     static DevicePool scratch_slot[2];
+    static DevicePool far_slot[2];
+    BatchView bv = bv_in;
+    bv.pc_far_r2 = nullptr; bv.pc_far_tab = nullptr;
+    static const bool far_on = [] { const char* e = std::getenv("MQC_HIP_PC_FAR"); return !(e && e[0] == '0'); }();
+    if (far_on && bv.npc >= PC_FAR_MIN && bv.pc) {
+        // per atom: beyond R^2 = 42 / p_min (p_min = twice the most diffuse exponent on the atom) a charge is far for
+        // every primitive pair on it
+        static std::vector<double> hr2[2];
+        std::vector<double>& r2 = hr2[bv.slot & 1];
+        r2.assign(topo.natoms, 0.0);
+        std::vector<double> amin(topo.natoms, 1.0e300);
+        for (const auto& sh : topo.shells)
+            for (int k = 0; k < sh.nprim; ++k) amin[sh.atom] = std::min(amin[sh.atom], topo.exps[sh.poff + k]);
+        for (int a = 0; a < topo.natoms; ++a) r2[a] = amin[a] < 1.0e299 ? BOYS_TMAX / (2.0 * amin[a]) : 1.0e300;
+        const size_t tab_doubles = (size_t)bv.nfrag * topo.natoms * PC_FAR_NT;
+        double* base = (double*)far_slot[bv.slot & 1].ensure(sizeof(double) * (tab_doubles + topo.natoms + 32));
+        if (base) {
+            (void)hipMemcpyAsync(base, r2.data(), sizeof(double) * topo.natoms, hipMemcpyHostToDevice, s);
+            double* tab = base + ((topo.natoms + 31) & ~31);
+            hipLaunchKernelGGL(pc_far_table_kernel, dim3(topo.natoms, bv.nfrag), dim3(256), 0, s, bv, base, tab);
+            bv.pc_far_r2 = base; bv.pc_far_tab = tab;
+        }
+    }
     // one device list with an offset per class and host buckets that outlive the asynchronous uploads: no host
     // synchronisation between the class launches (the batch view of the NEXT call reuses them only after the stream
     // has been drained by the SCF loop)

@@ -226,3 +226,34 @@ def test_embedded_gradient_is_refused():
                       point_charge_xyz=xyz[None, 3:], point_charges=np.full((1, 6), 0.1))
     rec = methods.run_hip_scf_groups(_settings(), [g], want_gradient=True, gradients_out=[])[0]
     assert rec["has_error"][0] and b"point charges" in bytes(rec["message"][0])
+
+
+@pytest.mark.parametrize("basis", ["cc-pvdz", "6-31g"])
+def test_large_point_charge_field_far_table_matches_oracle(basis):
+    """A field of 400 charges (a 512-fragment FMO run carries ~1500 per fragment): charges beyond an atom's far radius
+    (p_min R^2 > 42) enter the same-centre shell pairs through the per-atom table of sum q d^{tuv}(1/|A - C|)
+    (kern_int1e.hip, pc_far_table_kernel), the near ones and all two-centre pairs through the direct sum.  The embedding
+    operator u must equal the oracle's point-charge potential to 1e-11 per element, the energy to 1e-9 -- for a water
+    and for a water pair (s, p and d pairs on one centre and on two)."""
+    system = w3_system()
+    z = np.asarray(system.element_numbers); xyz = np.ascontiguousarray(system.coordinates.T)
+    rng = np.random.default_rng(17)
+    make = oracle_make_mol(system, basis)
+    for atoms in ([0, 1, 2], [0, 1, 2, 3, 4, 5]):
+        centre = xyz[atoms].mean(axis=0)
+        npc = 400
+        direction = rng.normal(size=(npc, 3)); direction /= np.linalg.norm(direction, axis=1)[:, None]
+        radius = np.concatenate([rng.uniform(4.0, 9.0, size=60), rng.uniform(9.0, 70.0, size=npc - 60)])     # near and far
+        pts = centre + direction * radius[:, None]
+        q = rng.uniform(-0.9, 0.9, size=npc)
+        g = FragmentGroup(z[atoms].astype(np.int32), xyz[atoms][None], np.zeros(1, dtype=np.int32),
+                          point_charge_xyz=pts[None], point_charges=q[None])
+        extras = []
+        rec = methods.run_hip_scf_groups(_settings(basis), [g], extras=("embedding_matrix",), extras_out=extras)[0]
+        assert not rec["has_error"].any(), rec["message"]
+        mol = make(atoms)
+        u = so.point_charge_potential(mol, pts, q)
+        assert np.max(np.abs(extras[0]["embedding_matrix"][0] - u)) < 1e-11
+        ref = so.run_rhf(mol, int(np.sum(z[atoms])), e_tol=1e-9, d_tol=1e-7, h_extra=u)
+        assert abs(rec["e_total"][0] - ref.energy) < 1e-9
+        assert rec["iterations"][0] == ref.iterations
