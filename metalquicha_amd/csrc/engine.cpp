@@ -488,13 +488,16 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         for (int f = 0; f < nf; ++f) std::memcpy(&job.hx[(size_t)f * topo.natoms * 3], xyz[job.start + f], sizeof(double) * topo.natoms * 3);
         HIP_CHECK_RET(hipMemcpyAsync(bv.xyz, job.hx.data(), sizeof(double) * job.hx.size(), hipMemcpyHostToDevice, s));
         if (npc > 0) {
+            // layout [charge][x, y, z, q][fragment], FRAGMENT FASTEST: the lanes of a wave are consecutive fragments, so a
+            // wave reads a charge's component as one contiguous 512-byte line -- with [fragment][charge][4] every lane
+            // streamed its own 49 KB array and a wave-load touched 64 cache lines (int1e: 40 % of a 512-fragment FMO run)
             job.hpc.resize((size_t)nf * npc * 4);
             for (int f = 0; f < nf; ++f) {
                 const mqc_hip_molecule_t* m = pcmol[job.start + f];
                 for (int g = 0; g < npc; ++g) {
-                    double* q = &job.hpc[((size_t)f * npc + g) * 4];
-                    q[0] = m->point_charge_xyz[3 * g]; q[1] = m->point_charge_xyz[3 * g + 1]; q[2] = m->point_charge_xyz[3 * g + 2];
-                    q[3] = m->point_charges[g];
+                    double* q = &job.hpc[(size_t)g * 4 * nf + f];
+                    q[0] = m->point_charge_xyz[3 * g]; q[(size_t)nf] = m->point_charge_xyz[3 * g + 1]; q[2 * (size_t)nf] = m->point_charge_xyz[3 * g + 2];
+                    q[3 * (size_t)nf] = m->point_charges[g];
                 }
             }
             HIP_CHECK_RET(hipMemcpyAsync((void*)bv.pc, job.hpc.data(), sizeof(double) * job.hpc.size(), hipMemcpyHostToDevice, s));

@@ -148,7 +148,7 @@ struct BatchView {      // plain pointers handed to kernels
     unsigned long long* eri_count;   // [1]: shell quartets the integral kernels formed (Schwarz survivors), or nullptr
     double* dip;                  // [nfrag][4]: tr(D x), tr(D y), tr(D z) about the origin, -
     int npc;                      // external point charges per fragment (0 = none)
-    const double* pc;             // [nfrag][npc][4] = x, y, z, q
+    const double* pc;             // [npc][4 = x, y, z, q][nfrag], fragment fastest (coalesced over the lanes of a wave)
     double* U;                    // [nfrag][n*n] embedding operator -sum_g q_g/|r - R_g| + h_extra (part of H), or nullptr
     const double* Hx;             // [nfrag][n*n] the caller's h_extra matrices, or nullptr
     // far field of the point charges (kern_int1e.hip, set by launch_int1e for large fields only): per atom the squared

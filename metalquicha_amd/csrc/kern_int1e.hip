@@ -25,18 +25,22 @@ constexpr int PC_FAR_LMAX = 4;                 // s, p, d pairs (f pairs keep th
 constexpr int PC_FAR_NT = nherm(PC_FAR_LMAX);  // 35
 constexpr int PC_FAR_MIN = 64;                 // fields smaller than this are summed directly
 
-__global__ void __launch_bounds__(256) pc_far_table_kernel(BatchView bv, const double* __restrict__ far_r2, double* __restrict__ tab)
+__global__ void __launch_bounds__(64) pc_far_table_kernel(BatchView bv, const double* __restrict__ far_r2, double* __restrict__ tab)
 {
-    const int a = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    // thread = fragment (the charge array is fragment-fastest: coalesced), block column = atom
+    const int a = blockIdx.y, f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= bv.nfrag) return;
     const TopologyDev& tp = bv.topo;
     const double* xyz = bv.xyz + ((size_t)f * tp.natoms + a) * 3;
     const double ax = xyz[0], ay = xyz[1], az = xyz[2], r2far = far_r2[a];
-    const double* pc = bv.pc + (size_t)f * bv.npc * 4;
+    const size_t nf = (size_t)bv.nfrag;
+    const double* pc = bv.pc + f;
     double acc[PC_FAR_NT];
 #pragma unroll
     for (int k = 0; k < PC_FAR_NT; ++k) acc[k] = 0.0;
-    for (int g = tid; g < bv.npc; g += 256) {
-        const double X = ax - pc[4 * g], Y = ay - pc[4 * g + 1], Z = az - pc[4 * g + 2], q = pc[4 * g + 3];
+    for (int g = 0; g < bv.npc; ++g) {
+        const double* c = pc + (size_t)g * 4 * nf;
+        const double X = ax - c[0], Y = ay - c[nf], Z = az - c[2 * nf], q = c[3 * nf];
         const double r2 = X * X + Y * Y + Z * Z;
         if (!(r2 > r2far) || q == 0.0) continue;
         // seeds of the Hermite recursion in the far limit: (-1)^n (2n - 1)!! / R^(2n+1)
@@ -50,16 +54,9 @@ __global__ void __launch_bounds__(256) pc_far_table_kernel(BatchView bv, const d
 #pragma unroll
         for (int k = 0; k < PC_FAR_NT; ++k) acc[k] += q * G[k];
     }
-    __shared__ double part[4][PC_FAR_NT];
+    double* out = tab + ((size_t)f * tp.natoms + a) * PC_FAR_NT;
 #pragma unroll
-    for (int k = 0; k < PC_FAR_NT; ++k) {
-        double v = acc[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if ((tid & 63) == 0) part[tid >> 6][k] = v;
-    }
-    __syncthreads();
-    if (tid < PC_FAR_NT) tab[((size_t)f * tp.natoms + a) * PC_FAR_NT + tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+    for (int k = 0; k < PC_FAR_NT; ++k) out[k] = acc[k];
 }
 
 template <int LA, int LB>
@@ -77,7 +74,8 @@ __device__ void int1e_block(const BatchView& bv, int f, int A, int B)
 #pragma unroll
     for (int i = 0; i < NCA * NCB; ++i) { sc[i] = 0.0; tc[i] = 0.0; vc[i] = 0.0; uc[i] = 0.0; }
     const int npc = bv.npc;
-    const double* pc = bv.pc + (size_t)f * npc * 4;
+    const size_t nfp = (size_t)bv.nfrag;
+    const double* pc = bv.pc + f;                 // [charge][x, y, z, q][fragment]
     const bool use_far = L <= PC_FAR_LMAX && atA == atB && npc > 0 && bv.pc_far_tab != nullptr;
     const double far_r2 = use_far ? bv.pc_far_r2[atA] : 0.0;
     const double* far_tab = use_far ? bv.pc_far_tab + ((size_t)f * tp.natoms + atA) * PC_FAR_NT : nullptr;
@@ -121,17 +119,22 @@ __device__ void int1e_block(const BatchView& bv, int f, int A, int B)
             // fragment (embedding_operator, mqc_libcint_fmo.f90:1143-1151), kept apart in uc
             for (int at = 0; at < tp.natoms + npc; ++at) {
                 const bool ext = at >= tp.natoms;
-                const double* ctr = ext ? pc + 4 * (at - tp.natoms) : xyz + 3 * at;
-                const double zq = ext ? ctr[3] : tp.zeff[at];
+                double cx, cy, cz, zq;
+                if (ext) {
+                    const double* c = pc + (size_t)(at - tp.natoms) * 4 * nfp;
+                    cx = c[0]; cy = c[nfp]; cz = c[2 * nfp]; zq = c[3 * nfp];
+                } else {
+                    cx = xyz[3 * at]; cy = xyz[3 * at + 1]; cz = xyz[3 * at + 2]; zq = tp.zeff[at];
+                }
                 if (zq == 0.0) continue;
                 if (ext && use_far) {
                     // same-centre pair (P = A for every primitive pair): a charge beyond the atom's far radius is in the
                     // asymptotic branch of the Boys function for ALL of them and sits in the per-atom table instead
-                    const double fx = ax - ctr[0], fy = ay - ctr[1], fz = az - ctr[2];
+                    const double fx = ax - cx, fy = ay - cy, fz = az - cz;
                     if (fx * fx + fy * fy + fz * fz > far_r2) continue;
                 }
                 double R[nherm(L)];
-                hermite_r<L>(p, px - ctr[0], py - ctr[1], pz - ctr[2], bv.boys, R);
+                hermite_r<L>(p, px - cx, py - cy, pz - cz, bv.boys, R);
                 const double pref = -zq * 2.0 * M_PI * ip_ * kab;
                 int k = 0;
 #pragma unroll
@@ -393,7 +396,7 @@ void launch_int1e(const BatchView& bv_in, const Topology& topo, hipStream_t s)
         if (base) {
             (void)hipMemcpyAsync(base, r2.data(), sizeof(double) * topo.natoms, hipMemcpyHostToDevice, s);
             double* tab = base + ((topo.natoms + 31) & ~31);
-            hipLaunchKernelGGL(pc_far_table_kernel, dim3(topo.natoms, bv.nfrag), dim3(256), 0, s, bv, base, tab);
+            hipLaunchKernelGGL(pc_far_table_kernel, dim3((bv.nfrag + 63) / 64, topo.natoms), dim3(64), 0, s, bv, base, tab);
             bv.pc_far_r2 = base; bv.pc_far_tab = tab;
         }
     }

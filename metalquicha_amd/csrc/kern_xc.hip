@@ -680,301 +680,11 @@ __device__ __forceinline__ void zero_group(const TopologyDev& tp, int g, double*
 }
 
 // PT points per tile; NV = ceil(n*n / 256) register accumulators per thread
-template <bool GGA, int PT, int NV>
-__global__ void __launch_bounds__(XC_NT) xc_kernel(BatchView bv, int only_active)
-{
-    extern __shared__ double lds[];
-    const int f = blockIdx.y;
-    if (only_active && bv.istate[4 * f] == ST_DONE) return;
-    const int n = bv.n, tid = threadIdx.x;
-    const TopologyDev& tp = bv.topo;
-    const GridDev& gd = bv.grid;
-    constexpr int PTP = PT + 1;                       // padded row: bank-conflict-free column walks
-    double* chi = lds;
-    double* gx = chi + (size_t)n * PTP;
-    double* gy = gx + (GGA ? (size_t)n * PTP : 0);
-    double* gz = gy + (GGA ? (size_t)n * PTP : 0);
-    double* X = gz + (GGA ? (size_t)n * PTP : 0);
-    double* A = X + (size_t)n * PTP;
-    double* pw = A + (size_t)n * PTP;                 // [PT] weight, then reused: w*vrho/2, 2 w vsigma grho_x,y,z
-    double* pvr = pw + PT;
-    double* pgx = pvr + PT;
-    double* pgy = pgx + PT;
-    double* pgz = pgy + PT;
-    double* red = pgz + PT;                           // 2 * 4 reduction slots
-
-    const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
-    const double* __restrict__ D = bv.D + (size_t)f * n * n;
-    const double* __restrict__ wts = gd.weights + (size_t)f * gd.npts;
-
-    double acc[NV];
-#pragma unroll
-    for (int k = 0; k < NV; ++k) acc[k] = 0.0;
-    double e_acc = 0.0, n_acc = 0.0;
-
-    const int ntiles = (gd.npts + PT - 1) / PT;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int g0 = tile * PT;
-        // 1. AO values for (point, shell) items, point fastest
-        for (int idx = tid; idx < tp.ngroup * PT; idx += XC_NT) {
-            const int rg = idx / PT, p = idx - rg * PT;
-            const int g = g0 + p;
-            if (g < gd.npts) {
-                const int oa = gd.pt_atom[g], it = gd.pt_tmpl[g];
-                eval_group<GGA>(tp, xyz, rg, xyz[3 * oa] + gd.tmpl_xyz[3 * it], xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1],
-                                xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2], chi, gx, gy, gz, PTP, p, bv.c2s);
-            } else {
-                zero_group<GGA>(tp, rg, chi, gx, gy, gz, PTP, p);
-            }
-        }
-        if (tid < PT) pw[tid] = (g0 + tid < gd.npts) ? wts[g0 + tid] : 0.0;
-        __syncthreads();
-        // 2. X = D chi
-        for (int idx = tid; idx < n * PT; idx += XC_NT) {
-            const int mu = idx / PT, p = idx - mu * PT;
-            const double* __restrict__ drow = D + (size_t)mu * n;
-            double s = 0.0;
-            for (int nu = 0; nu < n; ++nu) s += drow[nu] * chi[nu * PTP + p];
-            X[mu * PTP + p] = s;
-        }
-        __syncthreads();
-        // 3. density, functional, per-point coefficients
-        if (tid < PT) {
-            const int p = tid;
-            double rho = 0.0, rx = 0.0, ry = 0.0, rz = 0.0;
-            for (int mu = 0; mu < n; ++mu) {
-                const double x = X[mu * PTP + p];
-                rho += x * chi[mu * PTP + p];
-                if (GGA) { rx += x * gx[mu * PTP + p]; ry += x * gy[mu * PTP + p]; rz += x * gz[mu * PTP + p]; }
-            }
-            rx *= 2.0; ry *= 2.0; rz *= 2.0;
-            const double sigma = GGA ? rx * rx + ry * ry + rz * rz : 0.0;
-            double fx, vr, vs;
-            eval_functional(bv.xc, rho, sigma, fx, vr, vs);
-            const double w = pw[p];
-            e_acc += w * fx;
-            n_acc += w * rho;
-            pvr[p] = 0.5 * w * vr;
-            if (GGA) { const double t = 2.0 * w * vs; pgx[p] = t * rx; pgy[p] = t * ry; pgz[p] = t * rz; }
-        }
-        __syncthreads();
-        // 4. a[mu][p]
-        for (int idx = tid; idx < n * PT; idx += XC_NT) {
-            const int mu = idx / PT, p = idx - mu * PT;
-            double a = pvr[p] * chi[mu * PTP + p];
-            if (GGA) a += pgx[p] * gx[mu * PTP + p] + pgy[p] * gy[mu * PTP + p] + pgz[p] * gz[mu * PTP + p];
-            A[mu * PTP + p] = a;
-        }
-        __syncthreads();
-        // 5. A[mu][nu] += sum_p a[mu][p] chi[nu][p]   (registers)
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const int idx = tid + XC_NT * k;
-            if (idx < n * n) {
-                const int mu = idx / n, nu = idx - mu * n;
-                const double* __restrict__ ar = A + mu * PTP;
-                const double* __restrict__ cr = chi + nu * PTP;
-                double s = 0.0;
-#pragma unroll 8
-                for (int p = 0; p < PT; ++p) s += ar[p] * cr[p];
-                acc[k] += s;
-            }
-        }
-        __syncthreads();
-    }
-    // flush
-    double* Vx = bv.Vxc + (size_t)f * n * n;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        const int idx = tid + XC_NT * k;
-        if (idx < n * n && acc[k] != 0.0) atomicAdd(&Vx[idx], acc[k]);
-    }
-    // E_xc and N_e: lanes < PT of wave 0 hold the partial sums
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { e_acc += __shfl_down(e_acc, off, 64); n_acc += __shfl_down(n_acc, off, 64); }
-    if (tid == 0) {
-        atomicAdd(&bv.scal[(size_t)f * 8 + 5], e_acc);
-        atomicAdd(&bv.scal[(size_t)f * 8 + 6], n_acc);
-    }
-    (void)red;
-}
-
-// ------------------------------------------------------------------ MFMA path (n <= 48)
-// The two GEMM-shaped contractions of the quadrature, X = D chi and A += a chi^T, on the FP64 matrix
-// cores (v_mfma_f64_16x16x4_f64).  Each WAVE is independent: it owns 16 grid points at a time, keeps
-// the whole density matrix as MFMA A-fragments in registers (NT16 * NP/4 doubles per lane, loaded
-// once) and the n x n result tiles as MFMA accumulators across all its points.  Operand layout
-// (guide section 3): A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
-// C/D[row = (lane>>4) + 4*reg][col = lane&15].  LDS rows are 17 doubles so both the row-wise
-// (B of X = D chi) and the column-wise (A and B of a chi^T) fragment reads are conflict-free.
-typedef double v4f64 __attribute__((ext_vector_type(4)));
-constexpr int XM_RS = 17;      // LDS row stride in doubles (16 points + 1 pad)
-constexpr int XM_NW = 2;       // waves per workgroup
-
-template <bool GGA, int NT16>
-__global__ void __launch_bounds__(64 * XM_NW) xc_mfma_kernel(BatchView bv, int only_active)
-{
-    extern __shared__ double lds[];
-    const int f = blockIdx.y;
-    if (only_active && bv.istate[4 * f] == ST_DONE) return;
-    constexpr int NP = 16 * NT16, KS = NP / 4, NARR = GGA ? 4 : 1;
-    const int n = bv.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lo = lane & 15, hi = lane >> 4;
-    const TopologyDev& tp = bv.topo;
-    const GridDev& gd = bv.grid;
-    double* chi = lds + (size_t)wave * NARR * NP * XM_RS;
-    double* gx = chi + (GGA ? NP * XM_RS : 0);
-    double* gy = gx + (GGA ? NP * XM_RS : 0);
-    double* gz = gy + (GGA ? NP * XM_RS : 0);
-    const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
-    const double* __restrict__ D = bv.D + (size_t)f * n * n;
-    const double* __restrict__ wts = gd.weights + (size_t)f * gd.npts;
-
-    // zero the padding rows once; real rows are rewritten for every point group
-    for (int idx = lane; idx < NARR * NP * XM_RS; idx += 64) chi[idx] = 0.0;
-
-    // density matrix as A-fragments: dfrag[mt][ks] = D[16 mt + lo][4 ks + hi]
-    double dfrag[NT16][KS];
-#pragma unroll
-    for (int mt = 0; mt < NT16; ++mt)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int mu = 16 * mt + lo, nu = 4 * ks + hi;
-            dfrag[mt][ks] = (mu < n && nu < n) ? D[mu * n + nu] : 0.0;
-        }
-    v4f64 vacc[NT16][NT16];
-#pragma unroll
-    for (int a = 0; a < NT16; ++a)
-#pragma unroll
-        for (int b = 0; b < NT16; ++b) vacc[a][b] = (v4f64){0.0, 0.0, 0.0, 0.0};
-    double e_acc = 0.0, n_acc = 0.0;
-
-    const int ngroups = (gd.npts + 15) / 16;
-    for (int grp = blockIdx.x * XM_NW + wave; grp < ngroups; grp += gridDim.x * XM_NW) {
-        const int g0 = grp * 16;
-        // 1. AO values for (shell, point) items of this wave's 16 points
-        for (int idx = lane; idx < tp.ngroup * 16; idx += 64) {
-            const int rg = idx >> 4, p = idx & 15;
-            const int g = g0 + p;
-            if (g < gd.npts) {
-                const int oa = gd.pt_atom[g], it = gd.pt_tmpl[g];
-                eval_group<GGA>(tp, xyz, rg, xyz[3 * oa] + gd.tmpl_xyz[3 * it], xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1],
-                                xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2], chi, gx, gy, gz, XM_RS, p, bv.c2s);
-            } else {
-                zero_group<GGA>(tp, rg, chi, gx, gy, gz, XM_RS, p);
-            }
-        }
-        const double w = (g0 + lo < gd.npts) ? wts[g0 + lo] : 0.0;
-        // (DS operations of one wave execute in order; the fence keeps the compiler from reordering)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // 2. X = D chi on the matrix cores
-        v4f64 xacc[NT16];
-#pragma unroll
-        for (int mt = 0; mt < NT16; ++mt) xacc[mt] = (v4f64){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const double b = chi[(4 * ks + hi) * XM_RS + lo];
-#pragma unroll
-            for (int mt = 0; mt < NT16; ++mt) xacc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(dfrag[mt][ks], b, xacc[mt], 0, 0, 0);
-        }
-        // 3. density at this lane's point (p = lo): partial over the rows this lane holds, then across hi
-        double rho = 0.0, rx = 0.0, ry = 0.0, rz = 0.0;
-#pragma unroll
-        for (int mt = 0; mt < NT16; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int mu = 16 * mt + hi + 4 * r;
-                const double x = xacc[mt][r];
-                rho += x * chi[mu * XM_RS + lo];
-                if (GGA) { rx += x * gx[mu * XM_RS + lo]; ry += x * gy[mu * XM_RS + lo]; rz += x * gz[mu * XM_RS + lo]; }
-            }
-        rho += __shfl_xor(rho, 16, 64); rho += __shfl_xor(rho, 32, 64);
-        if (GGA) {
-            rx += __shfl_xor(rx, 16, 64); rx += __shfl_xor(rx, 32, 64);
-            ry += __shfl_xor(ry, 16, 64); ry += __shfl_xor(ry, 32, 64);
-            rz += __shfl_xor(rz, 16, 64); rz += __shfl_xor(rz, 32, 64);
-            rx *= 2.0; ry *= 2.0; rz *= 2.0;
-        }
-        const double sigma = GGA ? rx * rx + ry * ry + rz * rz : 0.0;
-        double fx, vr, vs;
-        eval_functional(bv.xc, rho, sigma, fx, vr, vs);
-        if (hi == 0) { e_acc += w * fx; n_acc += w * rho; }
-        const double pvr = 0.5 * w * vr;
-        const double t2 = 2.0 * w * vs;
-        const double pgx = t2 * rx, pgy = t2 * ry, pgz = t2 * rz;
-        // 4. a[mu][p], written over gx (LDA: into a register-free spot is not needed, a = pvr chi on the fly)
-        double* arow = GGA ? gx : chi;
-        if (GGA) {
-#pragma unroll
-            for (int mt = 0; mt < NT16; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int o = (16 * mt + hi + 4 * r) * XM_RS + lo;
-                    gx[o] = pvr * chi[o] + pgx * gx[o] + pgy * gy[o] + pgz * gz[o];
-                }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-        // 5. A += a chi^T on the matrix cores: k runs over the 16 points in 4 steps
-        //    (LDA: a[mu][p] = pvr[p] chi[mu][p]; the point factor is applied to the A fragment)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            double af[NT16], bf[NT16];
-            const double pf = GGA ? 1.0 : __shfl(pvr, 4 * ks + hi, 64);    // lane (4ks+hi) has lo = that point
-#pragma unroll
-            for (int t = 0; t < NT16; ++t) {
-                af[t] = arow[(16 * t + lo) * XM_RS + 4 * ks + hi] * pf;
-                bf[t] = chi[(16 * t + lo) * XM_RS + 4 * ks + hi];
-            }
-#pragma unroll
-            for (int mt = 0; mt < NT16; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT16; ++nt) vacc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mt], bf[nt], vacc[mt][nt], 0, 0, 0);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    // flush: lane holds A[mu = 16 mt + hi + 4 r][nu = 16 nt + lo]
-    double* Vx = bv.Vxc + (size_t)f * n * n;
-#pragma unroll
-    for (int mt = 0; mt < NT16; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT16; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int mu = 16 * mt + hi + 4 * r, nu = 16 * nt + lo;
-                const double v = vacc[mt][nt][r];
-                if (mu < n && nu < n && v != 0.0) atomicAdd(&Vx[mu * n + nu], v);
-            }
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) { e_acc += __shfl_down(e_acc, off, 64); n_acc += __shfl_down(n_acc, off, 64); }
-    if (lane == 0) {
-        atomicAdd(&bv.scal[(size_t)f * 8 + 5], e_acc);
-        atomicAdd(&bv.scal[(size_t)f * 8 + 6], n_acc);
-    }
-}
-
-template <bool GGA, int NT16>
-static void xc_mfma_launch(const BatchView& bv, int oa, hipStream_t s)
-{
-    const size_t lds = sizeof(double) * (size_t)XM_NW * (GGA ? 4 : 1) * 16 * NT16 * XM_RS;
-    auto kern = xc_mfma_kernel<GGA, NT16>;
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int ngroups = (bv.grid.npts + 15) / 16;
-    int gx = (16384 + bv.nfrag - 1) / bv.nfrag;
-    const int maxx = (ngroups + XM_NW - 1) / XM_NW;
-    if (gx > maxx) gx = maxx;
-    if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(kern, dim3(gx, bv.nfrag), dim3(64 * XM_NW), lds, s, bv, oa);
-}
+typedef double v4f64 __attribute__((ext_vector_type(4)));      // accumulator / result registers of v_mfma_f64_16x16x4
 
 // ------------------------------------------------------------------ tiled workgroup kernel, any n (round 2)
-// The wave-private kernel above keeps the whole density matrix and all n x n accumulator tiles in ONE wave's
-// registers: 400 registers, one wave per SIMD, every LDS / scalar / transcendental latency exposed, the functional
-// evaluated by 64 lanes for 16 points, and nothing above n = 48.  Here a WORKGROUP of XV_NW waves owns a tile of PT
+// (The round-1 kernels -- a wave-private MFMA kernel that kept the whole density matrix and all accumulator tiles in one
+// wave's 400 registers, and a VALU kernel above n = 48 -- were removed in round 3.)  Here a WORKGROUP of XV_NW waves owns a tile of PT
 // points: the AO slab [function][point] is shared in LDS, and the two GEMM-shaped contractions are cut into
 // 16 x 16 MFMA jobs dealt round-robin to the waves --
 //     X = D chi      jobs (row tile, point tile): D as A-fragments straight from global memory (one fragment's D is
@@ -2173,28 +1883,6 @@ __global__ void xc_reset_kernel(BatchView bv)
 }
 
 template <bool GGA, int PT, int NV>
-static void xc_launch(const BatchView& bv, int oa, hipStream_t s)
-{
-    const int n = bv.n;
-    const size_t lds = sizeof(double) * ((size_t)(GGA ? 6 : 3) * n * (PT + 1) + 5 * PT + 16);
-    auto kern = xc_kernel<GGA, PT, NV>;
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int ntiles = (bv.grid.npts + PT - 1) / PT;
-    int gx = (8192 + bv.nfrag - 1) / bv.nfrag;       // a few workgroups per CU overall; many tiles per workgroup
-    if (gx > ntiles) gx = ntiles;
-    if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(kern, dim3(gx, bv.nfrag), dim3(XC_NT), lds, s, bv, oa);
-}
-
-// ------------------------------------------------------------------ unrestricted Kohn-Sham
-// xc_add_potential_uks (mqc_libcint_xc.F90:929-1119): one AO evaluation per tile, the two spin densities from
-// D_a = C_a C_a^T and D_b (not doubled), the polarised functional, and per spin
-//     V_s = A_s + A_s^T,  A_s = (w (v_rho_s / 2 chi + (2 v_ss grad rho_s + v_ab grad rho_s') . grad chi))^T chi.
-// One launch per spin (flag bit 1 = beta): the densities and the functional are formed in both, the n x n update of
-// ONE spin accumulates in registers -- two accumulator sets would not fit for n ~ 100.  E_xc and N_e come from the
-// alpha launch.  V_b lives behind V_a in bv.Vxc ([2][nfrag][n*n]).  VALU contractions: a parity-first kernel; the
-// restricted path is the tuned one.
-template <bool GGA, int PT, int NV>
 __global__ void __launch_bounds__(XC_NT) xc_uks_kernel(BatchView bv, int flags)
 {
     extern __shared__ double lds[];
@@ -2351,11 +2039,9 @@ void launch_xc(const BatchView& bv, bool only_active, hipStream_t s)
         return true;
     }();
     (void)probed;
-    // MQC_HIP_XC_V1=1: the round-1 kernels (wave-private MFMA kernel for n <= 48, VALU kernel above), kept for A/B runs
-    static const bool v1 = [] { const char* e = std::getenv("MQC_HIP_XC_V1"); return e && e[0] == '1'; }();
-    if (!v1 && (gga ? xc_split_dispatch<true>(bv, oa, s) : xc_split_dispatch<false>(bv, oa, s))) return;
-    if (!v1 && (gga ? xc_pipe_dispatch<true>(bv, oa, s) : xc_pipe_dispatch<false>(bv, oa, s))) return;
-    if (!v1 && (gga ? xc_tile_dispatch<true>(bv, oa, s) : xc_tile_dispatch<false>(bv, oa, s))) {
+    if (gga ? xc_split_dispatch<true>(bv, oa, s) : xc_split_dispatch<false>(bv, oa, s)) return;
+    if (gga ? xc_pipe_dispatch<true>(bv, oa, s) : xc_pipe_dispatch<false>(bv, oa, s)) return;
+    if (gga ? xc_tile_dispatch<true>(bv, oa, s) : xc_tile_dispatch<false>(bv, oa, s)) {
 #if XC_STAMPS
         (void)hipStreamSynchronize(s);
         unsigned long long h[16];
@@ -2365,23 +2051,8 @@ void launch_xc(const BatchView& bv, bool only_active, hipStream_t s)
 #endif
         return;
     }
-    if (n <= 48) {
-        // fragment sizes of an MBE run: both GEMMs on the FP64 matrix cores
-        if (n <= 32) { if (gga) xc_mfma_launch<true, 2>(bv, oa, s); else xc_mfma_launch<false, 2>(bv, oa, s); }
-        else { if (gga) xc_mfma_launch<true, 3>(bv, oa, s); else xc_mfma_launch<false, 3>(bv, oa, s); }
-        return;
-    }
-    const int nv = (n * n + XC_NT - 1) / XC_NT;
-    // LDS: (6 or 3) * n * (PT+1) doubles: n = 48 GGA PT = 32 -> 76 KB (two workgroups per CU)
-    if (nv <= 10) {
-        if (gga) xc_launch<true, 32, 10>(bv, oa, s); else xc_launch<false, 32, 10>(bv, oa, s);
-    } else if (nv <= 29) {
-        if (gga) xc_launch<true, 16, 29>(bv, oa, s); else xc_launch<false, 32, 29>(bv, oa, s);
-    } else if (nv <= 54) {
-        if (gga) xc_launch<true, 16, 54>(bv, oa, s); else xc_launch<false, 16, 54>(bv, oa, s);
-    } else {
-        if (gga) xc_launch<true, 16, 77>(bv, oa, s); else xc_launch<false, 16, 77>(bv, oa, s);
-    }
+    // not reached: validate_options refuses fragments above n_ao = 256, the tile kernel covers everything below
+    std::fprintf(stderr, "mqc_hip: no quadrature kernel for n = %d\n", n);
 }
 
 
