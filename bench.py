@@ -306,6 +306,9 @@ def main():
                                 "xc_frac_of_fp64_peak": (st2.xc_flops / st2.xc_kernel_seconds / 1e12 / FP64_PEAK_TFLOPS) if st2.xc_kernel_seconds > 0 else None,
                                 "jk_kernel_seconds": st2.fock_kernel_seconds,
                                 "df_algorithmic_gbs": (st2.df_bytes / st2.fock_kernel_seconds / 1e9) if (kw.get("density_fitting") and st2.fock_kernel_seconds > 0) else None,
+                                # the bytes the J/K kernel really reads: the fitted tensor is stored packed [naux][npair], read once
+                                "df_stored_tensor_gbs": (st2.fock_bytes / st2.fock_kernel_seconds / 1e9) if (kw.get("density_fitting") and st2.fock_kernel_seconds > 0) else None,
+                                "df_stored_tensor_frac_of_hbm_peak": (st2.fock_bytes / st2.fock_kernel_seconds / 1e9 / HBM_PEAK_GBS) if (kw.get("density_fitting") and st2.fock_kernel_seconds > 0) else None,
                                 "df_algorithmic_tflops": (st2.df_flops / st2.fock_kernel_seconds / 1e12) if (kw.get("density_fitting") and st2.fock_kernel_seconds > 0) else None,
                                 "integral_stage_seconds": st2.eri_kernel_seconds, "scf_step_kernel_seconds": st2.scf_step_seconds}
         if rank == 0:
@@ -374,8 +377,8 @@ def main():
         big_s, big_b, big_n = st.fock_big_seconds, st.fock_big_bytes, int(st.fock_big_launches)
         if big_n == 0:       # small workloads (--side 2): all launches
             big_s, big_b, big_n = st.fock_kernel_seconds, st.fock_bytes, int(st.fock_launches)
-        jk_name = "df_j_kernel+df_k_kernel" if args.df else "jk_incore_kernel"
-        jk_bytes = st.df_bytes if args.df else big_b
+        jk_name = "df_jk_mfma_kernel" if args.df else "jk_incore_kernel"
+        jk_bytes = st.fock_bytes if args.df else big_b      # --df: the packed fitted tensor the kernel really reads (8 npair A per fragment-iteration)
         jk_secs = st.fock_kernel_seconds if args.df else big_s
         jk_launches = int(st.fock_launches) if args.df else big_n
         stages = {

@@ -667,7 +667,9 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
                 sx->stats.df_bytes += (double)remaining * 8.0 * (double)naux * (double)n * (double)n * block_len;
                 sx->stats.df_flops += (double)remaining * 4.0 * (double)naux * (double)n * (double)n * (1.0 + (xc.exx != 0.0 ? (double)nocc : 0.0)) * block_len;
             }
-            const double launch_bytes = use_df ? (double)remaining * 2.0 * (double)naux * (double)np * 8.0
+            // density fitting: the J/K kernel reads the fitted tensor once, and it is stored packed [naux][npair] -- about
+            // half of SURVEY 8d's 8 n^2 A (df_bytes keeps that figure; fock_bytes is what the kernel really streams)
+            const double launch_bytes = use_df ? (double)remaining * (double)naux * (double)np * 8.0
                                                : (double)remaining * (double)np * (double)np * 8.0 * (uhf ? 2.0 : 1.0);
             sx->stats.fock_kernel_seconds += ms * 1e-3 * block_len;
             sx->stats.fock_bytes += launch_bytes * block_len;

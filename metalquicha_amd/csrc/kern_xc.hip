@@ -1480,6 +1480,13 @@ static bool xc_pipe_dispatch(const BatchView& bv, int oa, hipStream_t s)
 // single-wave phase, and the functional runs at full width.  Price: the slab's angular part is formed twice and the
 // radial cache is read twice.  Same arithmetic as the tile kernel (mqc_libcint_xc.F90:796-927).
 constexpr int XS_PT = 32, XS_NT = 256, XS_SI = 4;      // tile points, threads, slab items per thread prefetched
+// row stride of the potential kernel's two LDS arrays.  33: the MFMA operand reads (row <- lane & 15, point <- lane >> 4)
+// of lanes (row, point) and (row + 1, point - 1) share a bank (SQ_LDS_BANK_CONFLICT = 29 % of the LDS cycles); 34 =
+// 2 (mod 32) is conflict-free for them -- and measured no faster on one box (805 / 807 against 795 / 796 ms per B3LYP
+// evaluation, -DXS_RS3=34): the kernel is not bound by the LDS array
+#ifndef XS_RS3
+#define XS_RS3 33
+#endif
 
 // value and a = c0 chi + c . grad chi of one shell at one point (l <= 2), from its radial value and derivative factor
 template <bool GGA>
@@ -1707,7 +1714,7 @@ __global__ void __launch_bounds__(XS_NT, NTC >= 4 ? 2 : 3) xc_potential_kernel(B
     extern __shared__ double lds[];
     const int f = blockIdx.y;
     if ((only_active & 1) && bv.istate[4 * f] == ST_DONE) return;
-    constexpr int PT = XS_PT, RS = PT + 1, NP = 16 * NTC, SL = 2 * NP * RS;
+    constexpr int PT = XS_PT, RS = XS_RS3, NP = 16 * NTC, SL = 2 * NP * RS;
     constexpr int NU = 2 * NTC * NTC, JU = (NU + 3) / 4;         // (output tile, half of the points) units, units per wave
     const int n = bv.n, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lo = lane & 15, hi = lane >> 4;
@@ -1839,7 +1846,7 @@ static bool xc_split_launch(const BatchView& bv, int oa, hipStream_t s)
     constexpr int PT = XS_PT;
     const size_t misc = 6 * PT + (((size_t)3 * bv.topo.natoms + 1) & ~(size_t)1) + ((size_t)bv.topo.nshell + 1) / 2;
     const size_t lds1 = sizeof(double) * ((size_t)(GGA ? 4 : 1) * 16 * NTC * (PT + 1) + 4 * PT + misc);
-    const size_t lds3 = sizeof(double) * ((size_t)2 * 16 * NTC * (PT + 1) + 8 * PT + misc);
+    const size_t lds3 = sizeof(double) * ((size_t)2 * 16 * NTC * XS_RS3 + 8 * PT + misc);
     if (lds1 > (size_t)160 * 1024 - 256 || lds3 > (size_t)160 * 1024 - 256) return false;
     auto k1 = xc_density_kernel<GGA, NTC>;
     auto k3 = xc_potential_kernel<GGA, NTC>;

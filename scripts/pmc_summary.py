@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Reduces separate rocprofv3 --pmc passes (CSV output) of bench.py into profiles/r02_pmc_summary.json and a per-kernel
-CSV per pass.  One pass per counter group, as MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE cannot share a
+"""Reduces separate rocprofv3 --pmc passes (CSV output) of bench.py into profiles/<round>_pmc_summary.json and a
+per-kernel CSV per pass (MQC_PROFILE_ROUND=r03 by default).  One pass per counter group, as MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE cannot share a
 pass; never together with trace domains).
 
     python scripts/pmc_summary.py <tag>=<dir> [...]       tags: fetch write sq mfma_b3lyp ...
@@ -16,6 +16,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROUND = os.environ.get("MQC_PROFILE_ROUND", "r03")
 
 
 def read_pass(directory):
@@ -54,7 +55,7 @@ def main():
         table, launches = read_pass(directory)
         counters = sorted({c for v in table.values() for c in v})
         rows = sorted(table.items(), key=lambda kv: -sum(kv[1].values()))
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_%s.csv" % tag), "w", newline="") as f:
+        with open(os.path.join(ROOT, "profiles", "%s_pmc_%s.csv" % (ROUND, tag)), "w", newline="") as f:
             w = csv.writer(f)
             w.writerow(["Kernel", "Launches"] + counters)
             for k, v in rows:
@@ -89,6 +90,21 @@ def main():
         tot_f = sum(v.get("FETCH_SIZE", 0.0) for k, v in p["fetch"]["kernels"].items() if k.startswith(("eri_", "schwarz_")) or "fillBuffer" in k)
         tot_w = sum(v.get("WRITE_SIZE", 0.0) for k, v in p["write"]["kernels"].items() if k.startswith(("eri_", "schwarz_")) or "fillBuffer" in k)
         out["eri_stage_hbm_bytes_total"] = 2.0 * tot_f * 1024.0 + tot_w * 1024.0
+    # density-fitted J/K: HBM bytes per launch of df_jk_mfma_kernel from its own FETCH_SIZE / WRITE_SIZE passes of bench.py --df
+    if "fetch_df" in p and "write_df" in p:
+        def pick_df(tag, counter):
+            best = (0.0, 0, 0.0)
+            for k, v in p[tag]["kernels"].items():
+                if k.startswith("df_jk_mfma_kernel") and v.get(counter, 0.0) > best[0]:
+                    best = (v.get(counter, 0.0), v["launches"], v.get("seconds_in_this_pass", 0.0))
+            return best
+        fk, nf, sec = pick_df("fetch_df", "FETCH_SIZE")
+        wk, nw, _ = pick_df("write_df", "WRITE_SIZE")
+        if nf:
+            out["df_jk_hbm_bytes_per_launch"] = (2.0 * fk * 1024.0) / nf + (wk * 1024.0) / max(nw, 1)
+            out["df_jk_launches_in_pass"] = nf
+            if sec > 0:
+                out["df_jk_hbm_gbs_in_pass"] = (2.0 * fk * 1024.0 + wk * 1024.0 * nf / max(nw, 1)) / sec / 1e9
     if "sq" in p:
         fl = 0.0
         for k, v in p["sq"]["kernels"].items():
@@ -97,7 +113,7 @@ def main():
         out["eri_fp64_flop_total"] = fl
         out["eri_fp64_evaluations_in_pass"] = 2          # bench.py --steps 1 --warmup 1: the cold evaluation + one timed step
         out["eri_fp64_note"] = "64 lanes x (2 FMA + ADD + MUL) wave-instructions of the eri_* / schwarz_* kernels; upper bound (inactive lanes counted)"
-    with open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json"), "w") as f:
+    with open(os.path.join(ROOT, "profiles", "%s_pmc_summary.json" % ROUND), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != "passes"}, indent=1))
 
