@@ -726,6 +726,35 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         HIP_CHECK_RET(hipMemcpyAsync(scal.data(), bv.scal, sizeof(double) * scal.size(), hipMemcpyDeviceToHost, s));
         HIP_CHECK_RET(hipMemcpyAsync(eps.data(), bv.eps, sizeof(double) * eps.size(), hipMemcpyDeviceToHost, s));
         HIP_CHECK_RET(hipMemcpyAsync(ist.data(), bv.istate, sizeof(int) * ist.size(), hipMemcpyDeviceToHost, s));
+        // matrices the callers asked for (total density, embedding operator, overlap): the whole chunk in one copy each
+        std::vector<double> allD, allU, allS;
+        {
+            bool want_d = embedded, want_s = false;
+            for (int f = 0; f < nf; ++f) {
+                const mqc_hip_scf_result_t* r = results[job.start + f];
+                if (r->mulliken_charges) { want_d = true; want_s = true; }
+                if (r->density) want_d = true;
+            }
+            const size_t tot = (size_t)nf * n * n;
+            if (want_d) {
+                allD.resize(tot);
+                HIP_CHECK_RET(hipMemcpyAsync(allD.data(), bv.D, sizeof(double) * tot, hipMemcpyDeviceToHost, s));
+            }
+            if (embedded) {
+                allU.resize(tot);
+                HIP_CHECK_RET(hipMemcpyAsync(allU.data(), bv.U, sizeof(double) * tot, hipMemcpyDeviceToHost, s));
+            }
+            if (want_s) {
+                allS.resize(tot);
+                HIP_CHECK_RET(hipMemcpyAsync(allS.data(), bv.S, sizeof(double) * tot, hipMemcpyDeviceToHost, s));
+            }
+            if (want_d && uhf) {
+                std::vector<double> db(tot);
+                HIP_CHECK_RET(hipMemcpyAsync(db.data(), bv.Db, sizeof(double) * tot, hipMemcpyDeviceToHost, s));
+                HIP_CHECK_RET(hipStreamSynchronize(s));
+                for (size_t k = 0; k < tot; ++k) allD[k] += db[k];          // total density = alpha + beta
+            }
+        }
         HIP_CHECK_RET(hipStreamSynchronize(s));
         sx->stats.eri_survivors += (int64_t)formed;
         for (int f = 0; f < nf; ++f) {
@@ -806,24 +835,20 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
             if (r->orbital_energies) std::memcpy(r->orbital_energies, &eps[(size_t)f * n], sizeof(double) * nmo);
             if (embedded || r->mulliken_charges) {
                 // what the embedded callers read besides the energy: tr(D u), u itself, Mulliken populations
-                // (inner_scf / fragment_charges, mqc_libcint_fmo.f90:1992-2021) -- n^2 host work on matrices copied back
+                // (inner_scf / fragment_charges, mqc_libcint_fmo.f90:1992-2021) -- n^2 host work on the matrices of the
+                // whole chunk, copied back ONCE above (one synchronous copy per matrix and fragment cost seconds of
+                // a 130 000-pair batch)
                 const size_t nn = (size_t)n * n;
-                std::vector<double> hd(nn), hm(nn);
-                HIP_CHECK_RET(hipMemcpyAsync(hd.data(), bv.D + (size_t)f * nn, sizeof(double) * nn, hipMemcpyDeviceToHost, s));
-                HIP_CHECK_RET(hipStreamSynchronize(s));
-                if (uhf) {
-                    HIP_CHECK_RET(hipMemcpy(hm.data(), bv.Db + (size_t)f * nn, sizeof(double) * nn, hipMemcpyDeviceToHost));
-                    for (size_t k = 0; k < nn; ++k) hd[k] += hm[k];
-                }
+                const double* hd = allD.data() + (size_t)f * nn;
                 if (embedded) {
-                    HIP_CHECK_RET(hipMemcpy(hm.data(), bv.U + (size_t)f * nn, sizeof(double) * nn, hipMemcpyDeviceToHost));
+                    const double* hu = allU.data() + (size_t)f * nn;
                     double e = 0.0;
-                    for (size_t k = 0; k < nn; ++k) e += hd[k] * hm[k];
+                    for (size_t k = 0; k < nn; ++k) e += hd[k] * hu[k];
                     r->e_embedding = e;
-                    if (r->embedding_matrix) std::memcpy(r->embedding_matrix, hm.data(), sizeof(double) * nn);
+                    if (r->embedding_matrix) std::memcpy(r->embedding_matrix, hu, sizeof(double) * nn);
                 }
                 if (r->mulliken_charges) {
-                    HIP_CHECK_RET(hipMemcpy(hm.data(), bv.S + (size_t)f * nn, sizeof(double) * nn, hipMemcpyDeviceToHost));
+                    const double* hm = allS.data() + (size_t)f * nn;
                     for (int a = 0; a < topo.natoms; ++a) r->mulliken_charges[a] = topo.zeff[a];
                     for (size_t sh = 0; sh < topo.shells.size(); ++sh) {
                         const int a = topo.shells[sh].atom, o0 = topo.shells[sh].aoff, nf_sh = 2 * topo.shells[sh].l + 1;
@@ -835,15 +860,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
                     }
                 }
             }
-            if (r->density) {
-                HIP_CHECK_RET(hipMemcpyAsync(r->density, bv.D + (size_t)f * n * n, sizeof(double) * n * n, hipMemcpyDeviceToHost, s));
-                HIP_CHECK_RET(hipStreamSynchronize(s));
-                if (uhf) {
-                    std::vector<double> db((size_t)n * n);
-                    HIP_CHECK_RET(hipMemcpy(db.data(), bv.Db + (size_t)f * n * n, sizeof(double) * n * n, hipMemcpyDeviceToHost));
-                    for (size_t k = 0; k < db.size(); ++k) r->density[k] += db[k];
-                }
-            }
+            if (r->density) std::memcpy(r->density, allD.data() + (size_t)f * n * n, sizeof(double) * n * n);
             r->has_error = 0; r->message[0] = '\0';
             if (use_df && scal[8 * f + 7] == 1.0)
                 fill_error(r, "density fitting: the auxiliary metric (P|Q) could not be factorised or diagonalised");
