@@ -40,6 +40,22 @@ static double now_s()
     return duration<double>(steady_clock::now().time_since_epoch()).count();
 }
 
+// Scratch (private segment).  The first time a kernel with a private segment runs on a hardware queue, ROCm reserves
+// that kernel's bytes per lane x 64 lanes x every wave slot of the device (CUs x 32) FOR THAT QUEUE, and aborts the
+// process (HSA_STATUS_ERROR_OUT_OF_RESOURCES, recorded in rounds 1 and 2) when the memory is not there.  No kernel the
+// dispatchers launch carries more than SCRATCH_BOUND_PER_LANE (scripts/scratch_report.py lists them from the code
+// objects; tests/test_host_logic.py asserts the bound on every build; the classes above it -- (dd|dp), (dd|dd), the (dd|
+// Schwarz bounds -- go through the LDS kernel, which has none), so the worst case is the bound on every hardware queue
+// the process may use, and the pools' HBM budget leaves that much alone.
+constexpr size_t SCRATCH_BOUND_PER_LANE = 8192;
+static size_t scratch_reservation_bytes(const mqc_hip_context* ctx)
+{
+    int queues = 4;                                         // the runtime's default
+    if (const char* e = std::getenv("GPU_MAX_HW_QUEUES")) queues = std::max(1, std::atoi(e));
+    const size_t waves = (size_t)std::max(1, ctx->prop.multiProcessorCount) * 32;
+    return (size_t)queues * SCRATCH_BOUND_PER_LANE * 64 * waves;
+}
+
 struct TopoDevHolder {
     TopologyDev dev;
 };
@@ -410,6 +426,13 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
             + ctx->pool_main2.capacity() + ctx->pool_eri2.capacity() + ctx->pool_df2.capacity() + ctx->pool_gridw2.capacity();
     // a lane shares the card with the other lane's batch: 40 % each instead of 80 %
     size_t budget = (size_t)((lane < 0 ? 0.80 : 0.40) * (double)free_b);
+    {
+        // ... and the pools never take what the runtime's scratch reservation may need (see scratch_reservation_bytes)
+        const size_t res = scratch_reservation_bytes(ctx);
+        const size_t room = free_b > res ? free_b - res : free_b / 8;
+        const size_t cap = lane < 0 ? room : room / 2;
+        if (cap < budget) budget = cap;
+    }
     if (ctx->hbm_budget_bytes && ctx->hbm_budget_bytes < budget) budget = ctx->hbm_budget_bytes;
     // Chunking.  Small batches run as one chunk on slot 0.  Large ones are cut into >= 4 chunks that
     // alternate between the two slots (each slot may hold half of the budget).

@@ -468,3 +468,37 @@ def test_two_rank_gloo_pull_queue_runs_every_term_once(tmp_path):
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("ok") == 2
+
+
+def test_no_launched_kernel_exceeds_the_scratch_bound():
+    """ROCm reserves scratch per hardware queue for a full device of waves; the engine's HBM budget leaves
+    n_queues x SCRATCH_BOUND_PER_LANE x 64 x (CUs x 32) alone (engine.cpp: scratch_reservation_bytes).  That promise holds
+    only while no kernel the dispatchers launch carries more: read the private-segment sizes from the code objects of
+    the built library (scripts/scratch_report.py) and check them against the routing rules of kern_eri.hip
+    (class_is_general: four-centre pass classes of total angular momentum >= 7 and the (dd| Schwarz bounds go through
+    the LDS kernel and are never launched)."""
+    import re
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import scratch_report
+    if not os.path.isfile("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("no llvm-objdump here")
+    src = open(os.path.join(ROOT, "metalquicha_amd", "csrc", "engine.cpp")).read()
+    bound = int(re.search(r"SCRATCH_BOUND_PER_LANE = (\d+);", src).group(1))
+    ks = scratch_report.kernels()
+    assert len(ks) > 150
+    never_launched, worst = [], (0, "")
+    for name, private, vgpr, sgpr, lds in ks:
+        base, args = scratch_report.pretty(name)
+        routed_to_lds_kernel = (base in ("eri_kernel", "eri_pass_kernel", "eri_twin_kernel", "eri_digest_kernel") and sum(args[:4]) >= 7) \
+            or (base in ("schwarz_pass_kernel", "schwarz_kernel") and args[:2] == [2, 2])
+        if routed_to_lds_kernel:
+            never_launched.append((base, args, private))
+            continue
+        if private > worst[0]:
+            worst = (private, "%s%s" % (base, args))
+        assert private <= bound, (base, args, private)
+    assert worst[0] > 0 and any(p > bound for _, _, p in never_launched)      # the rule is what keeps the big ones out
+    # the LDS kernels that take those classes have no private segment at all
+    for name, private, *_ in ks:
+        if scratch_report.pretty(name)[0].startswith(("eri_general_kernel", "schwarz_general")):
+            assert private == 0, name
