@@ -1479,6 +1479,7 @@ static bool xc_pipe_dispatch(const BatchView& bv, int oa, hipStream_t s)
 // Each kernel needs a fraction of the registers and LDS (three to five workgroups per CU), no wave ever waits for a
 // single-wave phase, and the functional runs at full width.  Price: the slab's angular part is formed twice and the
 // radial cache is read twice.  Same arithmetic as the tile kernel (mqc_libcint_xc.F90:796-927).
+static_assert(256 % 32 == 0, "the slab maps a thread to one grid point");
 constexpr int XS_PT = 32, XS_NT = 256, XS_SI = 4;      // tile points, threads, slab items per thread prefetched
 // row stride of the potential kernel's two LDS arrays.  33: the MFMA operand reads (row <- lane & 15, point <- lane >> 4)
 // of lanes (row, point) and (row + 1, point - 1) share a bank (SQ_LDS_BANK_CONFLICT = 29 % of the LDS cycles); 34 =
@@ -1494,6 +1495,13 @@ __device__ __forceinline__ void emit_shell_a(int l, int ao, double dx, double dy
                                              double c0, double c1, double c2, double c3,
                                              double* __restrict__ chi, double* __restrict__ av, int ptp, int p)
 {
+    if (rad == 0.0 && drad == 0.0) {
+        // every primitive of the shell was below the exponent cutoff at this point (the radial cache stores exact zeros):
+        // the functions and a are zero -- written without the angular arithmetic
+        const int nf = 2 * l + 1;
+        for (int m = 0; m < nf; ++m) { chi[(ao + m) * ptp + p] = 0.0; av[(ao + m) * ptp + p] = 0.0; }
+        return;
+    }
     const double cd = GGA ? (c1 * dx + c2 * dy + c3 * dz) * drad : 0.0;        // c . r  R'/r
     if (l == 0) {
         chi[ao * ptp + p] = rad;
@@ -1603,16 +1611,18 @@ __global__ void __launch_bounds__(XS_NT, NTC >= 4 ? 2 : 3) xc_density_kernel(Bat
         // ---- slab: (shell, point) items, point fastest (lanes along the points)
         {
             const int g0 = tile * PT;
+            // XS_NT is a multiple of PT: all items of a thread sit on ONE grid point (p = tid mod PT), shells 8 apart
+            const int p0 = tid & (PT - 1);
+            const double* pp0 = pxyz + 3 * (pbuf * PT + p0);
+            const double ptx = pp0[0], pty = pp0[1], ptz = pp0[2];
 #pragma unroll
             for (int k = 0; k < XS_SI; ++k) {
-                const int idx = tid + XS_NT * k;
-                if (idx < nitem) {
-                    const int sh = idx / PT, p = idx - sh * PT;
+                const int sh = (tid >> 5) + (XS_NT / PT) * k;
+                if (sh < tp.nshell) {
                     const int sd = sdesc[sh];
                     const int ao = sd & 0xfff, l = (sd >> 12) & 0xf, at = sd >> 16;
-                    const double* pp = pxyz + 3 * (pbuf * PT + p);
-                    const double dx = pp[0] - axyz[3 * at], dy = pp[1] - axyz[3 * at + 1], dz = pp[2] - axyz[3 * at + 2];
-                    emit_shell<GGA, false>(l, ao, dx, dy, dz, rv[k], dv[k], chi, gx, gy, gz, RS, p, bv.c2s);
+                    const double dx = ptx - axyz[3 * at], dy = pty - axyz[3 * at + 1], dz = ptz - axyz[3 * at + 2];
+                    emit_shell<GGA, false>(l, ao, dx, dy, dz, rv[k], dv[k], chi, gx, gy, gz, RS, p0, bv.c2s);
                 }
             }
             const double* __restrict__ radt = radf + (size_t)tile * tp.nshell * 2 * PT;
@@ -1780,17 +1790,20 @@ __global__ void __launch_bounds__(XS_NT, NTC >= 4 ? 2 : 3) xc_potential_kernel(B
         // ---- slab: chi and a of every (shell, point)
         {
             const int g0 = tile * PT;
+            // all items of a thread sit on ONE grid point: its coordinates and coefficients are read once per tile
+            const int p0 = tid & (PT - 1);
+            const double* pp0 = pxyz + 3 * (buf * PT + p0);
+            const double ptx = pp0[0], pty = pp0[1], ptz = pp0[2];
+            const double* cp = coef + 4 * (buf * PT + p0);
+            const double c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
 #pragma unroll
             for (int k = 0; k < XS_SI; ++k) {
-                const int idx = tid + XS_NT * k;
-                if (idx < nitem) {
-                    const int sh = idx / PT, p = idx - sh * PT;
+                const int sh = (tid >> 5) + (XS_NT / PT) * k;
+                if (sh < tp.nshell) {
                     const int sd = sdesc[sh];
                     const int ao = sd & 0xfff, l = (sd >> 12) & 0xf, at = sd >> 16;
-                    const double* pp = pxyz + 3 * (buf * PT + p);
-                    const double dx = pp[0] - axyz[3 * at], dy = pp[1] - axyz[3 * at + 1], dz = pp[2] - axyz[3 * at + 2];
-                    const double* cp = coef + 4 * (buf * PT + p);
-                    emit_shell_a<GGA>(l, ao, dx, dy, dz, rv[k], dv[k], cp[0], cp[1], cp[2], cp[3], chi, av, RS, p);
+                    const double dx = ptx - axyz[3 * at], dy = pty - axyz[3 * at + 1], dz = ptz - axyz[3 * at + 2];
+                    emit_shell_a<GGA>(l, ao, dx, dy, dz, rv[k], dv[k], c0, c1, c2, c3, chi, av, RS, p0);
                 }
             }
             const double* __restrict__ radt = radf + (size_t)tile * tp.nshell * 2 * PT;

@@ -304,3 +304,63 @@ def test_finite_difference_hessian_through_one_batch():
     # the charge sum rule of the dipole derivatives: sum over atoms of d mu_k / d R_A,k' = charge * delta = 0
     assert np.max(np.abs(r.dipole_derivatives.reshape(3, 3, 3).sum(axis=1))) < 1e-4
 
+
+
+def _oracle_fragment_energy(job):
+    z, coords, nelec = job
+    import numpy as _np
+    from metalquicha_amd.methods import PhysicalFragment
+    from oracle import scf_oracle as _so
+    from tests.helpers import oracle_mol as _om
+    frag = PhysicalFragment(_np.asarray(z), _np.asarray(coords))
+    r = _so.run_rhf(_om("cc-pvdz", frag), int(nelec), 100, 1e-10, 1e-8)
+    return float(r.energy), int(r.iterations)
+
+
+def test_full_size_c3_workload_sample_matches_the_oracle():
+    """BASELINE configs[2] at FULL size -- (H2O)64, MBE-2, RHF/cc-pVDZ, 2080 SCFs in one engine call with bench.py's
+    settings (Schwarz screening at 1e-12, 1e-10 / 1e-8) -- with a sample of 12 dimers spread over the list and 4 monomers
+    against the oracle (live, eight worker processes): energies to 1e-9 (observed 1e-11), equal iteration counts; plus
+    the size-independent checks on the whole list: every fragment converged, c_dimer = 1 / c_monomer = 2 - N assembly
+    equals the bottom-up deltas, and a rigid motion of the cluster leaves the MBE-2 energy alone (1e-8)."""
+    import multiprocessing as mp
+    system = mbe.water_cluster(4)
+    terms = mbe.generate_mbe_term_list(system, 2)
+    assert len(terms) == 2080
+    st = methods.ScfSettings(basis_set="cc-pvdz", guess="gwh", energy_tol=1e-10, density_tol=1e-8, schwarz_tol=1e-12)
+    run = mbe.run_mbe(system, st, level=2, terms=terms)
+    assert not run.errors, run.errors[:3]
+    total, by_order, _ = mbe.compute_mbe(terms, run.energies)
+    coef = mbe.compute_mbe_coefficients(terms)
+    assert abs(float(np.dot(coef, run.energies)) - total) < 1e-8
+    assert -0.5 < by_order[2] < 0.0
+    dimers = [i for i, t in enumerate(terms) if len(t) == 2]
+    monos = [i for i, t in enumerate(terms) if len(t) == 1]
+    sample = dimers[::len(dimers) // 12][:12] + monos[::16][:4]
+    jobs = []
+    for i in sample:
+        frag = mbe.build_fragment(system, terms[i])
+        jobs.append((frag.element_numbers.tolist(), frag.coordinates.tolist(), int(frag.nelec)))
+    saved = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
+    for k in saved:
+        os.environ[k] = "1"
+    try:
+        with mp.get_context("spawn").Pool(8) as pool:
+            out = pool.map(_oracle_fragment_energy, jobs, chunksize=1)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    for i, (e, it) in zip(sample, out):
+        assert abs(run.energies[i] - e) < 1e-9, (terms[i], run.energies[i], e)
+        assert int(run.iterations[i]) == it, (terms[i], run.iterations[i], it)
+    # rigid motion of the whole cluster
+    rng = np.random.default_rng(4)
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    moved = mbe.FragmentedSystem(system.element_numbers, q @ system.coordinates + rng.uniform(-3, 3, size=(3, 1)), system.monomers,
+                                 system.charges, system.multiplicities)
+    run2 = mbe.run_mbe(moved, st, level=2, terms=terms)
+    assert not run2.errors
+    assert abs(mbe.compute_mbe(terms, run2.energies)[0] - total) < 1e-8

@@ -234,3 +234,27 @@ def test_functional_derivatives_by_finite_differences():
         sig = np.abs(vs) * sigma > 1e-5 * np.abs(f)          # where the sigma derivative is resolvable by differences
         assert sig.sum() > 50
         assert np.max((np.abs((fp - fm) / (2 * h * sigma) - vs) / np.abs(vs))[sig]) < 1e-4
+
+
+def test_recorded_fixtures_spot_check_against_the_live_oracle():
+    """tests/golden/oracle_fixtures.json holds OUTPUTS of this repository's oracle for the slow GPU parity cases, keyed by
+    their inputs -- a change to oracle/*.py does not change the key.  This test recomputes the cheapest recorded cases live
+    (the three B3LYP / def2-TZVP water monomers of the GMBE-2 workload test: grid, functional, f shells, SCF driver all in
+    play, 2-4 s each) and compares them with the file: an oracle that drifted shows up here, on the CPU, before the GPU
+    suite compares the engine with stale numbers."""
+    import json, os
+    from tests import helpers, workload_cases as wc
+    fixtures = json.load(open(helpers._FIXTURE_PATH))
+    system = wc.gmbe_system()
+    z = np.asarray(system.element_numbers); xyz = np.ascontiguousarray(system.coordinates.T)
+    checked = 0
+    for m in system.monomers:
+        atoms = [int(a) for a in m]
+        f = helpers.fragment_bohr(z[atoms], xyz[atoms])
+        key = helpers._fixture_key("gmbe2_b3lyp_def2tzvp", f, wc.GMBE_KEY)
+        assert key in fixtures, "fixture missing: run tests/golden/record_oracle_fixtures.py gmbe"
+        live = wc.gmbe_fragment_oracle(f)
+        assert abs(live["energy"] - fixtures[key]["energy"]) < 1e-10, (live, fixtures[key])
+        assert live["iterations"] == fixtures[key]["iterations"]
+        checked += 1
+    assert checked == 3
