@@ -466,7 +466,12 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         Job j; j.start = start; j.nf = (int)std::min<long>(chunk, ntot - start);
         jobs.push_back(std::move(j));
     }
-    const double stol = opts.schwarz_tol > 0.0 ? opts.schwarz_tol : 0.0;
+    // Schwarz screening of the in-core build pays for itself through the quartets it drops; for a handful of fragments
+    // the bounds (one thread per shell pair walking its primitive quartets: 1.6 ms for one cc-pVDZ water dimer) cost
+    // more than the screened quartets save, and the unscreened tensor needs no zero fill.  Energies move by < 1e-11 Eh
+    // either way (that is what the threshold means); MQC_HIP_SCHWARZ_MIN_FRAGMENTS=0 screens always.
+    static const int schwarz_min = [] { const char* e = std::getenv("MQC_HIP_SCHWARZ_MIN_FRAGMENTS"); return e ? std::atoi(e) : 9; }();
+    const double stol = (opts.schwarz_tol > 0.0 && ntot >= schwarz_min) ? opts.schwarz_tol : 0.0;
 
     // drains both streams before an error return hands the pools back
     auto bail = [&](int code) {
@@ -534,16 +539,17 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         sx->stats.t_setup += t1 - t0;
 
         if (!use_df && !use_direct) launch_eri_bounds(bv, topo, stol, s);     // screened build: bounds run next to the 1e stage
-        launch_int1e(bv, topo, s);
+        // The one-electron stage, the orthogonaliser and the starting guess need the geometry (S, H) only and are
+        // latency-bound (six class launches; one workgroup per fragment, Jacobi sweeps): they run on a side stream next
+        // to the compute-bound two-electron stage, which does not wait for them (0.7 ms of a single-fragment call)
+        hipStream_t so = ctx->side[sl.id & 1][2];
+        HIP_CHECK_RET(hipEventRecord(ctx->evo[sl.id & 1][0], s));             // uploads and resets above are in
+        HIP_CHECK_RET(hipStreamWaitEvent(so, ctx->evo[sl.id & 1][0], 0));
+        launch_int1e(bv, topo, so);
         // block-sharing plan and class lists of the integral stage: host work that depends on the geometry only, done
         // here while the bounds and one-electron kernels run
         if (!use_df && !use_direct) eri_plan_lists(bv, topo, s, job.hx.data());
         if ((rc = stage_check("int1e")) != MQC_HIP_OK) return rc;
-        // The orthogonaliser and the starting guess need S and H only and are latency-bound (one workgroup per
-        // fragment, Jacobi sweeps): they run on a side stream next to the compute-bound two-electron stage
-        hipStream_t so = ctx->side[sl.id & 1][2];
-        HIP_CHECK_RET(hipEventRecord(ctx->evo[sl.id & 1][0], s));
-        HIP_CHECK_RET(hipStreamWaitEvent(so, ctx->evo[sl.id & 1][0], 0));
         launch_orthogonalizer(bv, so);
         if ((rc = stage_check("orthogonalizer")) != MQC_HIP_OK) return rc;
         if (!atomic_guess) launch_guess(bv, opts.guess == MQC_HIP_GUESS_CORE ? MQC_HIP_GUESS_CORE : MQC_HIP_GUESS_GWH, so);
