@@ -626,19 +626,13 @@ __global__ void __launch_bounds__(64 * DJ_NW) df_jk_mfma_kernel(BatchView bv, in
     const double* __restrict__ Bf = bv.df_b + (size_t)f * na * (size_t)np;
     const double* __restrict__ D = bv.D + (size_t)f * n * n;
     const double* __restrict__ C = bv.C + (size_t)f * n * n;
-    // packed density, off-diagonal doubled: in LDS, or (DPG: large fragments) in the fragment's SCF workspace W, which
-    // nothing else uses while the J/K stage runs -- every workgroup of the fragment writes the same values
-    double* Dp = DPG ? bv.W + (size_t)f * 6 * n * n : lds;
-    double* row = lds + (DPG ? 0 : np);               // [np]  the current row of B
+    // (round 3: the packed density no longer sits in LDS or in the SCF workspace -- each thread keeps the elements that
+    // pair with the row elements it loads in registers, see dpk below; DPG is kept as a template parameter only so that
+    // the instantiation list of round 2 stands)
+    double* row = lds;                                // [np]  the current row of B
     double* Co = row + np;                            // [NP][OP] occupied orbitals, zero padded
     double* W = Co + (WITH_K ? (size_t)NP * OP : 0);  // [NP][WS]
 
-    for (int idx = tid; idx < np; idx += 64 * DJ_NW) {
-        int k, l;
-        df_unpack(idx, k, l);
-        const double d = D[k * n + l];
-        Dp[idx] = k == l ? d : 2.0 * d;
-    }
     if (WITH_K) {
         for (int idx = tid; idx < NP * OP; idx += 64 * DJ_NW) {
             const int r = idx / OP, i = idx - r * OP;
@@ -646,13 +640,42 @@ __global__ void __launch_bounds__(64 * DJ_NW) df_jk_mfma_kernel(BatchView bv, in
         }
         for (int idx = tid; idx < NP * WS; idx += 64 * DJ_NW) W[idx] = 0.0;
     }
-    double jacc[NLD], nxt[NLD];
+    double jacc[NLD], nxt[NLD], dpk[NLD];
 #pragma unroll
     for (int k = 0; k < NLD; ++k) jacc[k] = 0.0;
+    // this thread's packed-density elements (off-diagonal doubled): they pair with the row elements it loads, so c_R is
+    // formed from registers -- five products, a wave reduction and four numbers through LDS -- instead of every wave
+    // walking the whole row in LDS (18 steps of two LDS reads per lane and row)
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int idx = tid + 64 * DJ_NW * k;
+        dpk[k] = 0.0;
+        if (idx < np) {
+            int a, b;
+            df_unpack(idx, a, b);
+            const double d = D[a * n + b];
+            dpk[k] = a == b ? d : 2.0 * d;
+        }
+    }
+    __shared__ double cpart[2][DJ_NW];
+    int cbuf = 0;
     v4f64 kacc[JMAX];
 #pragma unroll
     for (int j = 0; j < JMAX; ++j) kacc[j] = (v4f64){0.0, 0.0, 0.0, 0.0};
     const int ntile = NT16 * (NT16 + 1) / 2;
+    // W_R = B_R C_occ gathers its A operand from the PACKED row: element (mu, la) sits at dj_pidx(mu, la).  The offsets
+    // do not depend on the row: those of the wave's first job are formed once (a job per wave covers n <= 64 with one
+    // orbital tile); further jobs compute them on the fly
+    constexpr int WOFF = 16;                        // k-steps covered by the cached offsets (NP <= 64)
+    int woff[WOFF];
+    {
+        const int job = wave, mt = job / OT, mu = 16 * mt + lo;
+#pragma unroll
+        for (int ks = 0; ks < WOFF; ++ks) {
+            const int la = 4 * ks + hi;
+            woff[ks] = (job < NT16 * OT && ks < (NP >> 2) && mu < n && la < n) ? dj_pidx(mu, la) : -1;
+        }
+    }
 
     int R = blockIdx.x;
     if (R < na) {
@@ -662,19 +685,24 @@ __global__ void __launch_bounds__(64 * DJ_NW) df_jk_mfma_kernel(BatchView bv, in
     __syncthreads();
     for (; R < na; R += gridDim.x) {
         double cur[NLD];
+        double cp = 0.0;
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) { cur[k] = nxt[k]; const int idx = tid + 64 * DJ_NW * k; if (idx < np) row[idx] = cur[k]; }
+        for (int k = 0; k < NLD; ++k) { cur[k] = nxt[k]; const int idx = tid + 64 * DJ_NW * k; if (idx < np) row[idx] = cur[k]; cp += cur[k] * dpk[k]; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cp += __shfl_xor(cp, off, 64);
+        if (lane == 0) cpart[cbuf][wave] = cp;
         const int Rn = R + gridDim.x;
         if (Rn < na) {
 #pragma unroll
             for (int k = 0; k < NLD; ++k) { const int idx = tid + 64 * DJ_NW * k; nxt[k] = idx < np ? Bf[(size_t)Rn * np + idx] : 0.0; }
         }
         __syncthreads();
-        // c_R: every wave forms the full dot product (no cross-wave exchange), then J += B_R c_R on the thread's pairs
+        // c_R = sum of the waves' partial dot products (written before the barrier above; the buffer alternates so that
+        // the next row's partials do not overwrite values a slower wave still reads), then J += B_R c_R on the thread's pairs
         double c = 0.0;
-        for (int idx = lane; idx < np; idx += 64) c += row[idx] * Dp[idx];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+        for (int w = 0; w < DJ_NW; ++w) c += cpart[cbuf][w];
+        cbuf ^= 1;
 #pragma unroll
         for (int k = 0; k < NLD; ++k) jacc[k] += cur[k] * c;
         if (WITH_K) {
@@ -683,6 +711,16 @@ __global__ void __launch_bounds__(64 * DJ_NW) df_jk_mfma_kernel(BatchView bv, in
                 const int mt = job / OT, ot = job - mt * OT;
                 const int mu = 16 * mt + lo;
                 v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+                if (job == wave && (NP >> 2) <= WOFF) {
+#pragma unroll
+                    for (int ks = 0; ks < WOFF; ++ks) {
+                        if (ks < (NP >> 2)) {
+                            const double a = woff[ks] >= 0 ? row[woff[ks]] : 0.0;
+                            const double b = Co[(4 * ks + hi) * OP + 16 * ot + lo];
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+                        }
+                    }
+                } else
                 for (int ks = 0; ks < (NP >> 2); ++ks) {
                     const int la = 4 * ks + hi;
                     const double a = (mu < n && la < n) ? row[dj_pidx(mu, la)] : 0.0;
@@ -750,7 +788,7 @@ template <int JMAX, int NLD, bool WITH_K, bool DPG>
 static void df_jk_mfma_launch(const BatchView& bv, int oa, hipStream_t s)
 {
     const int np16 = ((bv.n + 15) / 16) * 16, op = ((bv.nocc + 15) / 16) * 16;
-    const size_t lds = sizeof(double) * ((DPG ? 1 : 2) * (size_t)bv.npair + (WITH_K ? (size_t)np16 * op + (size_t)np16 * (op + 1) : 0) + 8);
+    const size_t lds = sizeof(double) * ((size_t)bv.npair + (WITH_K ? (size_t)np16 * op + (size_t)np16 * (op + 1) : 0) + 8);
     auto kern = df_jk_mfma_kernel<JMAX, NLD, WITH_K, DPG>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int gx = (3072 + bv.nfrag - 1) / bv.nfrag;
@@ -767,7 +805,7 @@ static bool df_jk_mfma_dispatch(const BatchView& bv, int oa, hipStream_t s)
     const bool k = bv.exx != 0.0;
     const int np16 = nt * 16, op = ((bv.nocc + 15) / 16) * 16;
     const size_t body = (k ? (size_t)np16 * op + (size_t)np16 * (op + 1) : 0) + 8;
-    const bool dpg = sizeof(double) * (2 * (size_t)bv.npair + body) > 64 * 1024;      // keep >= 2 workgroups per CU
+    const bool dpg = false;      // round 2: packed density in global memory for large fragments; unused since the density sits in registers
     if (sizeof(double) * ((size_t)bv.npair + body) > 150 * 1024) return false;
 #define DJ(JM, NL)                                                                                        \
     do {                                                                                                  \
