@@ -797,6 +797,194 @@ static void df_jk_mfma_launch(const BatchView& bv, int oa, hipStream_t s)
     hipLaunchKernelGGL(kern, dim3(gx, bv.nfrag), dim3(64 * DJ_NW), lds, s, bv, oa);
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 3: the same pass, but every WAVE walks its own auxiliary rows from start to end -- no workgroup barrier inside
+// the row loop.  The kernel above synchronises the workgroup three times per row (row parked | W complete | K done)
+// and its 60 MFMAs per row are cut into 3 + 6 jobs for 4 waves; 22 % of the matrix-core cycles were busy and the J/K
+// stage read its tensor at 0.14 of the HBM peak (profiles/r03_pmc_summary.json).  Here a wave owns rows R = wave,
+// wave + 4 G, ...: it parks its row in a wave-private LDS buffer (the gather of the W operands needs random access to
+// the packed row), forms c_R by a wave reduction against the packed density (shared, read-only LDS), updates its J
+// accumulators, runs ALL W = B_R C_occ jobs with interleaved accumulators, writes W to a wave-private buffer and runs
+// ALL lower-triangle K tiles with interleaved accumulators; the only workgroup barriers are the one after the
+// prologue and the ones of the final reduction of the four waves' J and K into one flush.  n <= 48, occupied
+// orbitals <= 16 (one orbital tile): the MBE fragment sizes; everything else keeps the kernel above.
+template <int NTC, int NLW>
+__global__ void __launch_bounds__(64 * DJ_NW, 2) df_jk_wave_kernel(BatchView bv, int only_active)
+{
+    extern __shared__ double lds[];
+    const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (only_active && bv.istate[4 * f] == ST_DONE) return;
+    const int lo = lane & 15, hi = lane >> 4;
+    constexpr int NP = 16 * NTC, OP = 16, WS = OP + 1, KS = NP / 4, NTILE = NTC * (NTC + 1) / 2;
+    const int n = bv.n, na = bv.naux, o = bv.nocc, np = bv.npair;
+    const double* __restrict__ Bf = bv.df_b + (size_t)f * na * (size_t)np;
+    const double* __restrict__ D = bv.D + (size_t)f * n * n;
+    const double* __restrict__ C = bv.C + (size_t)f * n * n;
+    double* Dp = lds;                                   // [np]  packed density, off-diagonal doubled (shared)
+    double* Co = Dp + np;                               // [NP][OP] occupied orbitals, zero padded (shared)
+    double* rowbuf = Co + NP * OP + (size_t)wave * (np + NP * WS);   // this wave's row [np] ...
+    double* W = rowbuf + np;                            // ... and its W [NP][WS]
+    for (int idx = tid; idx < np; idx += 64 * DJ_NW) {
+        int k, l;
+        df_unpack(idx, k, l);
+        const double d = D[k * n + l];
+        Dp[idx] = k == l ? d : 2.0 * d;
+    }
+    for (int idx = tid; idx < NP * OP; idx += 64 * DJ_NW) {
+        const int r = idx / OP, i = idx - r * OP;
+        Co[idx] = (r < n && i < o) ? C[r * n + i] : 0.0;
+    }
+    // gather offsets of the W operands (row-invariant): element (mu = 16 mt + lo, la = 4 ks + hi) of the packed row
+    // (two 16-bit offsets per register: npair <= 1176; 0xffff = outside the matrix)
+    unsigned woff[NTC][KS / 2];
+#pragma unroll
+    for (int mt = 0; mt < NTC; ++mt)
+#pragma unroll
+        for (int kp = 0; kp < KS / 2; ++kp) {
+            const int mu = 16 * mt + lo, la0 = 4 * (2 * kp) + hi, la1 = 4 * (2 * kp + 1) + hi;
+            const unsigned o0 = (mu < n && la0 < n) ? (unsigned)dj_pidx(mu, la0) : 0xffffu;
+            const unsigned o1 = (mu < n && la1 < n) ? (unsigned)dj_pidx(mu, la1) : 0xffffu;
+            woff[mt][kp] = o0 | (o1 << 16);
+        }
+    double jacc[NLW], nxt[NLW];
+#pragma unroll
+    for (int k = 0; k < NLW; ++k) jacc[k] = 0.0;
+    v4f64 kacc[NTILE];
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) kacc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    const int stride = (int)gridDim.x * DJ_NW;
+    int R = (int)blockIdx.x * DJ_NW + wave;
+    if (R < na) {
+#pragma unroll
+        for (int k = 0; k < NLW; ++k) { const int idx = lane + 64 * k; nxt[k] = idx < np ? Bf[(size_t)R * np + idx] : 0.0; }
+    }
+    __syncthreads();                                    // Dp, Co complete
+    for (; R < na; R += stride) {
+        // ---- the row: registers -> wave-private LDS; c_R; the next row goes in flight
+        double c = 0.0;
+#pragma unroll
+        for (int k = 0; k < NLW; ++k) {
+            const int idx = lane + 64 * k;
+            if (idx < np) { rowbuf[idx] = nxt[k]; c += nxt[k] * Dp[idx]; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+#pragma unroll
+        for (int k = 0; k < NLW; ++k) jacc[k] += nxt[k] * c;
+        const int Rn = R + stride;
+        if (Rn < na) {
+#pragma unroll
+            for (int k = 0; k < NLW; ++k) { const int idx = lane + 64 * k; nxt[k] = idx < np ? Bf[(size_t)Rn * np + idx] : 0.0; }
+        }
+        // ---- W_R = B_R C_occ: NTC row tiles, accumulators interleaved over the k-steps (wave-private data: the LDS
+        // writes above are ordered before these reads by the wave's own lgkmcnt)
+        v4f64 wacc[NTC];
+#pragma unroll
+        for (int mt = 0; mt < NTC; ++mt) wacc[mt] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const double cob = Co[(4 * ks + hi) * OP + lo];      // B operand of the step's jobs: C_occ row 4 ks + hi, orbital lo
+#pragma unroll
+            for (int mt = 0; mt < NTC; ++mt) {
+                const unsigned off = (ks & 1) ? (woff[mt][ks >> 1] >> 16) : (woff[mt][ks >> 1] & 0xffffu);
+                const double a = off != 0xffffu ? rowbuf[off] : 0.0;
+                wacc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, cob, wacc[mt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < NTC; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) W[(16 * mt + hi + 4 * r) * WS + lo] = wacc[mt][r];
+        // ---- K += W W^T on the lower-triangle tiles
+        double wa[NTC][4];
+#pragma unroll
+        for (int mt = 0; mt < NTC; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) wa[mt][ks] = W[(16 * mt + lo) * WS + 4 * ks + hi];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            int t = 0;
+#pragma unroll
+            for (int mt = 0; mt < NTC; ++mt)
+#pragma unroll
+                for (int nt = 0; nt <= mt; ++nt, ++t) kacc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[mt][ks], wa[nt][ks], kacc[t], 0, 0, 0);
+        }
+    }
+    // ---- the four waves' J and K meet in LDS (the row / W buffers are free now), one flush per workgroup
+    __syncthreads();
+    double* Jsum = Co + NP * OP;                        // [np] over the wave buffers
+    double* Ksum = Jsum + np;                           // [NP][NP]
+    for (int idx = tid; idx < np + NP * NP; idx += 64 * DJ_NW) Jsum[idx] = 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NLW; ++k) { const int idx = lane + 64 * k; if (idx < np && jacc[k] != 0.0) atomicAdd(&Jsum[idx], jacc[k]); }
+    {
+        int t = 0;
+#pragma unroll
+        for (int mt = 0; mt < NTC; ++mt)
+#pragma unroll
+            for (int nt = 0; nt <= mt; ++nt, ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double v = kacc[t][r];
+                    if (v != 0.0) atomicAdd(&Ksum[(16 * mt + hi + 4 * r) * NP + 16 * nt + lo], v);
+                }
+    }
+    __syncthreads();
+    double* J = bv.J + (size_t)f * n * n;
+    for (int idx = tid; idx < np; idx += 64 * DJ_NW) {
+        const double v = Jsum[idx];
+        if (v != 0.0) {
+            int a, b;
+            df_unpack(idx, a, b);
+            atomicAdd(&J[a * n + b], v);
+            if (a != b) atomicAdd(&J[b * n + a], v);
+        }
+    }
+    double* K = bv.K + (size_t)f * n * n;
+    for (int idx = tid; idx < NP * NP; idx += 64 * DJ_NW) {
+        const int mu = idx / NP, nu = idx - mu * NP;
+        // tiles (mt, nt) with mt >= nt were formed: a diagonal tile holds its whole 16 x 16 block, an off-diagonal one
+        // stands for its transpose as well
+        if (mu < n && nu < n && (mu >> 4) >= (nu >> 4)) {
+            const double v = 2.0 * Ksum[idx];
+            if (v != 0.0) {
+                atomicAdd(&K[mu * n + nu], v);
+                if ((mu >> 4) != (nu >> 4)) atomicAdd(&K[nu * n + mu], v);
+            }
+        }
+    }
+}
+
+template <int NTC, int NLW>
+static bool df_jk_wave_launch(const BatchView& bv, int oa, hipStream_t s)
+{
+    const int NP = 16 * NTC;
+    const size_t lds = sizeof(double) * ((size_t)bv.npair + (size_t)NP * 16 + DJ_NW * ((size_t)bv.npair + (size_t)NP * 17) + 8);
+    if (lds > (size_t)80 * 1024) return false;          // two workgroups per CU
+    if ((size_t)bv.npair + (size_t)NP * NP > DJ_NW * ((size_t)bv.npair + (size_t)NP * 17)) return false;   // final reduction fits the wave buffers
+    auto kern = df_jk_wave_kernel<NTC, NLW>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int gx = (2048 + bv.nfrag - 1) / bv.nfrag;           // workgroups per fragment: every wave should see several rows
+    const int maxg = (bv.naux + 4 * DJ_NW - 1) / (4 * DJ_NW);
+    if (gx > maxg) gx = maxg;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(kern, dim3(gx, bv.nfrag), dim3(64 * DJ_NW), lds, s, bv, oa);
+    return true;
+}
+
+// n <= 48, one orbital tile, exchange wanted (MQC_HIP_DF_WAVE=0: the workgroup kernel)
+static bool df_jk_wave_dispatch(const BatchView& bv, int oa, hipStream_t s)
+{
+    static const bool on = [] { const char* e = std::getenv("MQC_HIP_DF_WAVE"); return !(e && e[0] == '0'); }();
+    if (!on || bv.exx == 0.0 || bv.n > 48 || bv.nocc > 16) return false;
+    const int nt = (bv.n + 15) / 16, nlw = (bv.npair + 63) / 64;
+    if (nt == 1 && nlw <= 3) return df_jk_wave_launch<1, 3>(bv, oa, s);
+    if (nt == 2 && nlw <= 9) return df_jk_wave_launch<2, 9>(bv, oa, s);
+    if (nt == 3 && nlw <= 19) return df_jk_wave_launch<3, 19>(bv, oa, s);
+    return false;
+}
+
 // false: no instantiation covers this size (the round-1 kernels take it)
 static bool df_jk_mfma_dispatch(const BatchView& bv, int oa, hipStream_t s)
 {
@@ -909,6 +1097,7 @@ void launch_df_jk(const BatchView& bv, bool only_active, hipStream_t s)
     static const bool v1 = [] { const char* e = std::getenv("MQC_HIP_DF_V1"); return e && e[0] == '1'; }();
     if (!v1) {
         (void)hipMemsetAsync(bv.J, 0, sizeof(double) * (size_t)bv.nfrag * n * n, s);
+        if (df_jk_wave_dispatch(bv, oa, s)) return;
         if (df_jk_mfma_dispatch(bv, oa, s)) return;
     }
     const size_t ldsj = sizeof(double) * ((size_t)bv.npair + bv.naux + 8);
