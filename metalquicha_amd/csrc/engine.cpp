@@ -417,8 +417,8 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
     const int rad_pt = xc_tile_points(n);
     const size_t rad_tiles = xc.ncomp > 0 ? ((size_t)grid.npts + rad_pt - 1) / rad_pt : 0;
     const size_t rad_doubles = (xc.ncomp > 0 && rad_cache_on && !uhf_mem) ? rad_tiles * topo.shells.size() * 2 * rad_pt : 0;
-    // point buffer of the split quadrature (n <= 64, s/p/d shells, 32-point tiles): 4 doubles per padded grid point
-    const size_t pt4_doubles = (rad_doubles && n <= 64 && topo.lmax <= 2 && rad_pt == 32) ? rad_tiles * rad_pt * 4 : 0;
+    // point buffer of the split quadrature (n <= 96, s-f shells, 32-point tiles): 4 doubles per padded grid point
+    const size_t pt4_doubles = (rad_doubles && n <= 96 && topo.lmax <= 3 && rad_pt == 32) ? rad_tiles * rad_pt * 4 : 0;
     const size_t per_frag = sizeof(double) * (per_fragment_main_doubles(n, topo.natoms, uhf_mem, npc, hx) + two_e + (xc.ncomp > 0 ? (size_t)n * n * (uhf_mem ? 2 : 1) + grid.npts : 0) + rad_doubles + pt4_doubles);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);

@@ -1479,8 +1479,7 @@ static bool xc_pipe_dispatch(const BatchView& bv, int oa, hipStream_t s)
 // Each kernel needs a fraction of the registers and LDS (three to five workgroups per CU), no wave ever waits for a
 // single-wave phase, and the functional runs at full width.  Price: the slab's angular part is formed twice and the
 // radial cache is read twice.  Same arithmetic as the tile kernel (mqc_libcint_xc.F90:796-927).
-static_assert(256 % 32 == 0, "the slab maps a thread to one grid point");
-constexpr int XS_PT = 32, XS_NT = 256, XS_SI = 4;      // tile points, threads, slab items per thread prefetched
+constexpr int XS_PT = 32, XS_SI = 4;      // tile points; slab items per thread prefetched (threads: 64 x NW, a multiple of XS_PT)
 // row stride of the potential kernel's two LDS arrays.  33: the MFMA operand reads (row <- lane & 15, point <- lane >> 4)
 // of lanes (row, point) and (row + 1, point - 1) share a bank (SQ_LDS_BANK_CONFLICT = 29 % of the LDS cycles); 34 =
 // 2 (mod 32) is conflict-free for them -- and measured no faster on one box (805 / 807 against 795 / 796 ms per B3LYP
@@ -1489,8 +1488,9 @@ constexpr int XS_PT = 32, XS_NT = 256, XS_SI = 4;      // tile points, threads, 
 #define XS_RS3 33
 #endif
 
-// value and a = c0 chi + c . grad chi of one shell at one point (l <= 2), from its radial value and derivative factor
-template <bool GGA>
+// value and a = c0 chi + c . grad chi of one shell at one point (l <= 2; l = 3 with LF), from its radial value and
+// derivative factor
+template <bool GGA, bool LF = false>
 __device__ __forceinline__ void emit_shell_a(int l, int ao, double dx, double dy, double dz, double rad, double drad,
                                              double c0, double c1, double c2, double c3,
                                              double* __restrict__ chi, double* __restrict__ av, int ptp, int p)
@@ -1512,6 +1512,33 @@ __device__ __forceinline__ void emit_shell_a(int l, int ao, double dx, double dy
         av[ao * ptp + p] = c0 * vx + (GGA ? c1 * rad + dx * cd : 0.0);
         av[(ao + 1) * ptp + p] = c0 * vy + (GGA ? c2 * rad + dy * cd : 0.0);
         av[(ao + 2) * ptp + p] = c0 * vz + (GGA ? c3 * rad + dz * cd : 0.0);
+    } else if (LF && l == 3) {
+        // the seven real solid harmonics of an f shell over the ten cubic monomials (same table as emit_shell)
+        constexpr double T3[7][10] = {
+            {0, 1.7701307697799307, 0, 0, 0, 0, -0.59004358992664352, 0, 0, 0},
+            {0, 0, 0, 0, 2.8906114426405543, 0, 0, 0, 0, 0},
+            {0, -0.45704579946446572, 0, 0, 0, 0, -0.45704579946446572, 0, 1.8281831978578629, 0},
+            {0, 0, -1.1195289977703462, 0, 0, 0, 0, -1.1195289977703462, 0, 0.7463526651802308},
+            {-0.45704579946446572, 0, 0, -0.45704579946446572, 0, 1.8281831978578629, 0, 0, 0, 0},
+            {0, 0, 1.4453057213202771, 0, 0, 0, 0, -1.4453057213202771, 0, 0},
+            {0.59004358992664352, 0, 0, -1.7701307697799307, 0, 0, 0, 0, 0, 0}};
+        const double x2 = dx * dx, y2 = dy * dy, z2 = dz * dz, xy = dx * dy, xz = dx * dz, yz = dy * dz;
+        const double cv[10] = {x2 * dx, x2 * dy, x2 * dz, dx * y2, xy * dz, dx * z2, y2 * dy, y2 * dz, dy * z2, z2 * dz};
+        const double cgx[10] = {3.0 * x2, 2.0 * xy, 2.0 * xz, y2, yz, z2, 0.0, 0.0, 0.0, 0.0};
+        const double cgy[10] = {0.0, x2, 0.0, 2.0 * xy, xz, 0.0, 3.0 * y2, 2.0 * yz, z2, 0.0};
+        const double cgz[10] = {0.0, 0.0, x2, 0.0, xy, 2.0 * xz, 0.0, y2, 2.0 * yz, 3.0 * z2};
+#pragma unroll
+        for (int m = 0; m < 7; ++m) {
+            double v = 0.0, g = 0.0;
+#pragma unroll
+            for (int k = 0; k < 10; ++k)
+                if (T3[m][k] != 0.0) {
+                    v += T3[m][k] * cv[k];
+                    if (GGA) g += T3[m][k] * (c1 * cgx[k] + c2 * cgy[k] + c3 * cgz[k]);
+                }
+            chi[(ao + m) * ptp + p] = v * rad;
+            av[(ao + m) * ptp + p] = c0 * v * rad + (GGA ? g * rad + v * cd : 0.0);
+        }
     } else {
         const double cv[6] = {dx * dx, dx * dy, dx * dz, dy * dy, dy * dz, dz * dz};
         const double cgx[6] = {2.0 * dx, dy, dz, 0.0, 0.0, 0.0};
@@ -1532,13 +1559,14 @@ __device__ __forceinline__ void emit_shell_a(int l, int ao, double dx, double dy
     }
 }
 
-template <bool GGA, int NTC>
-__global__ void __launch_bounds__(XS_NT, NTC >= 4 ? 2 : 3) xc_density_kernel(BatchView bv, int only_active)
+template <bool GGA, int NTC, int NW, bool LF>
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (NTC >= 4 ? 2 : 3)) xc_density_kernel(BatchView bv, int only_active)
 {
     extern __shared__ double lds[];
     const int f = blockIdx.y;
     if ((only_active & 1) && bv.istate[4 * f] == ST_DONE) return;
-    constexpr int PT = XS_PT, RS = PT + 1, NP = 16 * NTC, ARR = GGA ? 4 : 1, SL = ARR * NP * RS, HK = 2 * NTC;   // HK: k-steps of half the functions
+    constexpr int XS_NT = 64 * NW, KPART = NW / 2;           // threads; parts the functions are cut into (2 or 4)
+    constexpr int PT = XS_PT, RS = PT + 1, NP = 16 * NTC, ARR = GGA ? 4 : 1, SL = ARR * NP * RS, HK = 4 * NTC / KPART;   // HK: k-steps of one part of the functions
     const int n = bv.n, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lo = lane & 15, hi = lane >> 4;
     const TopologyDev& tp = bv.topo;
@@ -1558,10 +1586,11 @@ __global__ void __launch_bounds__(XS_NT, NTC >= 4 ? 2 : 3) xc_density_kernel(Bat
     for (int idx = tid; idx < SL + 4 * PT; idx += XS_NT) lds[idx] = 0.0;          // rows n..NP-1 stay zero
     for (int sh = tid; sh < tp.nshell; sh += XS_NT) sdesc[sh] = tp.sh_aoff[sh] | (tp.sh_l[sh] << 12) | (tp.sh_atom[sh] << 16);
     for (int idx = tid; idx < 3 * tp.natoms; idx += XS_NT) axyz[idx] = xyz[idx];
-    // this wave's part of X = D chi: point tile pt, half kh of the functions, every row tile mt -- the B operand
+    // this wave's part of X = D chi: point tile pt, part kh of the functions (halves with four waves, quarters with
+    // eight), every row tile mt -- the B operand
     // (AO values of its points) is then the same for all its jobs, and rho / grad rho of its 16 points add up in
     // registers over the row tiles: one reduction per tile and wave
-    const int pt = (wave >> 1) & 1, kh = wave & 1;
+    const int pt = (wave / KPART) & 1, kh = wave % KPART;
     double dfrag[NTC][HK];
 #pragma unroll
     for (int mt = 0; mt < NTC; ++mt)
@@ -1622,7 +1651,7 @@ __global__ void __launch_bounds__(XS_NT, NTC >= 4 ? 2 : 3) xc_density_kernel(Bat
                     const int sd = sdesc[sh];
                     const int ao = sd & 0xfff, l = (sd >> 12) & 0xf, at = sd >> 16;
                     const double dx = ptx - axyz[3 * at], dy = pty - axyz[3 * at + 1], dz = ptz - axyz[3 * at + 2];
-                    emit_shell<GGA, false>(l, ao, dx, dy, dz, rv[k], dv[k], chi, gx, gy, gz, RS, p0, bv.c2s);
+                    emit_shell<GGA, LF>(l, ao, dx, dy, dz, rv[k], dv[k], chi, gx, gy, gz, RS, p0, bv.c2s);
                 }
             }
             const double* __restrict__ radt = radf + (size_t)tile * tp.nshell * 2 * PT;
@@ -1634,7 +1663,7 @@ __global__ void __launch_bounds__(XS_NT, NTC >= 4 ? 2 : 3) xc_density_kernel(Bat
                 const double dx = pp[0] - axyz[3 * at], dy = pp[1] - axyz[3 * at + 1], dz = pp[2] - axyz[3 * at + 2];
                 const bool in = g0 + p < gd.npts;
                 const double* r0 = radt + (size_t)sh * 2 * PT + p;
-                emit_shell<GGA, false>(l, ao, dx, dy, dz, in ? r0[0] : 0.0, (GGA && in) ? r0[PT] : 0.0, chi, gx, gy, gz, RS, p, bv.c2s);
+                emit_shell<GGA, LF>(l, ao, dx, dy, dz, in ? r0[0] : 0.0, (GGA && in) ? r0[PT] : 0.0, chi, gx, gy, gz, RS, p, bv.c2s);
             }
         }
         radial_fetch(tile + stride);
@@ -1718,14 +1747,15 @@ __global__ void __launch_bounds__(256) xc_functional_kernel(BatchView bv, int on
     }
 }
 
-template <bool GGA, int NTC>
-__global__ void __launch_bounds__(XS_NT, NTC >= 4 ? 2 : 3) xc_potential_kernel(BatchView bv, int only_active)
+template <bool GGA, int NTC, int NW, bool LF>
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : ((NTC >= 4 || LF) ? 2 : 3)) xc_potential_kernel(BatchView bv, int only_active)
 {
     extern __shared__ double lds[];
     const int f = blockIdx.y;
     if ((only_active & 1) && bv.istate[4 * f] == ST_DONE) return;
+    constexpr int XS_NT = 64 * NW;
     constexpr int PT = XS_PT, RS = XS_RS3, NP = 16 * NTC, SL = 2 * NP * RS;
-    constexpr int NU = 2 * NTC * NTC, JU = (NU + 3) / 4;         // (output tile, half of the points) units, units per wave
+    constexpr int NU = 2 * NTC * NTC, JU = (NU + NW - 1) / NW;   // (output tile, half of the points) units, units per wave
     const int n = bv.n, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lo = lane & 15, hi = lane >> 4;
     const TopologyDev& tp = bv.topo;
@@ -1803,7 +1833,7 @@ __global__ void __launch_bounds__(XS_NT, NTC >= 4 ? 2 : 3) xc_potential_kernel(B
                     const int sd = sdesc[sh];
                     const int ao = sd & 0xfff, l = (sd >> 12) & 0xf, at = sd >> 16;
                     const double dx = ptx - axyz[3 * at], dy = pty - axyz[3 * at + 1], dz = ptz - axyz[3 * at + 2];
-                    emit_shell_a<GGA>(l, ao, dx, dy, dz, rv[k], dv[k], c0, c1, c2, c3, chi, av, RS, p0);
+                    emit_shell_a<GGA, LF>(l, ao, dx, dy, dz, rv[k], dv[k], c0, c1, c2, c3, chi, av, RS, p0);
                 }
             }
             const double* __restrict__ radt = radf + (size_t)tile * tp.nshell * 2 * PT;
@@ -1816,7 +1846,7 @@ __global__ void __launch_bounds__(XS_NT, NTC >= 4 ? 2 : 3) xc_potential_kernel(B
                 const bool in = g0 + p < gd.npts;
                 const double* r0 = radt + (size_t)sh * 2 * PT + p;
                 const double* cp = coef + 4 * (buf * PT + p);
-                emit_shell_a<GGA>(l, ao, dx, dy, dz, in ? r0[0] : 0.0, (GGA && in) ? r0[PT] : 0.0, cp[0], cp[1], cp[2], cp[3], chi, av, RS, p);
+                emit_shell_a<GGA, LF>(l, ao, dx, dy, dz, in ? r0[0] : 0.0, (GGA && in) ? r0[PT] : 0.0, cp[0], cp[1], cp[2], cp[3], chi, av, RS, p);
             }
         }
         radial_fetch(next);
@@ -1826,7 +1856,7 @@ __global__ void __launch_bounds__(XS_NT, NTC >= 4 ? 2 : 3) xc_potential_kernel(B
         // ---- A += a chi^T: unit = (output tile t = mt NTC + nt, half kh of the tile's points)
 #pragma unroll
         for (int j = 0; j < JU; ++j) {
-            const int u = wave + 4 * j;
+            const int u = wave + NW * j;
             if (u < NU) {
                 const int t = u >> 1, kh = u & 1, mt = t / NTC, nt = t - mt * NTC;
                 const double* __restrict__ ar = av + (size_t)(16 * mt + lo) * RS + 16 * kh + hi;
@@ -1840,7 +1870,7 @@ __global__ void __launch_bounds__(XS_NT, NTC >= 4 ? 2 : 3) xc_potential_kernel(B
     double* Vx = bv.Vxc + (size_t)f * n * n;
 #pragma unroll
     for (int j = 0; j < JU; ++j) {
-        const int u = wave + 4 * j;
+        const int u = wave + NW * j;
         if (u < NU) {
             const int t = u >> 1, mt = t / NTC, nt = t - mt * NTC;
 #pragma unroll
@@ -1853,21 +1883,21 @@ __global__ void __launch_bounds__(XS_NT, NTC >= 4 ? 2 : 3) xc_potential_kernel(B
     }
 }
 
-template <bool GGA, int NTC>
+template <bool GGA, int NTC, int NW, bool LF>
 static bool xc_split_launch(const BatchView& bv, int oa, hipStream_t s)
 {
-    constexpr int PT = XS_PT;
+    constexpr int PT = XS_PT, NTHR = 64 * NW;
     const size_t misc = 6 * PT + (((size_t)3 * bv.topo.natoms + 1) & ~(size_t)1) + ((size_t)bv.topo.nshell + 1) / 2;
     const size_t lds1 = sizeof(double) * ((size_t)(GGA ? 4 : 1) * 16 * NTC * (PT + 1) + 4 * PT + misc);
     const size_t lds3 = sizeof(double) * ((size_t)2 * 16 * NTC * XS_RS3 + 8 * PT + misc);
     if (lds1 > (size_t)160 * 1024 - 256 || lds3 > (size_t)160 * 1024 - 256) return false;
-    auto k1 = xc_density_kernel<GGA, NTC>;
-    auto k3 = xc_potential_kernel<GGA, NTC>;
+    auto k1 = xc_density_kernel<GGA, NTC, NW, LF>;
+    auto k3 = xc_potential_kernel<GGA, NTC, NW, LF>;
     (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
     (void)hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
     const int ntiles = (bv.grid.npts + PT - 1) / PT;
-    // density: no state carried from tile to tile, any number of workgroups; ~8 rounds of three per CU over the batch
-    int g1 = (6144 + bv.nfrag - 1) / bv.nfrag;
+    // density: no state carried from tile to tile, any number of workgroups; ~8 rounds of the resident set over the batch
+    int g1 = ((NW == 8 ? 2048 : 6144) + bv.nfrag - 1) / bv.nfrag;
     if (g1 > ntiles) g1 = ntiles;
     if (g1 < 1) g1 = 1;
     // potential: the accumulators are flushed once per workgroup (n^2 atomics), so a workgroup takes many tiles
@@ -1877,23 +1907,30 @@ static bool xc_split_launch(const BatchView& bv, int oa, hipStream_t s)
     const int npad = ntiles * PT;
     int g2 = (npad + 255) / 256;
     if (g2 > 64) g2 = 64;
-    hipLaunchKernelGGL(k1, dim3(g1, bv.nfrag), dim3(XS_NT), lds1, s, bv, oa);
+    hipLaunchKernelGGL(k1, dim3(g1, bv.nfrag), dim3(NTHR), lds1, s, bv, oa);
     hipLaunchKernelGGL(xc_functional_kernel<GGA>, dim3(g2, bv.nfrag), dim3(256), 0, s, bv, oa);
-    hipLaunchKernelGGL(k3, dim3(g3, bv.nfrag), dim3(XS_NT), lds3, s, bv, oa);
+    hipLaunchKernelGGL(k3, dim3(g3, bv.nfrag), dim3(NTHR), lds3, s, bv, oa);
     return true;
 }
 
-// n <= 64, restricted, s/p/d shells, radial cache at 32-point tiles, point buffer there (MQC_HIP_XC_SPLIT=0: off)
+// n <= 96, restricted, s/p/d (f from n > 32) shells, radial cache at 32-point tiles, point buffer there
+// (MQC_HIP_XC_SPLIT=0: off).  Four waves per workgroup up to n = 64, eight above (def2-TZVP water dimer n = 86,
+// cc-pVDZ trimers n = 72): the functions of X = D chi are then cut into quarters and the (tile, half) units of the
+// potential kernel are dealt to eight waves, so that the density fragments and accumulators still fit the registers.
 template <bool GGA>
 static bool xc_split_dispatch(const BatchView& bv, int oa, hipStream_t s)
 {
     static const bool on = [] { const char* e = std::getenv("MQC_HIP_XC_SPLIT"); return !(e && e[0] == '0'); }();
-    if (!on || bv.uhf || bv.n > 64 || bv.topo.lmax > 2 || !bv.grid.rad || bv.grid.rad_pt != XS_PT || !bv.grid.pt4) return false;
+    if (!on || bv.uhf || bv.n > 96 || bv.topo.lmax > 3 || !bv.grid.rad || bv.grid.rad_pt != XS_PT || !bv.grid.pt4) return false;
     const int nt = (bv.n + 15) / 16;
-    if (nt == 1) return xc_split_launch<GGA, 1>(bv, oa, s);
-    if (nt == 2) return xc_split_launch<GGA, 2>(bv, oa, s);
-    if (nt == 3) return xc_split_launch<GGA, 3>(bv, oa, s);
-    return xc_split_launch<GGA, 4>(bv, oa, s);
+    const bool f = bv.topo.lmax == 3;
+    if (f && nt <= 2) return false;
+    if (nt == 1) return xc_split_launch<GGA, 1, 4, false>(bv, oa, s);
+    if (nt == 2) return xc_split_launch<GGA, 2, 4, false>(bv, oa, s);
+    if (nt == 3) return f ? xc_split_launch<GGA, 3, 4, true>(bv, oa, s) : xc_split_launch<GGA, 3, 4, false>(bv, oa, s);
+    if (nt == 4) return f ? xc_split_launch<GGA, 4, 4, true>(bv, oa, s) : xc_split_launch<GGA, 4, 4, false>(bv, oa, s);
+    if (nt == 5) return f ? xc_split_launch<GGA, 5, 8, true>(bv, oa, s) : xc_split_launch<GGA, 5, 8, false>(bv, oa, s);
+    return f ? xc_split_launch<GGA, 6, 8, true>(bv, oa, s) : xc_split_launch<GGA, 6, 8, false>(bv, oa, s);
 }
 
 __global__ void xc_reset_kernel(BatchView bv)
