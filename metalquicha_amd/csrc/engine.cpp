@@ -242,11 +242,13 @@ static int validate_options(const mqc_hip_scf_options_t& o, const Topology& topo
     {
         XcSpec tmp; std::string e;
         if (!parse_functional(o.functional, tmp, e)) { msg = e; return MQC_HIP_ERR_UNSUPPORTED; }
+        if (tmp.gga == 2 && topo.nao > 140) { msg = "meta-GGA functionals are available up to n_ao = 140"; return MQC_HIP_ERR_UNSUPPORTED; }
         if (tmp.ncomp > 0 && topo.natoms > 64) { msg = "XC grid: fragments above 64 atoms are not supported yet"; return MQC_HIP_ERR_UNSUPPORTED; }
     }
     if (o.want_gradient) {
         XcSpec tg; std::string eg;
         parse_functional(o.functional, tg, eg);
+        if (tg.gga == 2) { msg = "analytic gradients of meta-GGA functionals are not built (energies only)"; return MQC_HIP_ERR_UNSUPPORTED; }
         if (o.density_fitting) { msg = "analytic gradients are available on the exact-ERI path; the density-fitted two-electron derivative is not built yet"; return MQC_HIP_ERR_UNSUPPORTED; }
         if (topo.lmax > 2) { msg = "analytic gradients cover s, p and d shells"; return MQC_HIP_ERR_UNSUPPORTED; }
     }
@@ -263,6 +265,7 @@ static int validate_options(const mqc_hip_scf_options_t& o, const Topology& topo
             XcSpec tu; std::string eu;
             parse_functional(o.functional, tu, eu);
             if (tu.ncomp > 0 && topo.nao > 140) { msg = "unrestricted Kohn-Sham is available up to n_ao = 140"; return MQC_HIP_ERR_UNSUPPORTED; }
+            if (tu.gga == 2) { msg = "meta-GGA functionals are available for restricted runs (the spin-polarised TPSS forms are not built)"; return MQC_HIP_ERR_UNSUPPORTED; }
         }
     } else if (topo.nelec < 2) { msg = "RHF: no electrons to place"; return MQC_HIP_ERR_VALIDATION; }
     if (o.guess < MQC_HIP_GUESS_AUTO || o.guess > MQC_HIP_GUESS_SAC) { msg = "unknown initial guess"; return MQC_HIP_ERR_VALIDATION; }

@@ -81,13 +81,13 @@ private:
 };
 
 // exchange-correlation components (libxc-equivalent ids, unpolarised)
-enum : int { XC_LDA_X = 1, XC_LDA_C_VWN, XC_LDA_C_VWN_RPA, XC_GGA_X_B88, XC_GGA_C_LYP, XC_GGA_X_PBE, XC_GGA_C_PBE };
+enum : int { XC_LDA_X = 1, XC_LDA_C_VWN, XC_LDA_C_VWN_RPA, XC_GGA_X_B88, XC_GGA_C_LYP, XC_GGA_X_PBE, XC_GGA_C_PBE, XC_MGGA_X_TPSS, XC_MGGA_C_TPSS };
 struct XcSpec {
     int ncomp = 0;
     int id[6] = {0, 0, 0, 0, 0, 0};
     double w[6] = {0, 0, 0, 0, 0, 0};
     double exx = 1.0;     // exact-exchange fraction
-    int gga = 0;
+    int gga = 0;          // 1: needs grad rho; 2: meta-GGA, needs grad rho and tau
 };
 
 // quadrature grid of a batch: per-topology point list (atom, template point) + per-fragment weights

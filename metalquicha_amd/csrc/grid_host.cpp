@@ -118,7 +118,8 @@ bool parse_functional(const char* name_in, XcSpec& spec, std::string& err)
         spec.exx = 0.20; spec.gga = 1;
     }
     else if (n == "pbe0") { add(XC_GGA_X_PBE, 0.75); add(XC_GGA_C_PBE, 1.0); spec.exx = 0.25; spec.gga = 1; }
-    else { err = "functional '" + n + "' is not available on the HIP backend (svwn, pbe, blyp, b3lyp, pbe0)"; return false; }
+    else if (n == "tpss") { add(XC_MGGA_X_TPSS, 1.0); add(XC_MGGA_C_TPSS, 1.0); spec.exx = 0.0; spec.gga = 2; }     // mqc_xc_spec.f90:142-166
+    else { err = "functional '" + n + "' is not available on the HIP backend (svwn, pbe, blyp, b3lyp, pbe0, tpss)"; return false; }
     return true;
 }
 

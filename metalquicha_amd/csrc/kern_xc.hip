@@ -353,6 +353,98 @@ __device__ __forceinline__ void eval_functional_pol(const XcSpec& xc, double ra_
     }
 }
 
+
+// ------------------------------------------------------------------ meta-GGA (restricted): value + d/d(rho, sigma, tau)
+struct D3 {
+    double v, d[3];
+};
+__device__ __forceinline__ D3 mk3(double v) { return {v, {0.0, 0.0, 0.0}}; }
+__device__ __forceinline__ D3 var3(double v, int i) { D3 r = mk3(v); r.d[i] = 1.0; return r; }
+__device__ __forceinline__ D3 operator+(D3 a, D3 b) { D3 r; r.v = a.v + b.v; for (int i = 0; i < 3; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+__device__ __forceinline__ D3 operator-(D3 a, D3 b) { D3 r; r.v = a.v - b.v; for (int i = 0; i < 3; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+__device__ __forceinline__ D3 operator*(D3 a, D3 b) { D3 r; r.v = a.v * b.v; for (int i = 0; i < 3; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+__device__ __forceinline__ D3 operator/(D3 a, D3 b)
+{
+    const double inv = 1.0 / b.v, q = a.v * inv;
+    D3 r; r.v = q;
+    for (int i = 0; i < 3; ++i) r.d[i] = (a.d[i] - q * b.d[i]) * inv;
+    return r;
+}
+__device__ __forceinline__ D3 operator+(D3 a, double b) { a.v += b; return a; }
+__device__ __forceinline__ D3 operator+(double b, D3 a) { a.v += b; return a; }
+__device__ __forceinline__ D3 operator-(D3 a, double b) { a.v -= b; return a; }
+__device__ __forceinline__ D3 operator-(double b, D3 a) { return mk3(b) - a; }
+__device__ __forceinline__ D3 operator*(D3 a, double b) { a.v *= b; for (int i = 0; i < 3; ++i) a.d[i] *= b; return a; }
+__device__ __forceinline__ D3 operator*(double b, D3 a) { return a * b; }
+__device__ __forceinline__ D3 operator/(D3 a, double b) { return a * (1.0 / b); }
+__device__ __forceinline__ D3 operator/(double b, D3 a) { return mk3(b) / a; }
+__device__ __forceinline__ D3 chain3(D3 x, double f, double df) { D3 r; r.v = f; for (int i = 0; i < 3; ++i) r.d[i] = df * x.d[i]; return r; }
+__device__ __forceinline__ D3 exp3(D3 x) { const double f = exp(x.v); return chain3(x, f, f); }
+__device__ __forceinline__ D3 log3(D3 x) { return chain3(x, log(x.v), 1.0 / x.v); }
+__device__ __forceinline__ D3 sqrt3(D3 x) { const double f = sqrt(x.v); return chain3(x, f, 0.5 / f); }
+__device__ __forceinline__ D3 cbrt3(D3 x) { const double f = cbrt(x.v); return chain3(x, f, f / (3.0 * x.v)); }
+
+// PBE correlation energy per particle at zeta = 0 or zeta = 1 (lda_c_pw_mod inside), the two ends TPSS needs
+__device__ __forceinline__ D3 pbe_c_eps_fixed_zeta(D3 rho, D3 sigma, bool ferro)
+{
+    const D3 r13 = cbrt3(rho);
+    const D3 rs = 0.6203504908994001 / r13;
+    const D3 srs = sqrt3(rs);
+    const double A = ferro ? 0.01554535 : 0.0310907, a1 = ferro ? 0.20548 : 0.21370, b1 = ferro ? 14.1189 : 7.5957,
+                 b2 = ferro ? 6.1977 : 3.5876, b3 = ferro ? 3.3662 : 1.6382, b4 = ferro ? 0.62517 : 0.49294;
+    const D3 q = 2.0 * A * (b1 * srs + b2 * rs + b3 * rs * srs + b4 * rs * rs);
+    const D3 ec = -2.0 * A * (1.0 + a1 * rs) * log3(1.0 + 1.0 / q);
+    const double phi = ferro ? 0.7937005259840998 : 1.0, phi3 = phi * phi * phi;
+    const D3 kf = 3.0936677262801355 * r13;
+    const D3 ks2 = (4.0 / M_PI) * kf;
+    const D3 t2 = sigma / (4.0 * phi * phi * ks2 * rho * rho);
+    const D3 Aa = (PBE_BETA / PBE_GAMMA) / (exp3(-1.0 * ec / (PBE_GAMMA * phi3)) - 1.0);
+    const D3 at2 = Aa * t2;
+    const D3 H = PBE_GAMMA * phi3 * log3(1.0 + (PBE_BETA / PBE_GAMMA) * t2 * (1.0 + at2) / (1.0 + at2 + at2 * at2));
+    return ec + H;
+}
+
+// libxc mgga_x_tpss + mgga_c_tpss, unpolarised (Tao, Perdew, Staroverov, Scuseria, PRL 91, 146401 eqs. 5-14);
+// f per volume and d/d(rho, sigma, tau), zero below the density threshold.  mqc_xc_spec.f90:142-166 names the pair.
+__device__ __forceinline__ void eval_functional_mgga(const XcSpec& xc, double rho_in, double sigma_in, double tau_in, double& f, double* dv)
+{
+    f = 0.0;
+    dv[0] = dv[1] = dv[2] = 0.0;
+    if (!(rho_in > XC_DENS_THRESHOLD)) return;
+    const D3 rho = var3(rho_in, 0), sigma = var3(fmax(sigma_in, 1.0e-40), 1), tau = var3(fmax(tau_in, 1.0e-20), 2);
+    const D3 r13 = cbrt3(rho);
+    const D3 z = sigma / (8.0 * rho * tau);
+    const D3 z2 = z * z;
+    for (int k = 0; k < xc.ncomp; ++k) {
+        D3 d = mk3(0.0);
+        if (xc.id[k] == XC_MGGA_X_TPSS) {
+            const double b = 0.40, c = 1.59096, e = 1.537, kappa = 0.804, mu = 0.21951, mu_ge = 10.0 / 81.0, se = 1.2397580409095959;
+            const D3 r23 = r13 * r13;
+            const D3 p = sigma / ((4.0 * 9.570780000627305) * (r23 * rho * rho));            // 4 (3 pi^2)^(2/3) rho^(8/3)
+            const D3 tau_unif = (0.3 * 9.570780000627305) * (r23 * rho);
+            const D3 alpha = (tau - sigma / (8.0 * rho)) / tau_unif;
+            const D3 qb = 0.45 * (alpha - 1.0) / sqrt3(1.0 + b * alpha * (alpha - 1.0)) + (2.0 / 3.0) * p;
+            const D3 opz2 = 1.0 + z2;
+            const D3 num = (mu_ge + c * z2 / (opz2 * opz2)) * p + (146.0 / 2025.0) * qb * qb
+                         - (73.0 / 405.0) * qb * sqrt3(0.5 * (0.36 * z2 + p * p)) + (mu_ge * mu_ge / kappa) * p * p
+                         + (2.0 * se * mu_ge * 0.36) * z2 + (e * mu) * p * p * p;
+            const D3 den = (1.0 + se * p) * (1.0 + se * p);
+            const D3 x = num / den;
+            const D3 fx = (1.0 + kappa) - kappa / (1.0 + x / kappa);
+            d = -0.7385587663820224 * (rho * r13) * fx;
+        } else if (xc.id[k] == XC_MGGA_C_TPSS) {
+            const double dd = 2.8, C0 = 0.53;
+            const D3 e_pbe = pbe_c_eps_fixed_zeta(rho, sigma, false);
+            const D3 e_one = pbe_c_eps_fixed_zeta(0.5 * rho, 0.25 * sigma, true);
+            const D3 e_til = e_one.v > e_pbe.v ? e_one : e_pbe;
+            const D3 e_rev = e_pbe * (1.0 + C0 * z2) - (1.0 + C0) * z2 * e_til;
+            d = rho * e_rev * (1.0 + dd * e_rev * z2 * z);
+        }
+        f += xc.w[k] * d.v;
+        for (int i = 0; i < 3; ++i) dv[i] += xc.w[k] * d.d[i];
+    }
+}
+
 // ------------------------------------------------------------------ Becke / Treutler partition weights
 __device__ __forceinline__ double becke_cutoff(double nu)
 {
@@ -2076,12 +2168,161 @@ static void xc_uks_launch(const BatchView& bv, int oa, hipStream_t s)
         hipLaunchKernelGGL(kern, dim3(gx, bv.nfrag), dim3(XC_NT), lds, s, bv, oa | (spin << 1));
 }
 
+// Restricted meta-GGA quadrature, parity-first on the vector units (the reference's meta-GGA lives on its CPU backend:
+// eval_rho's tau, mqc_libcint_ao.f90:374-417; accumulate_xc_matrix's third term, mqc_libcint_xc.F90:1436-1448).
+// Per tile of PT points: chi and grad chi in LDS, X = D chi -> rho, grad rho; X = D d_d chi for d = x, y, z ->
+// tau = 1/2 sum_d X_d . d_d chi; then A = (w v_rho / 2) chi + w c . grad chi and
+//     acc += A^T chi + (w v_tau / 4) sum_d (d_d chi)^T d_d chi        (V_xc = acc + acc^T)
+template <int PT, int NV>
+__global__ void __launch_bounds__(XC_NT) xc_mgga_kernel(BatchView bv, int flags)
+{
+    extern __shared__ double lds[];
+    const int f = blockIdx.y;
+    if ((flags & 1) && bv.istate[4 * f] == ST_DONE) return;
+    const int n = bv.n, tid = threadIdx.x;
+    const TopologyDev& tp = bv.topo;
+    const GridDev& gd = bv.grid;
+    constexpr int PTP = PT + 1;
+    double* chi = lds;
+    double* gx = chi + (size_t)n * PTP;
+    double* gy = gx + (size_t)n * PTP;
+    double* gz = gy + (size_t)n * PTP;
+    double* X = gz + (size_t)n * PTP;
+    double* A = X + (size_t)n * PTP;
+    double* pw = A + (size_t)n * PTP;                 // [PT] weights
+    double* pc = pw + PT;                             // [5][PT]: w v_rho / 2, w c_x, w c_y, w c_z, w v_tau / 4
+
+    const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
+    const double* __restrict__ D = bv.D + (size_t)f * n * n;
+    const double* __restrict__ wts = gd.weights + (size_t)f * gd.npts;
+
+    double acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = 0.0;
+    double e_acc = 0.0, n_acc = 0.0;
+
+    const int ntiles = (gd.npts + PT - 1) / PT;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int g0 = tile * PT;
+        for (int idx = tid; idx < tp.ngroup * PT; idx += XC_NT) {
+            const int rg = idx / PT, p = idx - rg * PT;
+            const int g = g0 + p;
+            if (g < gd.npts) {
+                const int oa = gd.pt_atom[g], it = gd.pt_tmpl[g];
+                eval_group<true>(tp, xyz, rg, xyz[3 * oa] + gd.tmpl_xyz[3 * it], xyz[3 * oa + 1] + gd.tmpl_xyz[3 * it + 1],
+                                 xyz[3 * oa + 2] + gd.tmpl_xyz[3 * it + 2], chi, gx, gy, gz, PTP, p, bv.c2s);
+            } else {
+                zero_group<true>(tp, rg, chi, gx, gy, gz, PTP, p);
+            }
+        }
+        if (tid < PT) pw[tid] = (g0 + tid < gd.npts) ? wts[g0 + tid] : 0.0;
+        double rho = 0.0, gr[3] = {0.0, 0.0, 0.0}, tau = 0.0;
+        for (int pass = 0; pass < 4; ++pass) {
+            const double* __restrict__ src = pass == 0 ? chi : pass == 1 ? gx : pass == 2 ? gy : gz;
+            __syncthreads();
+            for (int idx = tid; idx < n * PT; idx += XC_NT) {
+                const int mu = idx / PT, p = idx - mu * PT;
+                const double* __restrict__ dr = D + (size_t)mu * n;
+                double sum = 0.0;
+                for (int nu = 0; nu < n; ++nu) sum += dr[nu] * src[nu * PTP + p];
+                X[mu * PTP + p] = sum;
+            }
+            __syncthreads();
+            if (tid < PT) {
+                const int p = tid;
+                if (pass == 0) {
+                    for (int mu = 0; mu < n; ++mu) {
+                        const double x = X[mu * PTP + p];
+                        rho += x * chi[mu * PTP + p];
+                        gr[0] += x * gx[mu * PTP + p]; gr[1] += x * gy[mu * PTP + p]; gr[2] += x * gz[mu * PTP + p];
+                    }
+                } else {
+                    double t = 0.0;
+                    for (int mu = 0; mu < n; ++mu) t += X[mu * PTP + p] * src[mu * PTP + p];
+                    tau += 0.5 * t;
+                }
+            }
+        }
+        if (tid < PT) {
+            const int p = tid;
+            for (int d = 0; d < 3; ++d) gr[d] *= 2.0;
+            const double sigma = gr[0] * gr[0] + gr[1] * gr[1] + gr[2] * gr[2];
+            double fx, dv[3];
+            eval_functional_mgga(bv.xc, rho, sigma, tau, fx, dv);
+            const double w = pw[p];
+            e_acc += w * fx;
+            n_acc += w * rho;
+            pc[p] = 0.5 * w * dv[0];
+            for (int d = 0; d < 3; ++d) pc[(1 + d) * PT + p] = w * 2.0 * dv[1] * gr[d];
+            pc[4 * PT + p] = 0.25 * w * dv[2];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < n * PT; idx += XC_NT) {
+            const int mu = idx / PT, p = idx - mu * PT;
+            A[mu * PTP + p] = pc[p] * chi[mu * PTP + p] + pc[PT + p] * gx[mu * PTP + p] + pc[2 * PT + p] * gy[mu * PTP + p]
+                            + pc[3 * PT + p] * gz[mu * PTP + p];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int idx = tid + XC_NT * k;
+            if (idx < n * n) {
+                const int mu = idx / n, nu = idx - mu * n;
+                const double* __restrict__ ar = A + mu * PTP;
+                const double* __restrict__ cr = chi + nu * PTP;
+                double sum = 0.0;
+#pragma unroll 4
+                for (int p = 0; p < PT; ++p)
+                    sum += ar[p] * cr[p] + pc[4 * PT + p] * (gx[mu * PTP + p] * gx[nu * PTP + p] + gy[mu * PTP + p] * gy[nu * PTP + p]
+                                                             + gz[mu * PTP + p] * gz[nu * PTP + p]);
+                acc[k] += sum;
+            }
+        }
+        __syncthreads();
+    }
+    double* Vx = bv.Vxc + (size_t)f * n * n;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int idx = tid + XC_NT * k;
+        if (idx < n * n && acc[k] != 0.0) atomicAdd(&Vx[idx], acc[k]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { e_acc += __shfl_down(e_acc, off, 64); n_acc += __shfl_down(n_acc, off, 64); }
+    if (tid == 0) {
+        atomicAdd(&bv.scal[(size_t)f * 8 + 5], e_acc);
+        atomicAdd(&bv.scal[(size_t)f * 8 + 6], n_acc);
+    }
+}
+
+template <int PT, int NV>
+static void xc_mgga_launch(const BatchView& bv, int oa, hipStream_t s)
+{
+    const int n = bv.n;
+    const size_t lds = sizeof(double) * ((size_t)6 * n * (PT + 1) + 6 * PT + 16);
+    auto kern = xc_mgga_kernel<PT, NV>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int ntiles = (bv.grid.npts + PT - 1) / PT;
+    int gx = (8192 + bv.nfrag - 1) / bv.nfrag;
+    if (gx > ntiles) gx = ntiles;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(kern, dim3(gx, bv.nfrag), dim3(XC_NT), lds, s, bv, oa);
+}
+
 void launch_xc(const BatchView& bv, bool only_active, hipStream_t s)
 {
     const int n = bv.n, oa = only_active ? 1 : 0;
     (void)hipMemsetAsync(bv.Vxc, 0, sizeof(double) * (size_t)bv.nfrag * n * n * (bv.uhf ? 2 : 1), s);
     hipLaunchKernelGGL(xc_reset_kernel, dim3((bv.nfrag + 255) / 256), dim3(256), 0, s, bv);
     const bool gga = bv.xc.gga != 0;
+    if (bv.xc.gga == 2) {
+        // meta-GGA (restricted, n <= 140: validate_options refuses the rest): 16-point tiles, LDS 6 n 17 doubles <= 114 KB
+        const int nv = (n * n + XC_NT - 1) / XC_NT;
+        if (nv <= 10) xc_mgga_launch<16, 10>(bv, oa, s);
+        else if (nv <= 29) xc_mgga_launch<16, 29>(bv, oa, s);
+        else if (nv <= 54) xc_mgga_launch<16, 54>(bv, oa, s);
+        else xc_mgga_launch<16, 77>(bv, oa, s);
+        return;
+    }
     if (bv.uhf) {
         // n <= 116 (the in-core path UHF runs on): 16-point tiles, GGA LDS 7 n 17 doubles <= 110 KB
         const int nv = (n * n + XC_NT - 1) / XC_NT;

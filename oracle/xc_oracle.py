@@ -12,7 +12,8 @@ The functional arithmetic lives in libxc 7.1.2 (third party, absent from /root/r
 CMakeLists.txt:387-392).  Its published closed forms are restated here for the unpolarised case
 (lda_x, lda_c_vwn, lda_c_vwn_rpa, gga_x_b88, gga_c_lyp, gga_x_pbe, gga_c_pbe with lda_c_pw_mod)
 with derivatives by forward-mode dual numbers, and pinned by the reference's KS goldens
-(validation/validation_tests_cpu.json: SVWN, PBE, B3LYP, PBE0 on H2O/cc-pVDZ, PBE on CH4).
+(validation/validation_tests_cpu.json: SVWN, PBE, B3LYP, PBE0 on H2O/cc-pVDZ, PBE on CH4), plus the meta-GGA
+mgga_x_tpss + mgga_c_tpss pair (restricted only) pinned by the TPSS row of the same manifest.
 """
 from __future__ import annotations
 
@@ -392,6 +393,91 @@ def eval_functional_pol(name: str, ra, rb, saa, sab, sbb):
     return np.where(ok, f, z), [np.where(ok, t, z) for t in dv]
 
 
+# ------------------------------------------------------------------ meta-GGA: TPSS (unpolarised), variables (rho, sigma, tau)
+# libxc 7.1.2 mgga_x_tpss / mgga_c_tpss, i.e. Tao, Perdew, Staroverov, Scuseria, PRL 91, 146401 (2003) eqs. 5-14, with
+# libxc's parameters (b 0.40, c 1.59096, e 1.537, kappa 0.804, mu 0.21951; d 2.8, C(0,0) 0.53, PBE beta and lda_c_pw_mod
+# inside the correlation).  tau = 1/2 sum_i n_i |grad phi_i|^2 (mqc_libcint_ao.f90:374-417).
+TAU_THRESHOLD = 1.0e-20
+
+
+def _where(c, a, b):
+    return DualN(np.where(c, a.v, b.v), [np.where(c, x, y) for x, y in zip(a.d, b.d)])
+
+
+def mgga_x_tpss(rho, sigma, tau):
+    b, c, e, kappa, mu = 0.40, 1.59096, 1.537, 0.804, 0.21951
+    mu_ge = 10.0 / 81.0
+    p = sigma / (4.0 * (3.0 * math.pi ** 2) ** (2.0 / 3.0) * rho ** (8.0 / 3.0))
+    z = sigma / (8.0 * rho * tau)
+    tau_unif = 0.3 * (3.0 * math.pi ** 2) ** (2.0 / 3.0) * rho ** (5.0 / 3.0)
+    alpha = (tau - sigma / (8.0 * rho)) / tau_unif
+    qb = 0.45 * (alpha - 1.0) / nsqrt(1.0 + b * alpha * (alpha - 1.0)) + (2.0 / 3.0) * p
+    z2 = z * z
+    num = ((mu_ge + c * z2 / ((1.0 + z2) * (1.0 + z2))) * p + (146.0 / 2025.0) * qb * qb
+           - (73.0 / 405.0) * qb * nsqrt(0.5 * (0.36 * z2 + p * p)) + (mu_ge * mu_ge / kappa) * p * p
+           + 2.0 * math.sqrt(e) * mu_ge * 0.36 * z2 + e * mu * p * p * p)
+    den = (1.0 + math.sqrt(e) * p) * (1.0 + math.sqrt(e) * p)
+    x = num / den
+    fx = 1.0 + kappa - kappa / (1.0 + x / kappa)
+    return -0.75 * (3.0 / math.pi) ** (1.0 / 3.0) * rho ** (4.0 / 3.0) * fx
+
+
+def _pbe_c_eps_fixed_zeta(rho, sigma, ferro: bool):
+    """PBE correlation energy PER PARTICLE at zeta = 0 or zeta = 1 (no zeta derivative is needed at either end)."""
+    rs = (3.0 / (4.0 * math.pi)) ** (1.0 / 3.0) * rho ** (-1.0 / 3.0)
+    if ferro:
+        ec = _pw_mod_g(rs, 0.01554535, 0.20548, 14.1189, 6.1977, 3.3662, 0.62517)
+        phi = 2.0 ** (-1.0 / 3.0)
+    else:
+        ec = _pw_mod_g(rs, 0.0310907, 0.21370, 7.5957, 3.5876, 1.6382, 0.49294)
+        phi = 1.0
+    phi3 = phi ** 3
+    kf = (3.0 * math.pi ** 2) ** (1.0 / 3.0) * rho ** (1.0 / 3.0)
+    ks2 = 4.0 * kf / math.pi
+    t2 = sigma / (4.0 * phi * phi * ks2 * rho * rho)
+    A = (PBE_BETA / PBE_GAMMA) / (nexp(-ec / (PBE_GAMMA * phi3)) - 1.0)
+    at2 = A * t2
+    H = PBE_GAMMA * phi3 * nlog(1.0 + (PBE_BETA / PBE_GAMMA) * t2 * (1.0 + at2) / (1.0 + at2 + at2 * at2))
+    return ec + H
+
+
+def mgga_c_tpss(rho, sigma, tau):
+    d, C0 = 2.8, 0.53                      # C(zeta = 0, xi = 0)
+    z = sigma / (8.0 * rho * tau)
+    e_pbe = _pbe_c_eps_fixed_zeta(rho, sigma, False)
+    e_one = _pbe_c_eps_fixed_zeta(0.5 * rho, 0.25 * sigma, True)       # one spin channel on its own, fully polarised
+    e_til = _where(e_one.v > e_pbe.v, e_one, e_pbe)
+    z2 = z * z
+    e_rev = e_pbe * (1.0 + C0 * z2) - (1.0 + C0) * z2 * e_til
+    return rho * e_rev * (1.0 + d * e_rev * z2 * z)
+
+
+MGGA_FUNCTIONALS = {
+    "tpss": ([(1.0, mgga_x_tpss), (1.0, mgga_c_tpss)], 0.0),
+}
+
+
+RESTRICTED_FUNCTIONALS = set(FUNCTIONALS) | set(MGGA_FUNCTIONALS)      # what the restricted Kohn-Sham leg covers
+
+
+def eval_functional_mgga(name: str, rho, sigma, tau):
+    """-> f per volume, v_rho, v_sigma, v_tau; zero where rho is below the threshold."""
+    comps, _ = MGGA_FUNCTIONALS[name.lower()]
+    ok = rho > DENS_THRESHOLD
+    r = np.where(ok, rho, 1.0)
+    s = np.where(ok, np.maximum(sigma, 1.0e-40), 1.0e-40)
+    t = np.where(ok, np.maximum(tau, TAU_THRESHOLD), 1.0)
+    V = [DualN.var(x, i, 3) for i, x in enumerate((r, s, t))]
+    f = 0.0
+    dv = [0.0] * 3
+    for wgt, fn in comps:
+        q = fn(*V)
+        f = f + wgt * q.v
+        dv = [a + wgt * b for a, b in zip(dv, q.d)]
+    zz = np.zeros_like(rho)
+    return np.where(ok, f, zz), np.where(ok, dv[0], zz), np.where(ok, dv[1], zz), np.where(ok, dv[2], zz)
+
+
 @dataclass
 class XCOracle:
     """`xc` object for scf_oracle.run_rhf: .exx and .potential(D) -> (E_xc, V_xc)."""
@@ -401,7 +487,12 @@ class XCOracle:
     block: int = 4096          # AO_POINT_BLOCK, mqc_libcint_ao.f90:47
 
     def __post_init__(self):
-        self.comps, self.exx, self.gga = FUNCTIONALS[self.name.lower()]
+        self.mgga = self.name.lower() in MGGA_FUNCTIONALS
+        if self.mgga:
+            self.comps, self.exx = MGGA_FUNCTIONALS[self.name.lower()]
+            self.gga = True
+        else:
+            self.comps, self.exx, self.gga = FUNCTIONALS[self.name.lower()]
         numbers = [int(round(z)) for z in self.mol.z]
         self.pts, self.w, self.owner = grid_oracle.build_grid(numbers, self.mol.xyz, self.level)
         self.n_electrons = 0.0
@@ -424,7 +515,15 @@ class XCOracle:
                 sigma = np.einsum("dp,dp->p", grho, grho)
             else:
                 sigma = np.zeros_like(rho)
-            f, vr, vs = eval_functional(self.name, rho, sigma)
+            if self.mgga:
+                # tau = 1/2 sum_d rowdot(d_d chi D, d_d chi); V += 1/2 sum_d (w v_tau d_d chi)^T d_d chi
+                # (eval_rho, mqc_libcint_ao.f90:403-417; accumulate_xc_matrix, mqc_libcint_xc.F90:1436-1448)
+                tau = 0.5 * sum(np.einsum("pi,pi->p", g[k] @ D, g[k]) for k in range(3))
+                f, vr, vs, vt = eval_functional_mgga(self.name, rho, sigma, tau)
+                for k in range(3):
+                    V += 0.5 * (g[k] * (w * vt)[:, None]).T @ g[k]
+            else:
+                f, vr, vs = eval_functional(self.name, rho, sigma)
             exc += float(np.dot(w, f)); nel += float(np.dot(w, rho))
             V += (ao * (w * vr)[:, None]).T @ ao
             if self.gga:

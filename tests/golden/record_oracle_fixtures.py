@@ -1,6 +1,6 @@
 """Records the slow oracle results of tests/test_gpu_workloads.py into tests/golden/oracle_fixtures.json.
 
-    python tests/golden/record_oracle_fixtures.py [case ...]        # cases: fmo_df_rks gmbe (default: all)
+    python tests/golden/record_oracle_fixtures.py [case ...]        # cases: fmo_df_rks gmbe tpss (default: all)
 
 CPU only: the oracle is numpy + oracle/liboracle_ints.so; nothing here touches the engine.  The keys are those the
 tests compute (label + digest of geometry and settings), so a changed input can never pick up a stale record."""
@@ -18,7 +18,7 @@ from tests import helpers, workload_cases as wc      # noqa: E402
 
 
 def main(argv):
-    want = set(argv) or {"fmo_df_rks", "gmbe"}
+    want = set(argv) or {"fmo_df_rks", "gmbe", "tpss"}
     path = helpers._FIXTURE_PATH
     cur = json.load(open(path)) if os.path.isfile(path) else {}
     if "fmo_df_rks" in want:
@@ -39,6 +39,13 @@ def main(argv):
             t0 = time.time()
             cur[key] = wc.gmbe_fragment_oracle(f)
             print(key, cur[key]["energy"], "%.0f s" % (time.time() - t0), flush=True)
+    if "tpss" in want:
+        for df in (False, True):
+            for f in wc.tpss_fragments():
+                key = helpers._fixture_key("tpss_water_batch", f, wc.TPSS_KEY % ("df:" + wc.AUX if df else "exact"))
+                t0 = time.time()
+                cur[key] = wc.tpss_oracle(f, df)
+                print(key, cur[key]["energy"], "%.0f s" % (time.time() - t0), flush=True)
     with open(path, "w") as f:
         json.dump(cur, f, indent=1, sort_keys=True)
 

@@ -477,7 +477,7 @@ from metalquicha_amd.basis import ANGSTROM_TO_BOHR, SYMBOL_TO_Z
 from oracle import xc_oracle
 
 _CASES = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "manifest_subset.json")))["cases"]
-_KS = [c for c in _CASES if c["method"] == "dft" and c["functional"] in xc_oracle.FUNCTIONALS and "grid 3" in c["name"]
+_KS = [c for c in _CASES if c["method"] == "dft" and c["functional"] in xc_oracle.RESTRICTED_FUNCTIONALS and "grid 3" in c["name"]
        and not c["unrestricted"] and not c["density_fitting"]]
 _RHF = [c for c in _CASES if c["method"] == "hf" and "mbe_level" not in c and c["driver"] == "Energy" and not c["unrestricted"]
         and not c["density_fitting"] and "*" not in c["basis"]]        # Pople star sets are Cartesian: refused, tested below

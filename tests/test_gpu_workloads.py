@@ -1,6 +1,7 @@
 """GPU parity tests of BASELINE.json's larger configurations at reduced size, with the METHOD each one names:
 
   configs[3]  GMBE-2 B3LYP/def2-TZVP with the XC grid kernel   -> gmbe.run_gmbe(level=2) on (H2O)3, f shells, n = 43 / 86
+  meta-GGA    TPSS, exact and density-fitted Coulomb              -> a water and a water dimer in one batch
   configs[4]  512-fragment FMO-2 DF-RKS                          -> fmo.run_fmo2 with density fitting AND a functional on
                                                                     (H2O)8 against the oracle's driver, and a c5-SHAPED
                                                                     27-fragment run checked through properties
@@ -119,3 +120,26 @@ def test_gmbe2_b3lyp_def2_tzvp_matches_per_fragment_oracle():
     assert abs(run.total - total) < 3e-8
     # non-overlapping monomers: GMBE(2) is MBE(2) (c_dimer = 1, c_monomer = 2 - N)
     assert sorted(int(round(c)) for c in run.coefficients) == [-1, -1, -1, 1, 1, 1]
+
+
+@pytest.mark.parametrize("df", [False, True], ids=["exact", "density-fitted"])
+def test_tpss_batch_matches_oracle(df):
+    """Meta-GGA leg (tau in the density, the v_tau term in the potential; mqc_libcint_xc.F90:1436-1448): TPSS on a
+    water and a water dimer in one batch against the oracle, whose TPSS is pinned by the reference's own
+    -76.422747225964 (tests/test_oracle_golden.py)."""
+    frags = wc.tpss_fragments()
+    res = methods.run_hip_scf_batch(wc.tpss_settings(df), frags)
+    for f, r in zip(frags, res):
+        assert not r.has_error, r.error_message
+        o = recorded_oracle("tpss_water_batch", f, wc.TPSS_KEY % ("df:" + wc.AUX if df else "exact"),
+                                    lambda f=f: wc.tpss_oracle(f, df))
+        assert o["converged"]
+        assert abs(r.energy.scf - o["energy"]) < 1e-8, (r.energy.scf, o["energy"])
+
+
+def test_tpss_refusals_name_what_is_missing():
+    w = wc.tpss_fragments()[0]
+    r = methods.run_hip_scf(methods.ScfSettings(basis_set="sto-3g", functional="tpss", unrestricted=True), w)
+    assert r.has_error and "restricted" in r.error_message
+    r = methods.run_hip_scf(methods.ScfSettings(basis_set="sto-3g", functional="tpss"), w, want_gradient=True)
+    assert r.has_error and "gradient" in r.error_message

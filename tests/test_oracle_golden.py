@@ -121,7 +121,7 @@ _CASES = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "manif
 _RHF = [c for c in _CASES if c["method"] == "hf" and "mbe_level" not in c and c["driver"] == "Energy"
         and not c["unrestricted"] and not c["density_fitting"]]
 _DF = [c for c in _CASES if c["method"] == "hf" and c["density_fitting"] and c["driver"] == "Energy" and not c["unrestricted"]]
-_KS = [c for c in _CASES if c["method"] == "dft" and c["functional"] in xc_oracle.FUNCTIONALS and "grid 3" in c["name"]
+_KS = [c for c in _CASES if c["method"] == "dft" and c["functional"] in xc_oracle.RESTRICTED_FUNCTIONALS and "grid 3" in c["name"]
        and not c["unrestricted"] and not c["density_fitting"]]
 
 
@@ -172,8 +172,9 @@ def test_grid_matches_reference_counts():
 
 @pytest.mark.parametrize("case", _KS, ids=[c["name"] for c in _KS])
 def test_manifest_kohn_sham(case):
-    """KS goldens (SVWN, PBE, B3LYP, PBE0 on H2O; PBE on CH4), tolerance 1e-9: pins the grid and the
-    restated libxc functionals (lda_x, vwn5, vwn_rpa, b88, lyp, pbe x/c with pw_mod)."""
+    """KS goldens (SVWN, PBE, B3LYP, PBE0, TPSS on H2O; PBE on CH4), tolerance 1e-9: pins the grid and the
+    restated libxc functionals (lda_x, vwn5, vwn_rpa, b88, lyp, pbe x/c with pw_mod, tpss x/c with tau and the
+    v_tau term of the potential)."""
     frag, mol = _mol(case)
     xc = xc_oracle.XCOracle(mol, case["functional"], case["grid_level"])
     r = so.run_rhf(mol, int(frag.nelec), case["maxiter"], 1e-10, 1e-7, xc=xc)
@@ -234,6 +235,29 @@ def test_functional_derivatives_by_finite_differences():
         sig = np.abs(vs) * sigma > 1e-5 * np.abs(f)          # where the sigma derivative is resolvable by differences
         assert sig.sum() > 50
         assert np.max((np.abs((fp - fm) / (2 * h * sigma) - vs) / np.abs(vs))[sig]) < 1e-4
+
+
+def test_meta_gga_derivatives_by_finite_differences():
+    rng = np.random.default_rng(5)
+    rho = 10.0 ** rng.uniform(-4, 1.5, size=300)
+    tau_w_ratio = rng.uniform(0.02, 0.98, size=300)               # z = tau_W / tau stays inside (0, 1)
+    sigma = (rho ** (4.0 / 3.0) * 10.0 ** rng.uniform(-2, 1, size=300)) ** 2
+    tau = sigma / (8.0 * rho) / tau_w_ratio
+    f, vr, vs, vt = xc_oracle.eval_functional_mgga("tpss", rho, sigma, tau)
+    h = 1e-6
+    for k, (x, v) in enumerate(((rho, vr), (sigma, vs), (tau, vt))):
+        args_p = [rho, sigma, tau]; args_m = [rho, sigma, tau]
+        args_p[k] = x * (1 + h); args_m[k] = x * (1 - h)
+        fp = xc_oracle.eval_functional_mgga("tpss", *args_p)[0]
+        fm = xc_oracle.eval_functional_mgga("tpss", *args_m)[0]
+        num = (fp - fm) / (2 * h * x)
+        big = np.abs(v) * x > 1e-5 * np.abs(f)
+        assert big.sum() > 100
+        assert np.max((np.abs(num - v) / np.abs(v))[big]) < 1e-4
+    # the uniform-gas limit: no gradient, tau = tau_unif -> TPSS exchange is LDA exchange with F_x(p = 0, z = 0, alpha = 1) = 1
+    r = np.array([0.3, 2.0]); tu = 0.3 * (3 * np.pi ** 2) ** (2 / 3) * r ** (5 / 3)
+    V = [xc_oracle.DualN.var(x, i, 3) for i, x in enumerate((r, np.full(2, 1e-40), tu))]
+    assert np.allclose(xc_oracle.mgga_x_tpss(*V).v, -0.75 * (3 / np.pi) ** (1 / 3) * r ** (4 / 3), rtol=1e-12)
 
 
 def test_recorded_fixtures_spot_check_against_the_live_oracle():

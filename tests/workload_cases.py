@@ -63,3 +63,28 @@ def gmbe_fragment_oracle(frag):
     from tests.helpers import oracle_mol, scf_record
     mol = oracle_mol("def2-tzvp", frag)
     return scf_record(so.run_rhf(mol, int(frag.nelec), 100, 1e-9, 1e-7, xc=xc_oracle.XCOracle(mol, "b3lyp", 3)))
+
+
+# ---- meta-GGA: TPSS on a water and a water dimer, cc-pVDZ, exact and density-fitted Coulomb -------------------------------
+TPSS_KEY = "cc-pvdz|tpss|%s|grid3|1e-9|1e-7|gwh"
+
+
+def tpss_fragments():
+    from tests.helpers import fragment_bohr, water_at
+    rng = np.random.default_rng(21)
+    ws = [water_at(rng, c) for c in ([0, 0, 0], [5.3, 0.4, -0.2])]
+    return [fragment_bohr([8, 1, 1], ws[0]), fragment_bohr([8, 1, 1, 8, 1, 1], np.vstack(ws))]
+
+
+def tpss_settings(df):
+    return ScfSettings(basis_set="cc-pvdz", functional="tpss", density_fitting=df, aux_basis_set=AUX if df else "",
+                       energy_tol=1e-9, density_tol=1e-7, guess="gwh")
+
+
+def tpss_oracle(frag, df):
+    from oracle import scf_oracle, xc_oracle
+    from tests.helpers import oracle_mol, scf_record
+    mol = oracle_mol("cc-pvdz", frag)
+    aux = oracle_mol(AUX, frag) if df else None
+    o = scf_oracle.run_rhf(mol, int(frag.nelec), 100, 1e-9, 1e-7, aux=aux, xc=xc_oracle.XCOracle(mol, "tpss", 3))
+    return scf_record(o)
