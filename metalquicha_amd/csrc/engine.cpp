@@ -21,8 +21,8 @@
 namespace mqc {
 const std::string& last_error_string();
 void eri_plan_lists(const BatchView& bv, const Topology& topo, hipStream_t s, const double* host_xyz);   // kern_eri.hip
-bool launch_gradient(const BatchView& bv, const Topology& topo, double* d_grad, double* work, int* d_lists, size_t list_capacity_ints,
-                     hipStream_t s, std::string& err);                                                      // kern_grad.hip
+bool launch_gradient(const BatchView& bv, const Topology& topo, const Topology* aux, double* d_grad, double* work, int* d_lists,
+                     size_t list_capacity_ints, hipStream_t s, std::string& err);                                                      // kern_grad.hip
 void launch_scale(double* p, size_t count, double f, hipStream_t s);      // kern_df.hip
 void launch_jk_direct_incremental(const BatchView& bv, const Topology& topo, double thresh, bool only_active, hipStream_t s);   // kern_eri.hip
 static DevicePool g_grad_pool[2];
@@ -249,7 +249,6 @@ static int validate_options(const mqc_hip_scf_options_t& o, const Topology& topo
         XcSpec tg; std::string eg;
         parse_functional(o.functional, tg, eg);
         if (tg.gga == 2) { msg = "analytic gradients of meta-GGA functionals are not built (energies only)"; return MQC_HIP_ERR_UNSUPPORTED; }
-        if (o.density_fitting) { msg = "analytic gradients are available on the exact-ERI path; the density-fitted two-electron derivative is not built yet"; return MQC_HIP_ERR_UNSUPPORTED; }
         if (topo.lmax > 2) { msg = "analytic gradients cover s, p and d shells"; return MQC_HIP_ERR_UNSUPPORTED; }
     }
     // restricted iff multiplicity 1, even electron count and not forced (mqc_cuest_driver.f90:127)
@@ -740,7 +739,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
             double* gwork = d_grad + (((size_t)nf * topo.natoms * 3 + 7) & ~size_t(7));
             int* glists = (int*)(gwork + 2 * (size_t)nf * nnh);
             std::string gerr;
-            if (!launch_gradient(bv, topo, d_grad, gwork, glists, lint, s, gerr)) return fail(MQC_HIP_ERR_UNSUPPORTED, gerr);
+            if (!launch_gradient(bv, topo, aux, d_grad, gwork, glists, lint, s, gerr)) return fail(MQC_HIP_ERR_UNSUPPORTED, gerr);
             hgrad.resize((size_t)nf * topo.natoms * 3);
             HIP_CHECK_RET(hipMemcpyAsync(hgrad.data(), d_grad, sizeof(double) * hgrad.size(), hipMemcpyDeviceToHost, s));
         }

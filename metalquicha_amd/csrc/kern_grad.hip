@@ -352,10 +352,29 @@ __global__ void __launch_bounds__(64) grad1e_kernel(BatchView bv, int la, int lb
 // Two-electron term: wave = (unique shell quartet, fragment).
 struct Grad2eLayout { int e_ab, e_cd, r0, r1, tuv, fb, gc, tmp, g0, gp, gm, total; };
 
+// The "function" 1 as a one-primitive s shell: exponent 0, coefficient 1.  With it in the fourth (or second and fourth)
+// slot the quartet routine below differentiates the three- and two-centre Coulomb integrals of density fitting:
+// (ab|P) = (ab|P 1), (P|Q) = (P 1|Q 1); the unit shell sits on its partner's atom, so the force the quartet routine
+// hands it by translational invariance lands where it belongs.
+__device__ const double g_unit_shell[2] = {0.0, 1.0};
+__device__ __forceinline__ ShellRef unit_shell_at(const ShellRef& at)
+{
+    ShellRef r;
+    r.nprim = 1; r.exps = &g_unit_shell[0]; r.coefs = &g_unit_shell[1];
+    r.x = at.x; r.y = at.y; r.z = at.z;
+    return r;
+}
+
+// mode GRAD_EXACT: list = unique orbital quartets, Gamma from the densities (header of this file).
+// mode GRAD_DF3C:  list = (A >= B orbital, P auxiliary, -): Gamma = w gam3[P][ab], w = 1 (A == B) or 2.
+// mode GRAD_DF2C:  list = (P >= Q auxiliary as A and C):     Gamma = w gam2[P][Q],  w = 1 (P == Q) or 2.
+enum : int { GRAD_EXACT = 0, GRAD_DF3C = 1, GRAD_DF2C = 2 };
+
 __global__ void __launch_bounds__(64) eri_grad_kernel(BatchView bv, int la, int lb, int lc, int ld, Grad2eLayout lay,
                                                       const int* __restrict__ list, int nq, const double* __restrict__ Dtot,
                                                       const double* __restrict__ Dbeta /* nullptr: restricted */,
-                                                      double* __restrict__ grad)
+                                                      double* __restrict__ grad, int mode = GRAD_EXACT,
+                                                      const double* __restrict__ gam = nullptr /* [nfrag][naux][n*n] or [nfrag][naux][naux] */)
 {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
@@ -363,9 +382,16 @@ __global__ void __launch_bounds__(64) eri_grad_kernel(BatchView bv, int la, int 
     const int iq = (int)(t / bv.nfrag), f = (int)(t % bv.nfrag);
     const int A = list[4 * iq], B = list[4 * iq + 1], C = list[4 * iq + 2], D = list[4 * iq + 3];
     const TopologyDev& tp = bv.topo;
+    const TopologyDev& tx = bv.aux;
     const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
-    const ShellRef sa = make_shell(tp, xyz, A), sb = make_shell(tp, xyz, B), sc = make_shell(tp, xyz, C), sd = make_shell(tp, xyz, D);
-    const int atA = tp.sh_atom[A], atB = tp.sh_atom[B], atC = tp.sh_atom[C], atD = tp.sh_atom[D];
+    const ShellRef sa = mode == GRAD_DF2C ? make_shell(tx, xyz, A) : make_shell(tp, xyz, A);
+    const ShellRef sc = mode == GRAD_EXACT ? make_shell(tp, xyz, C) : make_shell(tx, xyz, C);
+    const ShellRef sb = mode == GRAD_DF2C ? unit_shell_at(sa) : make_shell(tp, xyz, B);
+    const ShellRef sd = mode == GRAD_EXACT ? make_shell(tp, xyz, D) : unit_shell_at(sc);
+    const int atA = mode == GRAD_DF2C ? tx.sh_atom[A] : tp.sh_atom[A];
+    const int atC = mode == GRAD_EXACT ? tp.sh_atom[C] : tx.sh_atom[C];
+    const int atB = mode == GRAD_DF2C ? atA : tp.sh_atom[B];
+    const int atD = mode == GRAD_EXACT ? tp.sh_atom[D] : atC;
     if (atA == atB && atB == atC && atC == atD) return;          // one centre: translational invariance, no force
     const int nca = ncart(la), ncb = ncart(lb), ncc = ncart(lc), ncd = ncart(ld);
     const int nsa = nsph(la), nsb = nsph(lb), nsc = nsph(lc), nsd = nsph(ld);
@@ -391,11 +417,25 @@ __global__ void __launch_bounds__(64) eri_grad_kernel(BatchView bv, int la, int 
     const size_t nn = (size_t)n * n;
     const double* Dt = Dtot + f * nn;
     const double* Db = Dbeta ? Dbeta + f * nn : nullptr;
-    const int oa = tp.sh_aoff[A], ob = tp.sh_aoff[B], oc = tp.sh_aoff[C], od = tp.sh_aoff[D];
+    const int oa = mode == GRAD_DF2C ? tx.sh_aoff[A] : tp.sh_aoff[A], ob = mode == GRAD_DF2C ? 0 : tp.sh_aoff[B];
+    const int oc = mode == GRAD_EXACT ? tp.sh_aoff[C] : tx.sh_aoff[C], od = mode == GRAD_EXACT ? tp.sh_aoff[D] : 0;
 
     gr_fill_tuv(LR, tuv, lane);
     // ---- Gamma block in the spherical basis (into TMP), then four index transforms to Cartesian (-> GC)
-    {
+    if (mode != GRAD_EXACT) {
+        const int na = bv.naux;
+        const double w = (mode == GRAD_DF3C ? A == B : A == C) ? 1.0 : 2.0;
+        const double* g3 = gam + (size_t)f * na * (mode == GRAD_DF3C ? nn : (size_t)na);
+        for (int idx = lane; idx < nsa * nsb * nsc; idx += 64) {          // nsd = 1
+            int r = idx;
+            const int k = r % nsc; r /= nsc;
+            const int j = r % nsb;
+            const int i = r / nsb;
+            GC[idx] = w * (mode == GRAD_DF3C ? g3[(size_t)(oc + k) * nn + (size_t)(oa + i) * n + ob + j]
+                                             : g3[(size_t)(oa + i) * na + oc + k]);
+        }
+        __syncthreads();
+    } else {
         const double sab = (A == B) ? 1.0 : 2.0, scd = (C == D) ? 1.0 : 2.0;
         const bool same = (A == C && B == D) || (A == D && B == C);
         const double w = sab * scd * (same ? 1.0 : 2.0) / 8.0;
@@ -418,6 +458,8 @@ __global__ void __launch_bounds__(64) eri_grad_kernel(BatchView bv, int la, int 
             GC[idx] = w * g;
         }
         __syncthreads();
+    }
+    {
         // sph -> cart on one index: out[pre][nc][post] = sum_s coef(s, c) in[pre][ns][post]
         auto stage = [&](int l, int pre, int post, const double* in, double* out) {
             const int nc = ncart(l), ns = nsph(l);
@@ -575,6 +617,128 @@ __global__ void __launch_bounds__(64) eri_grad_kernel(BatchView bv, int la, int 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Density-fitted two-electron gradient (the reference GPU backend's own gradient is density-fitted:
+// compute_scf_gradient, backends/cuest/backend/mqc_cuest_gradient.f90:91-175; the CPU formulation it is checked
+// against is df_gradient of backends/libcint/mqc_libcint_gradient.f90).  With the fit B = W A3 (W = L^{-1} or
+// J^{-1/2}; W^T W = J^{-1}), fitted coefficients C^P = sum_Q W_QP B^Q and c = W^T (B . D):
+//     E_2e' = sum_{P, mu nu} Gam^P_{mu nu} (mu nu|P)'  -  1/2 sum_{PQ} gam_PQ (P|Q)'
+//     Gam^P = Dt c_P - x Z^P,      Z^P = sum_Q W_QP Y^Q,   Y^Q = sum_spin D_s B^Q D_s
+//     gam   = c c^T  - x sum_{mu nu} C^P_{mu nu} Z^Q_{mu nu}
+// x = exx (unrestricted, spin densities) or exx / 2 with D_s := D (restricted: two spins of D/2 each).
+// Parity-first arithmetic on the vector units: a gradient is one evaluation per geometry, not per SCF iteration.
+__device__ __forceinline__ double dfg_b(const double* __restrict__ Bq, int i, int j)
+{
+    return i >= j ? Bq[i * (i + 1) / 2 + j] : Bq[j * (j + 1) / 2 + i];
+}
+
+// c_P = sum_Q W[Q][P] g_Q,  g_Q = sum_pairs B[Q][pair] (2 - delta) Dt[pair]; one workgroup per fragment
+__global__ void __launch_bounds__(256) dfg_coef_kernel(BatchView bv, const double* __restrict__ Dtot, double* __restrict__ cvec)
+{
+    extern __shared__ double g[];            // [na]
+    const int f = blockIdx.x, n = bv.n, na = bv.naux, np = bv.npair, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const double* __restrict__ Dt = Dtot + (size_t)f * n * n;
+    const double* __restrict__ B = bv.df_b + (size_t)f * na * (size_t)np;
+    const double* __restrict__ W = bv.df_linv + (size_t)f * na * na;
+    const bool full = bv.scal[(size_t)f * 8 + 7] == 2.0;
+    for (int q = wave; q < na; q += 4) {
+        double sum = 0.0;
+        for (int pr = lane; pr < np; pr += 64) {
+            int k = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
+            while ((k + 1) * (k + 2) / 2 <= pr) ++k;
+            while (k * (k + 1) / 2 > pr) --k;
+            const int l = pr - k * (k + 1) / 2;
+            sum += B[(size_t)q * np + pr] * (k == l ? 1.0 : 2.0) * Dt[(size_t)k * n + l];
+        }
+        sum = wave_sum(sum);
+        if (lane == 0) g[q] = sum;
+    }
+    __syncthreads();
+    for (int p = tid; p < na; p += 256) {
+        double sum = 0.0;
+        for (int q = full ? 0 : p; q < na; ++q) sum += W[(size_t)q * na + p] * g[q];
+        cvec[(size_t)f * na + p] = sum;
+    }
+}
+
+// T^Q = B^Q D_s (pass 0) and Y^Q (+)= D_s T^Q (pass 1); thread per matrix element, grid (n*n/256, na, nfrag)
+__global__ void __launch_bounds__(256) dfg_half_kernel(BatchView bv, const double* __restrict__ Ds, double* __restrict__ T)
+{
+    const int f = blockIdx.z, q = blockIdx.y, n = bv.n, na = bv.naux, np = bv.npair;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * n) return;
+    const int i = idx / n, j = idx - i * n;
+    const double* __restrict__ Bq = bv.df_b + ((size_t)f * na + q) * (size_t)np;
+    const double* __restrict__ D = Ds + (size_t)f * n * n;
+    double sum = 0.0;
+    for (int k = 0; k < n; ++k) sum += dfg_b(Bq, i, k) * D[(size_t)k * n + j];
+    T[((size_t)f * na + q) * n * n + idx] = sum;
+}
+__global__ void __launch_bounds__(256) dfg_full_kernel(BatchView bv, const double* __restrict__ Ds, const double* __restrict__ T,
+                                                       double* __restrict__ Y, int accumulate)
+{
+    const int f = blockIdx.z, q = blockIdx.y, n = bv.n, na = bv.naux;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * n) return;
+    const int i = idx / n, j = idx - i * n;
+    const double* __restrict__ D = Ds + (size_t)f * n * n;
+    const double* __restrict__ Tq = T + ((size_t)f * na + q) * n * n;
+    double sum = 0.0;
+    for (int k = 0; k < n; ++k) sum += D[(size_t)i * n + k] * Tq[(size_t)k * n + j];
+    double* y = Y + ((size_t)f * na + q) * n * n + idx;
+    *y = accumulate ? *y + sum : sum;
+}
+
+// Z^P = sum_Q W[Q][P] Y^Q;  Gam^P = Dt c_P - x Z^P.  grid (n*n/256, na, nfrag)
+__global__ void __launch_bounds__(256) dfg_gamma_kernel(BatchView bv, const double* __restrict__ Dtot, const double* __restrict__ cvec,
+                                                        const double* __restrict__ Y, double x, double* __restrict__ Z,
+                                                        double* __restrict__ Gam)
+{
+    const int f = blockIdx.z, p = blockIdx.y, n = bv.n, na = bv.naux;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * n) return;
+    const double* __restrict__ W = bv.df_linv + (size_t)f * na * na;
+    const bool full = bv.scal[(size_t)f * 8 + 7] == 2.0;
+    const size_t nn = (size_t)n * n;
+    double z = 0.0;
+    for (int q = full ? 0 : p; q < na; ++q) z += W[(size_t)q * na + p] * Y[((size_t)f * na + q) * nn + idx];
+    Z[((size_t)f * na + p) * nn + idx] = z;
+    Gam[((size_t)f * na + p) * nn + idx] = Dtot[(size_t)f * nn + idx] * cvec[(size_t)f * na + p] - x * z;
+}
+
+// gam[P][Q] = c_P c_Q - x sum_{mu nu} C^P_{mu nu} Z^Q_{mu nu},  C^P = sum_R W[R][P] B^R; one wave per (P, Q), grid (na*na, nfrag)
+__global__ void __launch_bounds__(64) dfg_gamma2_kernel(BatchView bv, const double* __restrict__ cvec, const double* __restrict__ Cfit,
+                                                        const double* __restrict__ Z, double x, double* __restrict__ gam2)
+{
+    const int f = blockIdx.y, n = bv.n, na = bv.naux, np = bv.npair, lane = threadIdx.x;
+    const int p = blockIdx.x / na, q = blockIdx.x - p * na;
+    const double* __restrict__ Cp = Cfit + ((size_t)f * na + p) * (size_t)np;
+    const double* __restrict__ Zq = Z + ((size_t)f * na + q) * (size_t)n * n;
+    double sum = 0.0;
+    for (int idx = lane; idx < n * n; idx += 64) {
+        const int i = idx / n, j = idx - i * n;
+        sum += dfg_b(Cp, i, j) * Zq[idx];
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) gam2[((size_t)f * na + p) * na + q] = -0.5 * (cvec[(size_t)f * na + p] * cvec[(size_t)f * na + q] - x * sum);
+}
+
+// C^P[pair] = sum_R W[R][P] B^R[pair]; grid (npair/256, na, nfrag)
+__global__ void __launch_bounds__(256) dfg_cfit_kernel(BatchView bv, double* __restrict__ Cfit)
+{
+    const int f = blockIdx.z, p = blockIdx.y, na = bv.naux, np = bv.npair;
+    const int pr = blockIdx.x * 256 + threadIdx.x;
+    if (pr >= np) return;
+    const double* __restrict__ W = bv.df_linv + (size_t)f * na * na;
+    const double* __restrict__ B = bv.df_b + (size_t)f * na * (size_t)np;
+    const bool full = bv.scal[(size_t)f * 8 + 7] == 2.0;
+    double sum = 0.0;
+    for (int r = full ? 0 : p; r < na; ++r) sum += W[(size_t)r * na + p] * B[(size_t)r * np + pr];
+    Cfit[((size_t)f * na + p) * (size_t)np + pr] = sum;
+}
+
 // ---------------------------------------------------------------------------------------
 static Grad1eLayout grad1e_layout(int la, int lb)
 {
@@ -619,8 +783,81 @@ static Grad2eLayout grad2e_layout(int la, int lb, int lc, int ld)
 // work: device scratch of at least 2 * nfrag * n * n doubles (energy-weighted density, total density of a UHF run).
 bool launch_xc_gradient(const BatchView& bv, double* d_grad, hipStream_t s, std::string& err);      // kern_xc.hip
 
-bool launch_gradient(const BatchView& bv, const Topology& topo, double* d_grad, double* work, int* d_lists, size_t list_capacity_ints,
-                     hipStream_t s, std::string& err)
+static bool launch_df_gradient(const BatchView& bv, const Topology& topo, const Topology& aux, const double* Dtot, double* d_grad,
+                               hipStream_t s, std::string& err)
+{
+    const int n = bv.n, nf = bv.nfrag, na = bv.naux, np = bv.npair;
+    const size_t nn = (size_t)n * n;
+    if (aux.lmax > 3) { err = "density-fitted gradients cover auxiliary shells up to f"; return false; }
+    static DevicePool pool_slot[2], list_slot[2];
+    // [c | T | Y | Z | Gam | Cfit | gam2]
+    const size_t big = (size_t)nf * na * nn;
+    const size_t doubles = (size_t)nf * na + 4 * big + (size_t)nf * na * np + (size_t)nf * na * na + 64;
+    double* w = (double*)pool_slot[bv.slot & 1].ensure(sizeof(double) * doubles);
+    if (!w) { err = "out of device memory (density-fitted gradient)"; return false; }
+    double* cvec = w; double* T = cvec + (((size_t)nf * na + 7) & ~size_t(7));
+    double* Y = T + big; double* Z = Y + big; double* Gam = Z + big; double* Cfit = Gam + big; double* gam2 = Cfit + (size_t)nf * na * np;
+    const double x = bv.uhf ? bv.exx : 0.5 * bv.exx;
+    hipLaunchKernelGGL(dfg_coef_kernel, dim3(nf), dim3(256), sizeof(double) * (size_t)(na + 8), s, bv, Dtot, cvec);
+    const dim3 ge((unsigned)((nn + 255) / 256), na, nf);
+    if (bv.exx != 0.0) {
+        hipLaunchKernelGGL(dfg_half_kernel, ge, dim3(256), 0, s, bv, (const double*)bv.D, T);
+        hipLaunchKernelGGL(dfg_full_kernel, ge, dim3(256), 0, s, bv, (const double*)bv.D, (const double*)T, Y, 0);
+        if (bv.uhf) {
+            hipLaunchKernelGGL(dfg_half_kernel, ge, dim3(256), 0, s, bv, (const double*)bv.Db, T);
+            hipLaunchKernelGGL(dfg_full_kernel, ge, dim3(256), 0, s, bv, (const double*)bv.Db, (const double*)T, Y, 1);
+        }
+    } else {
+        (void)hipMemsetAsync(Y, 0, sizeof(double) * big, s);
+    }
+    hipLaunchKernelGGL(dfg_gamma_kernel, ge, dim3(256), 0, s, bv, Dtot, (const double*)cvec, (const double*)Y, x, Z, Gam);
+    hipLaunchKernelGGL(dfg_cfit_kernel, dim3((np + 255) / 256, na, nf), dim3(256), 0, s, bv, Cfit);
+    hipLaunchKernelGGL(dfg_gamma2_kernel, dim3(na * na, nf), dim3(64), 0, s, bv, (const double*)cvec, (const double*)Cfit, (const double*)Z, x, gam2);
+    // ---- task lists: (A >= B, P) by (la, lb, lp); (P >= Q) by (lp, lq)
+    const int ns = (int)topo.shells.size(), nx = (int)aux.shells.size();
+    std::vector<int> t3[3][3][4], t2[4][4];
+    for (int A = 0; A < ns; ++A)
+        for (int B = 0; B <= A; ++B)
+            for (int P = 0; P < nx; ++P) {
+                auto& v = t3[topo.shells[A].l][topo.shells[B].l][aux.shells[P].l];
+                v.push_back(A); v.push_back(B); v.push_back(P); v.push_back(0);
+            }
+    for (int P = 0; P < nx; ++P)
+        for (int Q = 0; Q <= P; ++Q) {
+            auto& v = t2[aux.shells[P].l][aux.shells[Q].l];
+            v.push_back(P); v.push_back(0); v.push_back(Q); v.push_back(0);
+        }
+    size_t tot = 0;
+    for (auto& a : t3) for (auto& b : a) for (auto& c : b) tot += c.size();
+    for (auto& a : t2) for (auto& b : a) tot += b.size();
+    int* d = (int*)list_slot[bv.slot & 1].ensure(sizeof(int) * (tot + 64));
+    if (!d) { err = "out of device memory (density-fitted gradient lists)"; return false; }
+    size_t off = 0;
+    auto run = [&](std::vector<int>& v, int la, int lb, int lc, int mode, const double* g) -> bool {
+        if (v.empty()) return true;
+        (void)hipMemcpyAsync(d + off, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, s);
+        const Grad2eLayout lay = grad2e_layout(la, lb, lc, 0);
+        if (sizeof(double) * (size_t)lay.total > 160 * 1024) { err = "gradient: class too large for LDS"; return false; }
+        const long total = (long)(v.size() / 4) * nf;
+        hipLaunchKernelGGL(eri_grad_kernel, dim3((unsigned)total), dim3(64), sizeof(double) * (size_t)lay.total, s, bv, la, lb, lc, 0, lay,
+                           d + off, (int)(v.size() / 4), (const double*)nullptr, (const double*)nullptr, d_grad, mode, g);
+        off += v.size();
+        return true;
+    };
+    for (int la = 0; la < 3; ++la)
+        for (int lb = 0; lb < 3; ++lb)
+            for (int lp = 0; lp < 4; ++lp)
+                if (!run(t3[la][lb][lp], la, lb, lp, GRAD_DF3C, Gam)) return false;
+    for (int lp = 0; lp < 4; ++lp)
+        for (int lq = 0; lq < 4; ++lq)
+            if (!run(t2[lp][lq], lp, 0, lq, GRAD_DF2C, gam2)) return false;
+    // the host vectors above die with this frame while their copies may still be in flight
+    (void)hipStreamSynchronize(s);
+    return true;
+}
+
+bool launch_gradient(const BatchView& bv, const Topology& topo, const Topology* aux, double* d_grad, double* work, int* d_lists,
+                     size_t list_capacity_ints, hipStream_t s, std::string& err)
 {
     const int n = bv.n, nf = bv.nfrag;
     const size_t nn = (size_t)n * n;
@@ -645,7 +882,7 @@ bool launch_gradient(const BatchView& bv, const Topology& topo, double* d_grad, 
         bk[la][lb].push_back(A); bk[la][lb].push_back(B);
     }
     size_t need = topo.pairs.size();
-    for (auto& cl : topo.classes) need += cl.quartets.size();
+    if (bv.naux == 0) for (auto& cl : topo.classes) need += cl.quartets.size();
     if (need + 64 > list_capacity_ints) { err = "gradient: list buffer too small"; return false; }
     size_t off = 0;
     (void)hipFuncSetAttribute((const void*)grad1e_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -661,7 +898,11 @@ bool launch_gradient(const BatchView& bv, const Topology& topo, double* d_grad, 
                                d_lists + off, (int)(v.size() / 2), Dtot, Wm, d_grad);
             off += v.size();
         }
-    // ---- two-electron: every canonical class
+    // ---- two-electron: density-fitted, or every canonical class of the exact integrals
+    if (bv.naux > 0) {
+        if (!aux) { err = "gradient: the auxiliary basis is missing"; return false; }
+        if (!launch_df_gradient(bv, topo, *aux, Dtot, d_grad, s, err)) return false;
+    } else
     for (auto& cl : topo.classes) {
         if (cl.quartets.empty()) continue;
         (void)hipMemcpyAsync(d_lists + off, cl.quartets.data(), cl.quartets.size() * sizeof(int), hipMemcpyHostToDevice, s);

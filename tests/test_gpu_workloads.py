@@ -143,3 +143,56 @@ def test_tpss_refusals_name_what_is_missing():
     assert r.has_error and "restricted" in r.error_message
     r = methods.run_hip_scf(methods.ScfSettings(basis_set="sto-3g", functional="tpss"), w, want_gradient=True)
     assert r.has_error and "gradient" in r.error_message
+
+
+def test_density_fitted_gradient_matches_differences_of_the_oracle_energy():
+    """The reference GPU backend's gradient is the density-fitted one (compute_scf_gradient, mqc_cuest_gradient.f90:91-175).
+    Engine: Gam^P (mu nu|P)' - 1/2 gam (P|Q)' through the quartet gradient kernel with a unit s shell in the empty slots.
+    Checked the way validation/check_gradient.f90 checks a gradient (its bound: 3.5e-8 Eh/a0), against differences of the
+    ORACLE's density-fitted RHF energy (d shells in the orbital basis, up to f in the auxiliary basis)."""
+    frag = fragment_bohr([8, 1, 1], wc.DF_GRAD_XYZ)
+    st = ScfSettings(basis_set="cc-pvdz", density_fitting=True, aux_basis_set=wc.AUX, energy_tol=1e-12, density_tol=1e-10,
+                     guess="gwh", max_iter=200)
+    r = methods.HFMethod(st).calc_gradient(frag)
+    assert not r.has_error, r.error_message
+    o = recorded_oracle("df_rhf_gradient_water", frag, wc.DF_GRAD_KEY, wc.df_gradient_oracle)
+    fd = np.array(o["gradient"])
+    assert np.max(np.abs(r.gradient - fd)) < 3.5e-8, (np.max(np.abs(r.gradient - fd)), r.gradient, fd)
+    assert np.max(np.abs(r.gradient.sum(axis=1))) < 1e-9
+
+
+@pytest.mark.parametrize("kind", ["df-b3lyp", "df-uhf", "df-pbe-dimer"])
+def test_density_fitted_gradients_match_differences_of_the_engine_energy(kind):
+    """Kohn-Sham (the exchange part of Gam scaled by the functional's exact-exchange fraction, none for PBE), unrestricted
+    (spin densities in the exchange part) and a two-molecule batch member: central differences of the engine's own
+    density-fitted energies, one batch."""
+    if kind == "df-pbe-dimer":
+        z = [8, 1, 1, 8, 1, 1]
+        xyz = np.vstack([wc.DF_GRAD_XYZ, wc.DF_GRAD_XYZ[:, [1, 0, 2]] * 0.97 + np.array([5.1, 0.3, -0.4])])
+        extra, mult, basis = dict(functional="pbe"), 1, "6-31g"
+    elif kind == "df-uhf":
+        z, xyz = [8, 1], np.array([[0.02, -0.01, 0.0], [0.11, 0.07, 1.83]])
+        extra, mult, basis = dict(), 2, "cc-pvdz"
+    else:
+        z, xyz = [8, 1, 1], wc.DF_GRAD_XYZ
+        extra, mult, basis = dict(functional="b3lyp"), 1, "cc-pvdz"
+    st = ScfSettings(basis_set=basis, density_fitting=True, aux_basis_set=wc.AUX, energy_tol=1e-12, density_tol=1e-10,
+                     guess="gwh", max_iter=200, **extra)
+    r = methods.HFMethod(st).calc_gradient(fragment_bohr(z, xyz, multiplicity=mult))
+    assert not r.has_error, r.error_message
+    h = 2e-3
+    frags = []
+    na = len(z)
+    for a in range(na):
+        for c in range(3):
+            for sgn in (+1, -1):
+                x = xyz.copy(); x[a, c] += sgn * h
+                frags.append(fragment_bohr(z, x, multiplicity=mult))
+    e = [q.energy.scf for q in methods.run_hip_scf_batch(st, frags)]
+    fd = np.zeros((3, na))
+    k = 0
+    for a in range(na):
+        for c in range(3):
+            fd[c, a] = (e[k] - e[k + 1]) / (2 * h); k += 2
+    assert np.max(np.abs(r.gradient - fd)) < 5e-6, (np.max(np.abs(r.gradient - fd)), r.gradient, fd)
+    assert np.max(np.abs(r.gradient.sum(axis=1))) < 1e-8

@@ -88,3 +88,31 @@ def tpss_oracle(frag, df):
     aux = oracle_mol(AUX, frag) if df else None
     o = scf_oracle.run_rhf(mol, int(frag.nelec), 100, 1e-9, 1e-7, aux=aux, xc=xc_oracle.XCOracle(mol, "tpss", 3))
     return scf_record(o)
+
+
+# ---- density-fitted gradient: four-point differences of the oracle's DF-RHF energy on a bent, asymmetric water -------------
+DF_GRAD_KEY = "cc-pvdz|df:%s|rhf|1e-12|1e-10|four-point h=2e-3" % AUX
+DF_GRAD_XYZ = np.array([[0.03, -0.02, -0.13], [0.10, 1.45, 1.05], [-0.05, -1.38, 1.12]])
+
+
+def df_gradient_oracle():
+    """-> {"gradient": [3][natoms]} by f' = [8 (f(h) - f(-h)) - (f(2h) - f(-2h))] / 12h of the oracle's density-fitted RHF energy
+    (check_gradient's procedure, validation/check_gradient.f90, with a higher-order stencil)."""
+    from oracle import scf_oracle
+    from tests.helpers import fragment_bohr, oracle_mol
+    h = 2e-3
+
+    def energy(x):
+        f = fragment_bohr([8, 1, 1], x)
+        o = scf_oracle.run_rhf(oracle_mol("cc-pvdz", f), 10, 200, 1e-12, 1e-10, aux=oracle_mol(AUX, f))
+        assert o.converged
+        return o.energy
+    g = np.zeros((3, 3))
+    for a in range(3):
+        for c in range(3):
+            e = {}
+            for k in (-2, -1, 1, 2):
+                x = DF_GRAD_XYZ.copy(); x[a, c] += k * h
+                e[k] = energy(x)
+            g[c, a] = (8.0 * (e[1] - e[-1]) - (e[2] - e[-2])) / (12.0 * h)
+    return {"gradient": g.tolist()}
