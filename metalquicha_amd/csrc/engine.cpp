@@ -275,7 +275,7 @@ static int validate_options(const mqc_hip_scf_options_t& o, const Topology& topo
     if (topo.lmax > CLASS_LMAX) {
         const bool direct = !o.density_fitting && (o.eri_mode == MQC_HIP_ERI_DIRECT || (o.eri_mode == MQC_HIP_ERI_AUTO && !incore_supported(topo.nao)));
         (void)direct;       // f classes are digested by the LDS kernel: the direct build covers them
-        if (o.density_fitting) { msg = "orbital f shells with density fitting are not available in this build of the HIP backend (three-centre kernels cover s, p, d orbital shells)"; return MQC_HIP_ERR_UNSUPPORTED; }
+        if (o.density_fitting && topo.lmax > 3) { msg = "density fitting covers orbital shells up to f"; return MQC_HIP_ERR_UNSUPPORTED; }
     }
     // n_ao <= 140: the Fock matrix is diagonalised in LDS; up to 256 it is rotated in global memory (L2), exact-ERI
     // direct path and the quadrature's z-split; density fitting keeps the 140 limit (its J/K kernels tile n in LDS)

@@ -248,6 +248,7 @@ void launch_eri_bounds(const BatchView& bv, const Topology& topo, double schwarz
 // wave-cooperative kernel for classes with an f (or g) shell (kern_eri_general.hip); false: class too large for LDS
 bool launch_eri_general(const BatchView& bv, int la, int lb, int lc, int ld, const int* d_list, int nq, const int* d_tasks, int ntasks,
                         const double* Q, double thresh, hipStream_t s);
+bool launch_df3c_general(const BatchView& bv, int la, int lb, int lp, const int* d_list, int nq, hipStream_t s);
 bool launch_schwarz_general(const BatchView& bv, int la, int lb, const int* d_pairs, int npairs, double* Qout, hipStream_t s);
 void eri_set_side_streams(int slot, const hipStream_t* streams, int count);
 void launch_jk_incore(const BatchView& bv, bool only_active, hipStream_t s);

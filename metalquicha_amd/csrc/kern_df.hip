@@ -1038,11 +1038,17 @@ void launch_df_build(const BatchView& bv, const Topology& topo, const Topology& 
     const int ns = (int)topo.shells.size(), nx = (int)aux.shells.size();
     // bucket tasks
     std::vector<int> t3[3][3][4], t2[4][4];
+    std::vector<int> t3f[4][4];              // an f shell in the bra: (l_b, l_P) -> entries (A, B, P, -) for the general kernel
     for (int A = 0; A < ns; ++A)
         for (int B = 0; B <= A; ++B) {
             int a = A, b = B;
             if (topo.shells[a].l < topo.shells[b].l) std::swap(a, b);
             for (int P = 0; P < nx; ++P) {
+                if (topo.shells[a].l == 3) {
+                    auto& v = t3f[topo.shells[b].l][aux.shells[P].l];
+                    v.push_back(a); v.push_back(b); v.push_back(P); v.push_back(0);
+                    continue;
+                }
                 auto& v = t3[topo.shells[a].l][topo.shells[b].l][aux.shells[P].l];
                 v.push_back(a); v.push_back(b); v.push_back(P);
             }
@@ -1057,8 +1063,18 @@ void launch_df_build(const BatchView& bv, const Topology& topo, const Topology& 
     size_t tot = 0;
     for (auto& x : t3) for (auto& y : x) for (auto& z : y) tot += z.size();
     for (auto& x : t2) for (auto& y : x) tot += y.size();
+    for (auto& x : t3f) for (auto& y : x) tot += y.size();
     int* d = (int*)lists.ensure((tot + 64) * sizeof(int));
     size_t off = 0;
+    for (int lb = 0; lb < 4; ++lb)
+        for (int lp = 0; lp < 4; ++lp) {
+            auto& v = t3f[lb][lp];
+            if (v.empty()) continue;
+            (void)hipMemcpyAsync(d + off, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, s);
+            if (!launch_df3c_general(bv, 3, lb, lp, d + off, (int)(v.size() / 4), s))
+                std::fprintf(stderr, "mqc_hip: three-centre class (f %d | %d) does not fit the general kernel\n", lb, lp);
+            off += v.size();
+        }
 #define DF3(a, b, c) df3c_launch<a, b, c>(bv, t3[a][b][c], d + off, s); off += t3[a][b][c].size();
 #define DF3_ALLC(a, b) DF3(a, b, 0) DF3(a, b, 1) DF3(a, b, 2) DF3(a, b, 3)
     DF3_ALLC(0, 0) DF3_ALLC(1, 0) DF3_ALLC(1, 1) DF3_ALLC(2, 0) DF3_ALLC(2, 1) DF3_ALLC(2, 2)

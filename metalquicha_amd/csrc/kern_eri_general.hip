@@ -86,7 +86,12 @@ struct GenLayout {      // LDS offsets in doubles, computed by the host for the 
 
 }  // namespace
 
-enum { GEN_MODE_STORE = 0, GEN_MODE_SCHWARZ = 1, GEN_MODE_DIGEST = 2 };
+enum { GEN_MODE_STORE = 0, GEN_MODE_SCHWARZ = 1, GEN_MODE_DIGEST = 2, GEN_MODE_DF3C = 3 };
+
+// GEN_MODE_DF3C: the three-centre integrals of density fitting for orbital classes the register kernels of kern_df.hip
+// do not cover (an f shell in the bra): (ab|P) = (ab|P 1) with the "function" 1 as a one-primitive s shell of exponent 0
+// in the fourth slot; list entries are (A, B, P, -), the block goes to df_a3[P][pair(ab)].
+__device__ const double g_unit_shell_3c[2] = {0.0, 1.0};
 
 // what the direct (integral-recomputing) Fock build hands the digest mode
 struct GenDigest {
@@ -129,10 +134,14 @@ __global__ void __launch_bounds__(64) eri_general_kernel(BatchView bv, int la, i
         const double dk = 0.125 * bv.exx * fmax(fmax(dm[A * ns + C], dm[A * ns + D]), fmax(dm[B * ns + C], dm[B * ns + D]));
         if (!(q[A * ns + B] * q[C * ns + D] * deg * fmax(dj, dk) >= thresh)) return;
     }
-    if (MODE != GEN_MODE_SCHWARZ && lane == 0 && bv.eri_count) atomicAdd(bv.eri_count, 1ull);
+    if (MODE != GEN_MODE_SCHWARZ && MODE != GEN_MODE_DF3C && lane == 0 && bv.eri_count) atomicAdd(bv.eri_count, 1ull);
 
     const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
-    const ShellRef sa = make_shell(tp, xyz, A), sb = make_shell(tp, xyz, B), sc = make_shell(tp, xyz, C), sd = make_shell(tp, xyz, D);
+    const ShellRef sa = make_shell(tp, xyz, A), sb = make_shell(tp, xyz, B);
+    const ShellRef sc = MODE == GEN_MODE_DF3C ? make_shell(bv.aux, xyz, C) : make_shell(tp, xyz, C);
+    ShellRef sd;
+    if (MODE == GEN_MODE_DF3C) { sd.nprim = 1; sd.exps = &g_unit_shell_3c[0]; sd.coefs = &g_unit_shell_3c[1]; sd.x = sc.x; sd.y = sc.y; sd.z = sc.z; }
+    else sd = make_shell(tp, xyz, D);
     const int lab = la + lb, lcd = lc + ld, L = lab + lcd;
     const int nca = ncart(la), ncb = ncart(lb), ncc = ncart(lc), ncd = ncart(ld);
     const int ncab = nca * ncb, nccd = ncc * ncd;
@@ -332,6 +341,19 @@ __global__ void __launch_bounds__(64) eri_general_kernel(BatchView bv, int la, i
         }
         return;
     }
+    if (MODE == GEN_MODE_DF3C) {
+        const int oa3 = tp.sh_aoff[A], ob3 = tp.sh_aoff[B], op3 = bv.aux.sh_aoff[C];
+        double* A3 = bv.df_a3 + (size_t)f * bv.naux * (size_t)bv.npair;
+        for (int idx = lane; idx < nout; idx += 64) {          // nsd = 1
+            int r = idx;
+            const int k = r % nsc; r /= nsc;
+            const int j = r % nsb;
+            const int i = r / nsb;
+            if (A == B && j > i) continue;
+            A3[(size_t)(op3 + k) * bv.npair + pair_index(oa3 + i, ob3 + j)] = OUT[idx];
+        }
+        return;
+    }
     const int oa = tp.sh_aoff[A], ob = tp.sh_aoff[B], oc = tp.sh_aoff[C], od = tp.sh_aoff[D];
     if (MODE == GEN_MODE_DIGEST) {
         // the six pre-contracted scatter updates of eri_digest_kernel, lanes over the output pair of each
@@ -438,6 +460,21 @@ bool launch_eri_general(const BatchView& bv, int la, int lb, int lc, int ld, con
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(64), lds, s, bv, la, lb, lc, ld, lay, d_list, nq, d_tasks, ntasks, Q, thresh,
                        (double*)nullptr, GenDigest{});
+    return true;
+}
+
+// Three-centre integrals (ab|P) of one (la, lb, lp) class into df_a3; d_list holds (A, B, P, -) per entry
+bool launch_df3c_general(const BatchView& bv, int la, int lb, int lp, const int* d_list, int nq, hipStream_t s)
+{
+    const long total = (long)nq * bv.nfrag;
+    if (total == 0) return true;
+    const GenLayout lay = gen_layout(la, lb, lp, 0);
+    const size_t lds = sizeof(double) * (size_t)lay.total;
+    if (lds > 160 * 1024 || total > 0x7fffffffL) return false;
+    auto kern = eri_general_kernel<GEN_MODE_DF3C>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(64), lds, s, bv, la, lb, lp, 0, lay, d_list, nq, (const int*)nullptr, 0,
+                       (const double*)nullptr, 0.0, (double*)nullptr, GenDigest{});
     return true;
 }
 

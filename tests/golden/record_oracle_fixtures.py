@@ -1,6 +1,6 @@
 """Records the slow oracle results of tests/test_gpu_workloads.py into tests/golden/oracle_fixtures.json.
 
-    python tests/golden/record_oracle_fixtures.py [case ...]        # cases: fmo_df_rks gmbe tpss df_grad (default: all)
+    python tests/golden/record_oracle_fixtures.py [case ...]        # cases: fmo_df_rks gmbe tpss df_grad df_f (default: all)
 
 CPU only: the oracle is numpy + oracle/liboracle_ints.so; nothing here touches the engine.  The keys are those the
 tests compute (label + digest of geometry and settings), so a changed input can never pick up a stale record."""
@@ -18,7 +18,7 @@ from tests import helpers, workload_cases as wc      # noqa: E402
 
 
 def main(argv):
-    want = set(argv) or {"fmo_df_rks", "gmbe", "tpss", "df_grad"}
+    want = set(argv) or {"fmo_df_rks", "gmbe", "tpss", "df_grad", "df_f"}
     path = helpers._FIXTURE_PATH
     cur = json.load(open(path)) if os.path.isfile(path) else {}
     if "fmo_df_rks" in want:
@@ -45,6 +45,13 @@ def main(argv):
                 key = helpers._fixture_key("tpss_water_batch", f, wc.TPSS_KEY % ("df:" + wc.AUX if df else "exact"))
                 t0 = time.time()
                 cur[key] = wc.tpss_oracle(f, df)
+                print(key, cur[key]["energy"], "%.0f s" % (time.time() - t0), flush=True)
+    if "df_f" in want:
+        for fn in ("", "b3lyp"):
+            for f in wc.df_f_fragments():
+                key = helpers._fixture_key("df_f_orbitals", f, wc.DF_F_KEY % (fn or "rhf"))
+                t0 = time.time()
+                cur[key] = wc.df_f_oracle(f, fn)
                 print(key, cur[key]["energy"], "%.0f s" % (time.time() - t0), flush=True)
     if "df_grad" in want:
         key = helpers._fixture_key("df_rhf_gradient_water", helpers.fragment_bohr([8, 1, 1], wc.DF_GRAD_XYZ), wc.DF_GRAD_KEY)

@@ -196,3 +196,17 @@ def test_density_fitted_gradients_match_differences_of_the_engine_energy(kind):
             fd[c, a] = (e[k] - e[k + 1]) / (2 * h); k += 2
     assert np.max(np.abs(r.gradient - fd)) < 5e-6, (np.max(np.abs(r.gradient - fd)), r.gradient, fd)
     assert np.max(np.abs(r.gradient.sum(axis=1))) < 1e-8
+
+
+@pytest.mark.parametrize("functional", ["", "b3lyp"], ids=["rhf", "b3lyp"])
+def test_density_fitting_with_f_orbital_shells_matches_oracle(functional):
+    """configs[3]'s basis (def2-TZVP: an f shell on every oxygen) density-fitted, as the reference GPU backend runs it
+    (mqc_cuest_integrals.f90:702-736,1636-1748): the three-centre classes with an f shell in the bra come from the
+    general LDS kernel with a unit s shell in the fourth slot.  A water and a water dimer (n = 43 / 86) in one batch."""
+    frags = wc.df_f_fragments()
+    res = methods.run_hip_scf_batch(wc.df_f_settings(functional), frags)
+    for f, r in zip(frags, res):
+        assert not r.has_error, r.error_message
+        o = recorded_oracle("df_f_orbitals", f, wc.DF_F_KEY % (functional or "rhf"), lambda f=f: wc.df_f_oracle(f, functional))
+        assert o["converged"]
+        assert abs(r.energy.scf - o["energy"]) < 1e-8, (r.energy.scf, o["energy"])

@@ -116,3 +116,27 @@ def df_gradient_oracle():
                 e[k] = energy(x)
             g[c, a] = (8.0 * (e[1] - e[-1]) - (e[2] - e[-2])) / (12.0 * h)
     return {"gradient": g.tolist()}
+
+
+# ---- density fitting with f shells in the orbital basis (def2-TZVP): the density-fitted form of configs[3]'s method --------
+DF_F_KEY = "def2-tzvp|%s|df:" + AUX + "|grid3|1e-9|1e-7|gwh"
+
+
+def df_f_fragments():
+    from tests.helpers import fragment_bohr, water_at
+    rng = np.random.default_rng(33)
+    ws = [water_at(rng, c) for c in ([0, 0, 0], [5.4, -0.5, 0.3])]
+    return [fragment_bohr([8, 1, 1], ws[0]), fragment_bohr([8, 1, 1, 8, 1, 1], np.vstack(ws))]
+
+
+def df_f_settings(functional):
+    return ScfSettings(basis_set="def2-tzvp", functional=functional, density_fitting=True, aux_basis_set=AUX,
+                       energy_tol=1e-9, density_tol=1e-7, guess="gwh")
+
+
+def df_f_oracle(frag, functional):
+    from oracle import scf_oracle, xc_oracle
+    from tests.helpers import oracle_mol, scf_record
+    mol = oracle_mol("def2-tzvp", frag)
+    xc = xc_oracle.XCOracle(mol, functional, 3) if functional else None
+    return scf_record(scf_oracle.run_rhf(mol, int(frag.nelec), 100, 1e-9, 1e-7, aux=oracle_mol(AUX, frag), xc=xc))
