@@ -249,7 +249,7 @@ static int validate_options(const mqc_hip_scf_options_t& o, const Topology& topo
         XcSpec tg; std::string eg;
         parse_functional(o.functional, tg, eg);
         if (tg.gga == 2) { msg = "analytic gradients of meta-GGA functionals are not built (energies only)"; return MQC_HIP_ERR_UNSUPPORTED; }
-        if (topo.lmax > 2) { msg = "analytic gradients cover s, p and d shells"; return MQC_HIP_ERR_UNSUPPORTED; }
+        if (topo.lmax > 3) { msg = "analytic gradients cover s, p, d and f shells"; return MQC_HIP_ERR_UNSUPPORTED; }
     }
     // restricted iff multiplicity 1, even electron count and not forced (mqc_cuest_driver.f90:127)
     const bool uhf = o.unrestricted || topo.multiplicity != 1 || (topo.nelec % 2) != 0;

@@ -15,7 +15,7 @@
 // Gaussian raises and lowers its angular momentum, d/dA_x x_A^i e^{-a r_A^2} = 2a x_A^{i+1} (..) - i x_A^{i-1} (..), so the
 // Hermite tables are built one unit higher and the density factor (Gamma, D, W) is brought to the CARTESIAN basis
 // once per block; the derivative integrals are then contracted on the fly -- nine numbers per quartet (centres A, B, C;
-// D by translational invariance), never stored.  Shells up to d (the f classes have no gradient yet).
+// D by translational invariance), never stored.  Shells up to f; the two largest f classes pass their ket columns in chunks.
 #include "eri_kernels.hpp"
 
 namespace mqc {
@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(64) grad1e_kernel(BatchView bv, int la, int lb
 
 // ---------------------------------------------------------------------------------------
 // Two-electron term: wave = (unique shell quartet, fragment).
-struct Grad2eLayout { int e_ab, e_cd, r0, r1, tuv, fb, gc, tmp, g0, gp, gm, total; };
+struct Grad2eLayout { int e_ab, e_cd, r0, r1, tuv, fb, gc, tmp, g0, gp, gm, total, dchunk; };
 
 // The "function" 1 as a one-primitive s shell: exponent 0, coefficient 1.  With it in the fourth (or second and fourth)
 // slot the quartet routine below differentiates the three- and two-centre Coulomb integrals of density fitting:
@@ -523,12 +523,16 @@ __global__ void __launch_bounds__(64) eri_grad_kernel(BatchView bv, int la, int 
                     const double* R = gr_hermite_r(LR, X, Y, Z, Fb, tuv, R0, R1, lane);
                     const double* Fx = Ecd; const double* Fy = Ecd + ne_cd; const double* Fz = Ecd + 2 * ne_cd;
                     // ket-contracted intermediates: G[h][k] = sum (-1)^{tau+nu+phi} F F F R_{t+tau,u+nu,v+phi}
+                    // (f f|f d) and (f f|f f) do not fit the LDS with every ket column at once: the columns go through
+                    // in chunks of dn Cartesian components of shell D (dn = ncd everywhere else: one pass, as before)
+                    const int dnmax = lay.dchunk;
+                    for (int d0 = 0; d0 < ncd; d0 += dnmax) {
+                    const int dn = min(dnmax, ncd - d0);
+                    const int kcd = ncc * dn, kcp = ncart(lc + 1) * dn, kcm = (lc > 0 ? ncart(lc - 1) : 0) * dn;
                     auto ket = [&](int lcx, int nh, int nk, double* G) {
-                        const int nck = ncart(lcx);
-                        (void)nck;
                         for (int idx = lane; idx < nh * nk; idx += 64) {
                             const int h = idx / nk, k = idx - h * nk;
-                            const int ic = k / ncd, id = k - ic * ncd;
+                            const int ic = k / dn, id = d0 + (k - ic * dn);
                             int cx, cy, cz, dx, dy, dz;
                             cart_lmn(lcx, ic, cx, cy, cz);
                             cart_lmn(ld, id, dx, dy, dz);
@@ -549,9 +553,9 @@ __global__ void __launch_bounds__(64) eri_grad_kernel(BatchView bv, int la, int 
                             G[idx] = g;
                         }
                     };
-                    ket(lc, nh1, nccd, G0);
-                    ket(lc + 1, nh0, ncp, GP);
-                    if (lc > 0) ket(lc - 1, nh0, ncm, GM);
+                    ket(lc, nh1, kcd, G0);
+                    ket(lc + 1, nh0, kcp, GP);
+                    if (lc > 0) ket(lc - 1, nh0, kcm, GM);
                     __syncthreads();
                     const double* Ex = Eab; const double* Ey = Eab + ne_ab; const double* Ez = Eab + 2 * ne_ab;
                     // bra contraction: sum_tuv E[a'][b'] G[hidx(t,u,v)][col], stride = columns of that G
@@ -573,33 +577,37 @@ __global__ void __launch_bounds__(64) eri_grad_kernel(BatchView bv, int la, int 
                         if (gam == 0.0) continue;
                         const int iab = idx / nccd, icd = idx - iab * nccd;
                         const int ia = iab / ncb, ib = iab - ia * ncb;
-                        const int ic = icd / ncd, id = icd - ic * ncd;
+                        const int ic = icd / ncd, idf = icd - ic * ncd;
+                        if (idf < d0 || idf >= d0 + dn) continue;
+                        const int id = idf - d0, kc = ic * dn + id;
                         int ax, ay, az, bx, by, bz, cx, cy, cz;
                         cart_lmn(la, ia, ax, ay, az);
                         cart_lmn(lb, ib, bx, by, bz);
                         cart_lmn(lc, ic, cx, cy, cz);
                         const double pg = pref * gam;
                         // centre A
-                        gA[0] += pg * (2.0 * a * bra(ax + 1, ay, az, bx, by, bz, G0, nccd, icd) - ax * bra(ax - 1, ay, az, bx, by, bz, G0, nccd, icd));
-                        gA[1] += pg * (2.0 * a * bra(ax, ay + 1, az, bx, by, bz, G0, nccd, icd) - ay * bra(ax, ay - 1, az, bx, by, bz, G0, nccd, icd));
-                        gA[2] += pg * (2.0 * a * bra(ax, ay, az + 1, bx, by, bz, G0, nccd, icd) - az * bra(ax, ay, az - 1, bx, by, bz, G0, nccd, icd));
+                        gA[0] += pg * (2.0 * a * bra(ax + 1, ay, az, bx, by, bz, G0, kcd, kc) - ax * bra(ax - 1, ay, az, bx, by, bz, G0, kcd, kc));
+                        gA[1] += pg * (2.0 * a * bra(ax, ay + 1, az, bx, by, bz, G0, kcd, kc) - ay * bra(ax, ay - 1, az, bx, by, bz, G0, kcd, kc));
+                        gA[2] += pg * (2.0 * a * bra(ax, ay, az + 1, bx, by, bz, G0, kcd, kc) - az * bra(ax, ay, az - 1, bx, by, bz, G0, kcd, kc));
                         // centre B
-                        gB[0] += pg * (2.0 * b * bra(ax, ay, az, bx + 1, by, bz, G0, nccd, icd) - bx * bra(ax, ay, az, bx - 1, by, bz, G0, nccd, icd));
-                        gB[1] += pg * (2.0 * b * bra(ax, ay, az, bx, by + 1, bz, G0, nccd, icd) - by * bra(ax, ay, az, bx, by - 1, bz, G0, nccd, icd));
-                        gB[2] += pg * (2.0 * b * bra(ax, ay, az, bx, by, bz + 1, G0, nccd, icd) - bz * bra(ax, ay, az, bx, by, bz - 1, G0, nccd, icd));
+                        gB[0] += pg * (2.0 * b * bra(ax, ay, az, bx + 1, by, bz, G0, kcd, kc) - bx * bra(ax, ay, az, bx - 1, by, bz, G0, kcd, kc));
+                        gB[1] += pg * (2.0 * b * bra(ax, ay, az, bx, by + 1, bz, G0, kcd, kc) - by * bra(ax, ay, az, bx, by - 1, bz, G0, kcd, kc));
+                        gB[2] += pg * (2.0 * b * bra(ax, ay, az, bx, by, bz + 1, G0, kcd, kc) - bz * bra(ax, ay, az, bx, by, bz - 1, G0, kcd, kc));
                         // centre C: ket raised / lowered on c
                         {
-                            const int kxp = cart_index(lc + 1, cx + 1, cz) * ncd + id;
-                            const int kyp = cart_index(lc + 1, cx, cz) * ncd + id;
-                            const int kzp = cart_index(lc + 1, cx, cz + 1) * ncd + id;
-                            double vx = 2.0 * c * bra(ax, ay, az, bx, by, bz, GP, ncp, kxp);
-                            double vy = 2.0 * c * bra(ax, ay, az, bx, by, bz, GP, ncp, kyp);
-                            double vz = 2.0 * c * bra(ax, ay, az, bx, by, bz, GP, ncp, kzp);
-                            if (cx > 0) vx -= cx * bra(ax, ay, az, bx, by, bz, GM, ncm, cart_index(lc - 1, cx - 1, cz) * ncd + id);
-                            if (cy > 0) vy -= cy * bra(ax, ay, az, bx, by, bz, GM, ncm, cart_index(lc - 1, cx, cz) * ncd + id);
-                            if (cz > 0) vz -= cz * bra(ax, ay, az, bx, by, bz, GM, ncm, cart_index(lc - 1, cx, cz - 1) * ncd + id);
+                            const int kxp = cart_index(lc + 1, cx + 1, cz) * dn + id;
+                            const int kyp = cart_index(lc + 1, cx, cz) * dn + id;
+                            const int kzp = cart_index(lc + 1, cx, cz + 1) * dn + id;
+                            double vx = 2.0 * c * bra(ax, ay, az, bx, by, bz, GP, kcp, kxp);
+                            double vy = 2.0 * c * bra(ax, ay, az, bx, by, bz, GP, kcp, kyp);
+                            double vz = 2.0 * c * bra(ax, ay, az, bx, by, bz, GP, kcp, kzp);
+                            if (cx > 0) vx -= cx * bra(ax, ay, az, bx, by, bz, GM, kcm, cart_index(lc - 1, cx - 1, cz) * dn + id);
+                            if (cy > 0) vy -= cy * bra(ax, ay, az, bx, by, bz, GM, kcm, cart_index(lc - 1, cx, cz) * dn + id);
+                            if (cz > 0) vz -= cz * bra(ax, ay, az, bx, by, bz, GM, kcm, cart_index(lc - 1, cx, cz - 1) * dn + id);
                             gCc[0] += pg * vx; gCc[1] += pg * vy; gCc[2] += pg * vz;
                         }
+                    }
+                    if (d0 + dn < ncd) __syncthreads();      // the next chunk overwrites G0 / GP / GM
                     }
                 }
             __syncthreads();
@@ -772,9 +780,22 @@ static Grad2eLayout grad2e_layout(int la, int lb, int lc, int ld)
     if (t2 > gcsz) gcsz = t2;
     if (t0 > gcsz) gcsz = t0;
     g.gc = take(gcsz); g.tmp = take(tmp);
-    g.g0 = take(nherm(la + lb + 1) * ncart(lc) * ncart(ld));
-    g.gp = take(nherm(la + lb) * ncart(lc + 1) * ncart(ld));
-    g.gm = take(lc > 0 ? nherm(la + lb) * ncart(lc - 1) * ncart(ld) : 2);
+    g.dchunk = ncart(ld);
+    const int before = off;
+    auto take_g = [&](int dn) {
+        g.g0 = take(nherm(la + lb + 1) * ncart(lc) * dn);
+        g.gp = take(nherm(la + lb) * ncart(lc + 1) * dn);
+        g.gm = take(lc > 0 ? nherm(la + lb) * ncart(lc - 1) * dn : 2);
+    };
+    take_g(g.dchunk);
+    if (sizeof(double) * (size_t)off > 160 * 1024) {
+        // (f f|f d), (f f|f f): one Cartesian component of shell D per pass, and the intermediates take over the
+        // staging buffer of the solid-harmonic transform (finished before the primitive loops start)
+        g.dchunk = 1;
+        off = g.tmp;
+        take_g(1);
+        if (off < before) off = before;
+    }
     g.total = off;
     return g;
 }
@@ -815,7 +836,7 @@ static bool launch_df_gradient(const BatchView& bv, const Topology& topo, const 
     hipLaunchKernelGGL(dfg_gamma2_kernel, dim3(na * na, nf), dim3(64), 0, s, bv, (const double*)cvec, (const double*)Cfit, (const double*)Z, x, gam2);
     // ---- task lists: (A >= B, P) by (la, lb, lp); (P >= Q) by (lp, lq)
     const int ns = (int)topo.shells.size(), nx = (int)aux.shells.size();
-    std::vector<int> t3[3][3][4], t2[4][4];
+    std::vector<int> t3[4][4][4], t2[4][4];
     for (int A = 0; A < ns; ++A)
         for (int B = 0; B <= A; ++B)
             for (int P = 0; P < nx; ++P) {
@@ -844,8 +865,8 @@ static bool launch_df_gradient(const BatchView& bv, const Topology& topo, const 
         off += v.size();
         return true;
     };
-    for (int la = 0; la < 3; ++la)
-        for (int lb = 0; lb < 3; ++lb)
+    for (int la = 0; la < 4; ++la)
+        for (int lb = 0; lb < 4; ++lb)
             for (int lp = 0; lp < 4; ++lp)
                 if (!run(t3[la][lb][lp], la, lb, lp, GRAD_DF3C, Gam)) return false;
     for (int lp = 0; lp < 4; ++lp)
@@ -861,7 +882,7 @@ bool launch_gradient(const BatchView& bv, const Topology& topo, const Topology* 
 {
     const int n = bv.n, nf = bv.nfrag;
     const size_t nn = (size_t)n * n;
-    if (topo.lmax > 2) { err = "analytic gradients cover s, p and d shells"; return false; }
+    if (topo.lmax > 3) { err = "analytic gradients cover s, p, d and f shells"; return false; }
     double* Wm = work;
     double* Dtot = bv.D;
     (void)hipMemsetAsync(d_grad, 0, sizeof(double) * (size_t)nf * topo.natoms * 3, s);
@@ -872,7 +893,7 @@ bool launch_gradient(const BatchView& bv, const Topology& topo, const Topology* 
         hipLaunchKernelGGL(grad_total_density_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, bv, Dtot);
     }
     // ---- one-electron: pairs bucketed by (la >= lb)
-    static std::vector<int> bucket[2][3][3];
+    static std::vector<int> bucket[2][4][4];
     auto& bk = bucket[bv.slot & 1];
     for (auto& row : bk) for (auto& b : row) b.clear();
     for (size_t k = 0; k + 1 < topo.pairs.size(); k += 2) {
@@ -887,7 +908,7 @@ bool launch_gradient(const BatchView& bv, const Topology& topo, const Topology* 
     size_t off = 0;
     (void)hipFuncSetAttribute((const void*)grad1e_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)eri_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    for (int la = 0; la <= 2; ++la)
+    for (int la = 0; la <= 3; ++la)
         for (int lb = 0; lb <= la; ++lb) {
             auto& v = bk[la][lb];
             if (v.empty()) continue;

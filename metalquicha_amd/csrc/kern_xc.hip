@@ -2383,7 +2383,7 @@ __device__ __forceinline__ void put_function(double P, const double* Pi, const d
 
 template <bool GGA>
 __device__ void emit_shell_d2(int l, int ao, double dx, double dy, double dz, double R0, double R1, double R2,
-                              double* __restrict__ base, size_t S, int ptp, int p)
+                              double* __restrict__ base, size_t S, int ptp, int p, const double* __restrict__ c2s)
 {
     const double x[3] = {dx, dy, dz};
     if (l == 0) {
@@ -2396,7 +2396,7 @@ __device__ void emit_shell_d2(int l, int ao, double dx, double dy, double dz, do
             Pi[k] = 1.0;
             put_function<GGA>(x[k], Pi, Pij, x, R0, R1, R2, base, S, (ao + k) * ptp + p);
         }
-    } else {
+    } else if (l == 2) {
         // l = 2: the five real solid harmonics as combinations of xx, xy, xz, yy, yz, zz (libcint order xy, yz, z2, xz, x2-y2)
         const int ca[6] = {0, 0, 0, 1, 1, 2}, cb[6] = {0, 1, 2, 1, 2, 2};
         for (int m = 0; m < 5; ++m) {
@@ -2409,6 +2409,32 @@ __device__ void emit_shell_d2(int l, int ao, double dx, double dy, double dz, do
                 Pi[a] += w * x[b]; Pi[b] += w * x[a];
                 // packed index of (a, b), a <= b: xx 0, xy 1, xz 2, yy 3, yz 4, zz 5 -- the same order as the Cartesian list
                 Pij[c] += (a == b) ? 2.0 * w : w;
+            }
+            put_function<GGA>(P, Pi, Pij, x, R0, R1, R2, base, S, (ao + m) * ptp + p);
+        }
+    } else {
+        // l >= 3: the real solid harmonics from the cart -> sph table over the monomials x^i y^j z^k and their derivatives
+        double pw[3][LMAX_AO + 1];
+        for (int d = 0; d < 3; ++d) { pw[d][0] = 1.0; for (int k = 1; k <= l; ++k) pw[d][k] = pw[d][k - 1] * x[d]; }
+        const int nc = ncart(l);
+        for (int m = 0; m < 2 * l + 1; ++m) {
+            double P = 0.0, Pi[3] = {0.0, 0.0, 0.0}, Pij[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            for (int c = 0; c < nc; ++c) {
+                const double w = c2s[c2s_table_offset(l) + m * nc + c];
+                if (w == 0.0) continue;
+                int e[3];
+                cart_lmn(l, c, e[0], e[1], e[2]);
+                // value and first derivative factor of every axis: f_d = x_d^e_d, f_d' = e_d x_d^(e_d - 1), f_d'' = e_d (e_d - 1) x_d^(e_d - 2)
+                double f0[3], f1[3], f2[3];
+                for (int d = 0; d < 3; ++d) {
+                    f0[d] = pw[d][e[d]];
+                    f1[d] = e[d] > 0 ? e[d] * pw[d][e[d] - 1] : 0.0;
+                    f2[d] = e[d] > 1 ? e[d] * (e[d] - 1) * pw[d][e[d] - 2] : 0.0;
+                }
+                P += w * f0[0] * f0[1] * f0[2];
+                Pi[0] += w * f1[0] * f0[1] * f0[2]; Pi[1] += w * f0[0] * f1[1] * f0[2]; Pi[2] += w * f0[0] * f0[1] * f1[2];
+                Pij[0] += w * f2[0] * f0[1] * f0[2]; Pij[1] += w * f1[0] * f1[1] * f0[2]; Pij[2] += w * f1[0] * f0[1] * f1[2];
+                Pij[3] += w * f0[0] * f2[1] * f0[2]; Pij[4] += w * f0[0] * f1[1] * f1[2]; Pij[5] += w * f0[0] * f0[1] * f2[2];
             }
             put_function<GGA>(P, Pi, Pij, x, R0, R1, R2, base, S, (ao + m) * ptp + p);
         }
@@ -2466,7 +2492,7 @@ __global__ void __launch_bounds__(XG_NT) xc_grad_kernel(BatchView bv, double* __
                     }
                 }
             }
-            emit_shell_d2<GGA>(l, tp.sh_aoff[sh], dx, dy, dz, R0, R1, R2, ao, S, PTP, p);
+            emit_shell_d2<GGA>(l, tp.sh_aoff[sh], dx, dy, dz, R0, R1, R2, ao, S, PTP, p, bv.c2s);
         }
         if (tid < PT) own[tid] = (g0 + tid < gd.npts) ? gd.pt_atom[g0 + tid] : 0;
         __syncthreads();

@@ -1,6 +1,6 @@
 """Records the slow oracle results of tests/test_gpu_workloads.py into tests/golden/oracle_fixtures.json.
 
-    python tests/golden/record_oracle_fixtures.py [case ...]        # cases: fmo_df_rks gmbe tpss df_grad df_f (default: all)
+    python tests/golden/record_oracle_fixtures.py [case ...]        # cases: fmo_df_rks gmbe tpss df_grad df_f f_grad (default: all)
 
 CPU only: the oracle is numpy + oracle/liboracle_ints.so; nothing here touches the engine.  The keys are those the
 tests compute (label + digest of geometry and settings), so a changed input can never pick up a stale record."""
@@ -18,7 +18,7 @@ from tests import helpers, workload_cases as wc      # noqa: E402
 
 
 def main(argv):
-    want = set(argv) or {"fmo_df_rks", "gmbe", "tpss", "df_grad", "df_f"}
+    want = set(argv) or {"fmo_df_rks", "gmbe", "tpss", "df_grad", "df_f", "f_grad"}
     path = helpers._FIXTURE_PATH
     cur = json.load(open(path)) if os.path.isfile(path) else {}
     if "fmo_df_rks" in want:
@@ -53,6 +53,13 @@ def main(argv):
                 t0 = time.time()
                 cur[key] = wc.df_f_oracle(f, fn)
                 print(key, cur[key]["energy"], "%.0f s" % (time.time() - t0), flush=True)
+    if "f_grad" in want:
+        for df in (False, True):
+            key = helpers._fixture_key("f_shell_gradient_co", helpers.fragment_bohr(wc.F_GRAD_Z, wc.F_GRAD_XYZ),
+                                       wc.F_GRAD_KEY % ("df:" + wc.AUX if df else "exact"))
+            t0 = time.time()
+            cur[key] = wc.f_gradient_oracle(df)
+            print(key, np.abs(np.array(cur[key]["gradient"])).max(), "%.0f s" % (time.time() - t0), flush=True)
     if "df_grad" in want:
         key = helpers._fixture_key("df_rhf_gradient_water", helpers.fragment_bohr([8, 1, 1], wc.DF_GRAD_XYZ), wc.DF_GRAD_KEY)
         t0 = time.time()

@@ -210,3 +210,43 @@ def test_density_fitting_with_f_orbital_shells_matches_oracle(functional):
         o = recorded_oracle("df_f_orbitals", f, wc.DF_F_KEY % (functional or "rhf"), lambda f=f: wc.df_f_oracle(f, functional))
         assert o["converged"]
         assert abs(r.energy.scf - o["energy"]) < 1e-8, (r.energy.scf, o["energy"])
+
+
+@pytest.mark.parametrize("df", [False, True], ids=["exact", "density-fitted"])
+def test_f_shell_gradient_matches_differences_of_the_oracle_energy(df):
+    """Gradients with f shells (def2-TZVP, configs[3]'s basis): CO puts an f shell on both centres, so every f class of the
+    quartet gradient kernel runs, (f f|f d) and (f f|f f) with their ket columns in chunks.  check_gradient's procedure and
+    bound (validation/check_gradient.f90: 3.5e-8 Eh/a0) with the oracle as the energy function."""
+    frag = fragment_bohr(wc.F_GRAD_Z, wc.F_GRAD_XYZ)
+    st = ScfSettings(basis_set="def2-tzvp", density_fitting=df, aux_basis_set=wc.AUX if df else "", energy_tol=1e-12,
+                     density_tol=1e-10, guess="gwh", max_iter=200)
+    r = methods.HFMethod(st).calc_gradient(frag)
+    assert not r.has_error, r.error_message
+    o = recorded_oracle("f_shell_gradient_co", frag, wc.F_GRAD_KEY % ("df:" + wc.AUX if df else "exact"),
+                        lambda: wc.f_gradient_oracle(df))
+    fd = np.array(o["gradient"])
+    assert np.max(np.abs(r.gradient - fd)) < 3.5e-8, (np.max(np.abs(r.gradient - fd)), r.gradient, fd)
+    assert np.max(np.abs(r.gradient.sum(axis=1))) < 1e-9
+
+
+def test_kohn_sham_f_shell_gradient_matches_differences_of_the_engine_energy():
+    """configs[3]'s method with a gradient: B3LYP/def2-TZVP on CO (second derivatives of the f functions in the
+    quadrature's gradient), central differences of the engine's own energies."""
+    st = ScfSettings(basis_set="def2-tzvp", functional="b3lyp", energy_tol=1e-12, density_tol=1e-10, guess="gwh", max_iter=200)
+    r = methods.HFMethod(st).calc_gradient(fragment_bohr(wc.F_GRAD_Z, wc.F_GRAD_XYZ))
+    assert not r.has_error, r.error_message
+    h = 2e-3
+    frags = []
+    for a in range(2):
+        for c in range(3):
+            for sgn in (+1, -1):
+                x = wc.F_GRAD_XYZ.copy(); x[a, c] += sgn * h
+                frags.append(fragment_bohr(wc.F_GRAD_Z, x))
+    e = [q.energy.scf for q in methods.run_hip_scf_batch(st, frags)]
+    fd = np.zeros((3, 2))
+    k = 0
+    for a in range(2):
+        for c in range(3):
+            fd[c, a] = (e[k] - e[k + 1]) / (2 * h); k += 2
+    assert np.max(np.abs(r.gradient - fd)) < 5e-6, (np.max(np.abs(r.gradient - fd)), r.gradient, fd)
+    assert np.max(np.abs(r.gradient.sum(axis=1))) < 1e-8

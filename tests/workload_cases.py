@@ -140,3 +140,31 @@ def df_f_oracle(frag, functional):
     mol = oracle_mol("def2-tzvp", frag)
     xc = xc_oracle.XCOracle(mol, functional, 3) if functional else None
     return scf_record(scf_oracle.run_rhf(mol, int(frag.nelec), 100, 1e-9, 1e-7, aux=oracle_mol(AUX, frag), xc=xc))
+
+
+# ---- f-shell gradients: carbon monoxide in def2-TZVP (an f shell on both atoms: every f class, the chunked ones included) ----
+F_GRAD_KEY = "def2-tzvp|%s|1e-12|1e-10|four-point h=2e-3"
+F_GRAD_Z = [6, 8]
+F_GRAD_XYZ = np.array([[0.02, -0.03, 0.01], [0.11, 0.07, 2.17]])
+
+
+def f_gradient_oracle(df):
+    """Four-point differences of the oracle's RHF energy (exact or density-fitted) -> {"gradient": [3][2]}."""
+    from oracle import scf_oracle
+    from tests.helpers import fragment_bohr, oracle_mol
+    h = 2e-3
+
+    def energy(x):
+        f = fragment_bohr(F_GRAD_Z, x)
+        o = scf_oracle.run_rhf(oracle_mol("def2-tzvp", f), 14, 200, 1e-12, 1e-10, aux=oracle_mol(AUX, f) if df else None)
+        assert o.converged
+        return o.energy
+    g = np.zeros((3, 2))
+    for a in range(2):
+        for c in range(3):
+            e = {}
+            for k in (-2, -1, 1, 2):
+                x = F_GRAD_XYZ.copy(); x[a, c] += k * h
+                e[k] = energy(x)
+            g[c, a] = (8.0 * (e[1] - e[-1]) - (e[2] - e[-2])) / (12.0 * h)
+    return {"gradient": g.tolist()}
