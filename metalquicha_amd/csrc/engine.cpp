@@ -264,7 +264,6 @@ static int validate_options(const mqc_hip_scf_options_t& o, const Topology& topo
             XcSpec tu; std::string eu;
             parse_functional(o.functional, tu, eu);
             if (tu.ncomp > 0 && topo.nao > 140) { msg = "unrestricted Kohn-Sham is available up to n_ao = 140"; return MQC_HIP_ERR_UNSUPPORTED; }
-            if (tu.gga == 2) { msg = "meta-GGA functionals are available for restricted runs (the spin-polarised TPSS forms are not built)"; return MQC_HIP_ERR_UNSUPPORTED; }
         }
     } else if (topo.nelec < 2) { msg = "RHF: no electrons to place"; return MQC_HIP_ERR_VALIDATION; }
     if (o.guess < MQC_HIP_GUESS_AUTO || o.guess > MQC_HIP_GUESS_SAC) { msg = "unknown initial guess"; return MQC_HIP_ERR_VALIDATION; }

@@ -354,94 +354,174 @@ __device__ __forceinline__ void eval_functional_pol(const XcSpec& xc, double ra_
 }
 
 
-// ------------------------------------------------------------------ meta-GGA (restricted): value + d/d(rho, sigma, tau)
-struct D3 {
-    double v, d[3];
+// ------------------------------------------------------------------ meta-GGA: value + N first derivatives
+// N = 3: (rho, sigma, tau), restricted.  N = 7: (rho_a, rho_b, sigma_aa, sigma_ab, sigma_bb, tau_a, tau_b), unrestricted.
+template <int N>
+struct DualN {
+    double v, d[N];
 };
-__device__ __forceinline__ D3 mk3(double v) { return {v, {0.0, 0.0, 0.0}}; }
-__device__ __forceinline__ D3 var3(double v, int i) { D3 r = mk3(v); r.d[i] = 1.0; return r; }
-__device__ __forceinline__ D3 operator+(D3 a, D3 b) { D3 r; r.v = a.v + b.v; for (int i = 0; i < 3; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
-__device__ __forceinline__ D3 operator-(D3 a, D3 b) { D3 r; r.v = a.v - b.v; for (int i = 0; i < 3; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
-__device__ __forceinline__ D3 operator*(D3 a, D3 b) { D3 r; r.v = a.v * b.v; for (int i = 0; i < 3; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
-__device__ __forceinline__ D3 operator/(D3 a, D3 b)
+template <int N> __device__ __forceinline__ DualN<N> mkn(double v) { DualN<N> r; r.v = v; for (int i = 0; i < N; ++i) r.d[i] = 0.0; return r; }
+template <int N> __device__ __forceinline__ DualN<N> varn(double v, int k) { DualN<N> r = mkn<N>(v); r.d[k] = 1.0; return r; }
+template <int N> __device__ __forceinline__ DualN<N> operator+(DualN<N> a, DualN<N> b) { DualN<N> r; r.v = a.v + b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+template <int N> __device__ __forceinline__ DualN<N> operator-(DualN<N> a, DualN<N> b) { DualN<N> r; r.v = a.v - b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+template <int N> __device__ __forceinline__ DualN<N> operator*(DualN<N> a, DualN<N> b) { DualN<N> r; r.v = a.v * b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+template <int N> __device__ __forceinline__ DualN<N> operator/(DualN<N> a, DualN<N> b)
 {
     const double inv = 1.0 / b.v, q = a.v * inv;
-    D3 r; r.v = q;
-    for (int i = 0; i < 3; ++i) r.d[i] = (a.d[i] - q * b.d[i]) * inv;
+    DualN<N> r; r.v = q;
+    for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] - q * b.d[i]) * inv;
     return r;
 }
-__device__ __forceinline__ D3 operator+(D3 a, double b) { a.v += b; return a; }
-__device__ __forceinline__ D3 operator+(double b, D3 a) { a.v += b; return a; }
-__device__ __forceinline__ D3 operator-(D3 a, double b) { a.v -= b; return a; }
-__device__ __forceinline__ D3 operator-(double b, D3 a) { return mk3(b) - a; }
-__device__ __forceinline__ D3 operator*(D3 a, double b) { a.v *= b; for (int i = 0; i < 3; ++i) a.d[i] *= b; return a; }
-__device__ __forceinline__ D3 operator*(double b, D3 a) { return a * b; }
-__device__ __forceinline__ D3 operator/(D3 a, double b) { return a * (1.0 / b); }
-__device__ __forceinline__ D3 operator/(double b, D3 a) { return mk3(b) / a; }
-__device__ __forceinline__ D3 chain3(D3 x, double f, double df) { D3 r; r.v = f; for (int i = 0; i < 3; ++i) r.d[i] = df * x.d[i]; return r; }
-__device__ __forceinline__ D3 exp3(D3 x) { const double f = exp(x.v); return chain3(x, f, f); }
-__device__ __forceinline__ D3 log3(D3 x) { return chain3(x, log(x.v), 1.0 / x.v); }
-__device__ __forceinline__ D3 sqrt3(D3 x) { const double f = sqrt(x.v); return chain3(x, f, 0.5 / f); }
-__device__ __forceinline__ D3 cbrt3(D3 x) { const double f = cbrt(x.v); return chain3(x, f, f / (3.0 * x.v)); }
+template <int N> __device__ __forceinline__ DualN<N> operator+(DualN<N> a, double b) { a.v += b; return a; }
+template <int N> __device__ __forceinline__ DualN<N> operator+(double b, DualN<N> a) { a.v += b; return a; }
+template <int N> __device__ __forceinline__ DualN<N> operator-(DualN<N> a, double b) { a.v -= b; return a; }
+template <int N> __device__ __forceinline__ DualN<N> operator-(double b, DualN<N> a) { return mkn<N>(b) - a; }
+template <int N> __device__ __forceinline__ DualN<N> operator*(DualN<N> a, double b) { a.v *= b; for (int i = 0; i < N; ++i) a.d[i] *= b; return a; }
+template <int N> __device__ __forceinline__ DualN<N> operator*(double b, DualN<N> a) { return a * b; }
+template <int N> __device__ __forceinline__ DualN<N> operator/(DualN<N> a, double b) { return a * (1.0 / b); }
+template <int N> __device__ __forceinline__ DualN<N> operator/(double b, DualN<N> a) { return mkn<N>(b) / a; }
+template <int N> __device__ __forceinline__ DualN<N> chainn(DualN<N> x, double f, double df) { DualN<N> r; r.v = f; for (int i = 0; i < N; ++i) r.d[i] = df * x.d[i]; return r; }
+template <int N> __device__ __forceinline__ DualN<N> expn(DualN<N> x) { const double f = exp(x.v); return chainn(x, f, f); }
+template <int N> __device__ __forceinline__ DualN<N> logn(DualN<N> x) { return chainn(x, log(x.v), 1.0 / x.v); }
+template <int N> __device__ __forceinline__ DualN<N> sqrtn(DualN<N> x) { const double f = sqrt(x.v); return chainn(x, f, 0.5 / f); }
+template <int N> __device__ __forceinline__ DualN<N> cbrtn(DualN<N> x) { const double f = cbrt(x.v); return chainn(x, f, f / (3.0 * x.v)); }
+template <int N> __device__ __forceinline__ DualN<N> maxn(DualN<N> a, DualN<N> b) { return a.v > b.v ? a : b; }
+
+template <int N> __device__ __forceinline__ DualN<N> pw_mod_gn(DualN<N> rs, DualN<N> srs, double A, double a1, double b1, double b2, double b3, double b4)
+{
+    const DualN<N> q = 2.0 * A * (b1 * srs + b2 * rs + b3 * rs * srs + b4 * rs * rs);
+    return -2.0 * A * (1.0 + a1 * rs) * logn(1.0 + 1.0 / q);
+}
+
+// the gradient correction H of PBE correlation on top of a uniform-gas energy ec, for a spin-scaling factor phi
+template <int N> __device__ __forceinline__ DualN<N> pbe_c_h(DualN<N> ec, DualN<N> phi, DualN<N> r13, DualN<N> rho, DualN<N> sigma)
+{
+    const DualN<N> phi3 = phi * phi * phi;
+    const DualN<N> ks2 = (4.0 / M_PI) * 3.0936677262801355 * r13;
+    const DualN<N> t2 = sigma / (4.0 * phi * phi * ks2 * rho * rho);
+    const DualN<N> Aa = (PBE_BETA / PBE_GAMMA) / (expn(-1.0 * ec / (PBE_GAMMA * phi3)) - 1.0);
+    const DualN<N> at2 = Aa * t2;
+    return PBE_GAMMA * phi3 * logn(1.0 + (PBE_BETA / PBE_GAMMA) * t2 * (1.0 + at2) / (1.0 + at2 + at2 * at2));
+}
 
 // PBE correlation energy per particle at zeta = 0 or zeta = 1 (lda_c_pw_mod inside), the two ends TPSS needs
-__device__ __forceinline__ D3 pbe_c_eps_fixed_zeta(D3 rho, D3 sigma, bool ferro)
+template <int N> __device__ __forceinline__ DualN<N> pbe_c_eps_fixed_zeta(DualN<N> rho, DualN<N> sigma, bool ferro)
 {
-    const D3 r13 = cbrt3(rho);
-    const D3 rs = 0.6203504908994001 / r13;
-    const D3 srs = sqrt3(rs);
-    const double A = ferro ? 0.01554535 : 0.0310907, a1 = ferro ? 0.20548 : 0.21370, b1 = ferro ? 14.1189 : 7.5957,
-                 b2 = ferro ? 6.1977 : 3.5876, b3 = ferro ? 3.3662 : 1.6382, b4 = ferro ? 0.62517 : 0.49294;
-    const D3 q = 2.0 * A * (b1 * srs + b2 * rs + b3 * rs * srs + b4 * rs * rs);
-    const D3 ec = -2.0 * A * (1.0 + a1 * rs) * log3(1.0 + 1.0 / q);
-    const double phi = ferro ? 0.7937005259840998 : 1.0, phi3 = phi * phi * phi;
-    const D3 kf = 3.0936677262801355 * r13;
-    const D3 ks2 = (4.0 / M_PI) * kf;
-    const D3 t2 = sigma / (4.0 * phi * phi * ks2 * rho * rho);
-    const D3 Aa = (PBE_BETA / PBE_GAMMA) / (exp3(-1.0 * ec / (PBE_GAMMA * phi3)) - 1.0);
-    const D3 at2 = Aa * t2;
-    const D3 H = PBE_GAMMA * phi3 * log3(1.0 + (PBE_BETA / PBE_GAMMA) * t2 * (1.0 + at2) / (1.0 + at2 + at2 * at2));
-    return ec + H;
+    const DualN<N> r13 = cbrtn(rho);
+    const DualN<N> rs = 0.6203504908994001 / r13;
+    const DualN<N> srs = sqrtn(rs);
+    const DualN<N> ec = ferro ? pw_mod_gn(rs, srs, 0.01554535, 0.20548, 14.1189, 6.1977, 3.3662, 0.62517)
+                              : pw_mod_gn(rs, srs, 0.0310907, 0.21370, 7.5957, 3.5876, 1.6382, 0.49294);
+    return ec + pbe_c_h(ec, mkn<N>(ferro ? 0.7937005259840998 : 1.0), r13, rho, sigma);
+}
+
+// PBE correlation energy per particle for two spin densities (gga_c_pbe with lda_c_pw_mod, as eval_functional_pol)
+template <int N> __device__ __forceinline__ DualN<N> pbe_c_eps_pol(DualN<N> rho, DualN<N> z, DualN<N> sigma)
+{
+    const DualN<N> r13 = cbrtn(rho);
+    const DualN<N> rs = 0.6203504908994001 / r13;
+    const DualN<N> srs = sqrtn(rs);
+    const DualN<N> g0 = pw_mod_gn(rs, srs, 0.0310907, 0.21370, 7.5957, 3.5876, 1.6382, 0.49294);
+    const DualN<N> g1 = pw_mod_gn(rs, srs, 0.01554535, 0.20548, 14.1189, 6.1977, 3.3662, 0.62517);
+    const DualN<N> g2 = pw_mod_gn(rs, srs, 0.0168869, 0.11125, 10.357, 3.6231, 0.88026, 0.49671);       // = -alpha_c
+    const DualN<N> opz13 = cbrtn(1.0 + z), omz13 = cbrtn(1.0 - z);
+    const DualN<N> fz = ((1.0 + z) * opz13 + (1.0 - z) * omz13 - 2.0) * (1.0 / 0.5198420997897464);
+    const DualN<N> z2 = z * z, z4 = z2 * z2;
+    const DualN<N> ec = g0 - g2 * fz * (1.0 - z4) * (1.0 / 1.709920934161365617563962776245) + (g1 - g0) * fz * z4;
+    const DualN<N> phi = 0.5 * (opz13 * opz13 + omz13 * omz13);
+    return ec + pbe_c_h(ec, phi, r13, rho, sigma);
+}
+
+// libxc mgga_x_tpss for a spin-unpolarised density, energy per volume (PRL 91, 146401 eqs. 5-10)
+template <int N> __device__ __forceinline__ DualN<N> tpss_x_unpol(DualN<N> rho, DualN<N> sigma, DualN<N> tau)
+{
+    const double b = 0.40, c = 1.59096, e = 1.537, kappa = 0.804, mu = 0.21951, mu_ge = 10.0 / 81.0, se = 1.2397580409095959;
+    const DualN<N> r13 = cbrtn(rho);
+    const DualN<N> r23 = r13 * r13;
+    const DualN<N> z = sigma / (8.0 * rho * tau);
+    const DualN<N> z2 = z * z;
+    const DualN<N> p = sigma / ((4.0 * 9.570780000627305) * (r23 * rho * rho));            // 4 (3 pi^2)^(2/3) rho^(8/3)
+    const DualN<N> tau_unif = (0.3 * 9.570780000627305) * (r23 * rho);
+    const DualN<N> alpha = (tau - sigma / (8.0 * rho)) / tau_unif;
+    const DualN<N> qb = 0.45 * (alpha - 1.0) / sqrtn(1.0 + b * alpha * (alpha - 1.0)) + (2.0 / 3.0) * p;
+    const DualN<N> opz2 = 1.0 + z2;
+    const DualN<N> num = (mu_ge + c * z2 / (opz2 * opz2)) * p + (146.0 / 2025.0) * qb * qb
+                       - (73.0 / 405.0) * qb * sqrtn(0.5 * (0.36 * z2 + p * p)) + (mu_ge * mu_ge / kappa) * p * p
+                       + (2.0 * se * mu_ge * 0.36) * z2 + (e * mu) * p * p * p;
+    const DualN<N> den = (1.0 + se * p) * (1.0 + se * p);
+    const DualN<N> x = num / den;
+    const DualN<N> fx = (1.0 + kappa) - kappa / (1.0 + x / kappa);
+    return -0.7385587663820224 * (rho * r13) * fx;
 }
 
 // libxc mgga_x_tpss + mgga_c_tpss, unpolarised (Tao, Perdew, Staroverov, Scuseria, PRL 91, 146401 eqs. 5-14);
 // f per volume and d/d(rho, sigma, tau), zero below the density threshold.  mqc_xc_spec.f90:142-166 names the pair.
 __device__ __forceinline__ void eval_functional_mgga(const XcSpec& xc, double rho_in, double sigma_in, double tau_in, double& f, double* dv)
 {
+    typedef DualN<3> D3;
     f = 0.0;
     dv[0] = dv[1] = dv[2] = 0.0;
     if (!(rho_in > XC_DENS_THRESHOLD)) return;
-    const D3 rho = var3(rho_in, 0), sigma = var3(fmax(sigma_in, 1.0e-40), 1), tau = var3(fmax(tau_in, 1.0e-20), 2);
-    const D3 r13 = cbrt3(rho);
-    const D3 z = sigma / (8.0 * rho * tau);
-    const D3 z2 = z * z;
+    const D3 rho = varn<3>(rho_in, 0), sigma = varn<3>(fmax(sigma_in, 1.0e-40), 1), tau = varn<3>(fmax(tau_in, 1.0e-20), 2);
     for (int k = 0; k < xc.ncomp; ++k) {
-        D3 d = mk3(0.0);
+        D3 d = mkn<3>(0.0);
         if (xc.id[k] == XC_MGGA_X_TPSS) {
-            const double b = 0.40, c = 1.59096, e = 1.537, kappa = 0.804, mu = 0.21951, mu_ge = 10.0 / 81.0, se = 1.2397580409095959;
-            const D3 r23 = r13 * r13;
-            const D3 p = sigma / ((4.0 * 9.570780000627305) * (r23 * rho * rho));            // 4 (3 pi^2)^(2/3) rho^(8/3)
-            const D3 tau_unif = (0.3 * 9.570780000627305) * (r23 * rho);
-            const D3 alpha = (tau - sigma / (8.0 * rho)) / tau_unif;
-            const D3 qb = 0.45 * (alpha - 1.0) / sqrt3(1.0 + b * alpha * (alpha - 1.0)) + (2.0 / 3.0) * p;
-            const D3 opz2 = 1.0 + z2;
-            const D3 num = (mu_ge + c * z2 / (opz2 * opz2)) * p + (146.0 / 2025.0) * qb * qb
-                         - (73.0 / 405.0) * qb * sqrt3(0.5 * (0.36 * z2 + p * p)) + (mu_ge * mu_ge / kappa) * p * p
-                         + (2.0 * se * mu_ge * 0.36) * z2 + (e * mu) * p * p * p;
-            const D3 den = (1.0 + se * p) * (1.0 + se * p);
-            const D3 x = num / den;
-            const D3 fx = (1.0 + kappa) - kappa / (1.0 + x / kappa);
-            d = -0.7385587663820224 * (rho * r13) * fx;
+            d = tpss_x_unpol(rho, sigma, tau);
         } else if (xc.id[k] == XC_MGGA_C_TPSS) {
             const double dd = 2.8, C0 = 0.53;
+            const D3 z = sigma / (8.0 * rho * tau);
+            const D3 z2 = z * z;
             const D3 e_pbe = pbe_c_eps_fixed_zeta(rho, sigma, false);
-            const D3 e_one = pbe_c_eps_fixed_zeta(0.5 * rho, 0.25 * sigma, true);
-            const D3 e_til = e_one.v > e_pbe.v ? e_one : e_pbe;
+            const D3 e_til = maxn(pbe_c_eps_fixed_zeta(0.5 * rho, 0.25 * sigma, true), e_pbe);
             const D3 e_rev = e_pbe * (1.0 + C0 * z2) - (1.0 + C0) * z2 * e_til;
             d = rho * e_rev * (1.0 + dd * e_rev * z2 * z);
         }
         f += xc.w[k] * d.v;
         for (int i = 0; i < 3; ++i) dv[i] += xc.w[k] * d.d[i];
+    }
+}
+
+// the same pair for two spin densities: exchange by spin scaling, correlation with C(zeta, xi) (eq. 14);
+// dv = d/d(rho_a, rho_b, sigma_aa, sigma_ab, sigma_bb, tau_a, tau_b)
+__device__ __forceinline__ void eval_functional_mgga_pol(const XcSpec& xc, double ra_in, double rb_in, double saa, double sab, double sbb,
+                                                         double ta_in, double tb_in, double& f, double* dv)
+{
+    typedef DualN<7> D7;
+    f = 0.0;
+    for (int i = 0; i < 7; ++i) dv[i] = 0.0;
+    if (!(ra_in + rb_in > XC_DENS_THRESHOLD)) return;
+    const D7 ra = varn<7>(fmax(ra_in, XC_SPIN_FLOOR), 0), rb = varn<7>(fmax(rb_in, XC_SPIN_FLOOR), 1);
+    const D7 Saa = varn<7>(fmax(saa, 1.0e-40), 2), Sab = varn<7>(sab, 3), Sbb = varn<7>(fmax(sbb, 1.0e-40), 4);
+    const D7 ta = varn<7>(fmax(ta_in, 1.0e-20), 5), tb = varn<7>(fmax(tb_in, 1.0e-20), 6);
+    for (int k = 0; k < xc.ncomp; ++k) {
+        D7 d = mkn<7>(0.0);
+        if (xc.id[k] == XC_MGGA_X_TPSS) {
+            d = 0.5 * (tpss_x_unpol(2.0 * ra, 4.0 * Saa, 2.0 * ta) + tpss_x_unpol(2.0 * rb, 4.0 * Sbb, 2.0 * tb));
+        } else if (xc.id[k] == XC_MGGA_C_TPSS) {
+            const double dd = 2.8;
+            const D7 rho = ra + rb;
+            const D7 zeta = (ra - rb) / rho;
+            const D7 sig = Saa + 2.0 * Sab + Sbb;
+            const D7 z = sig / (8.0 * rho * (ta + tb));
+            const D7 z2 = z * z;
+            const D7 e_pbe = pbe_c_eps_pol(rho, zeta, sig);
+            const D7 et_a = maxn(pbe_c_eps_fixed_zeta(ra, Saa, true), e_pbe);
+            const D7 et_b = maxn(pbe_c_eps_fixed_zeta(rb, Sbb, true), e_pbe);
+            const D7 omz = 1.0 - zeta, opz = 1.0 + zeta;
+            const D7 gz2 = (omz * omz * Saa - 2.0 * omz * opz * Sab + opz * opz * Sbb) / (rho * rho);       // |grad zeta|^2
+            const D7 r13 = cbrtn(rho);
+            const D7 xi2 = gz2 / ((4.0 * 9.570780000627305) * (r13 * r13));
+            const D7 zeta2 = zeta * zeta;
+            const D7 c0 = 0.53 + 0.87 * zeta2 + 0.50 * zeta2 * zeta2 + 2.26 * zeta2 * zeta2 * zeta2;
+            const D7 opz13 = cbrtn(opz), omz13 = cbrtn(omz);
+            const D7 den = 1.0 + 0.5 * xi2 * (1.0 / (opz * opz13) + 1.0 / (omz * omz13));
+            const D7 den2 = den * den;
+            const D7 C = c0 / (den2 * den2);
+            const D7 e_rev = e_pbe * (1.0 + C * z2) - (1.0 + C) * z2 * (ra * et_a + rb * et_b) / rho;
+            d = rho * e_rev * (1.0 + dd * e_rev * z2 * z);
+        }
+        f += xc.w[k] * d.v;
+        for (int i = 0; i < 7; ++i) dv[i] += xc.w[k] * d.d[i];
     }
 }
 
@@ -2168,21 +2248,22 @@ static void xc_uks_launch(const BatchView& bv, int oa, hipStream_t s)
         hipLaunchKernelGGL(kern, dim3(gx, bv.nfrag), dim3(XC_NT), lds, s, bv, oa | (spin << 1));
 }
 
-// Restricted meta-GGA quadrature, parity-first on the vector units (the reference's meta-GGA lives on its CPU backend:
+// Meta-GGA quadrature (restricted, or unrestricted with both spin densities per launch), parity-first on the vector units (the reference's meta-GGA lives on its CPU backend:
 // eval_rho's tau, mqc_libcint_ao.f90:374-417; accumulate_xc_matrix's third term, mqc_libcint_xc.F90:1436-1448).
 // Per tile of PT points: chi and grad chi in LDS, X = D chi -> rho, grad rho; X = D d_d chi for d = x, y, z ->
 // tau = 1/2 sum_d X_d . d_d chi; then A = (w v_rho / 2) chi + w c . grad chi and
 //     acc += A^T chi + (w v_tau / 4) sum_d (d_d chi)^T d_d chi        (V_xc = acc + acc^T)
-template <int PT, int NV>
+template <int PT, int NV, bool UKS>
 __global__ void __launch_bounds__(XC_NT) xc_mgga_kernel(BatchView bv, int flags)
 {
     extern __shared__ double lds[];
     const int f = blockIdx.y;
+    const bool beta = UKS && (flags & 2) != 0;           // unrestricted: one launch per spin potential, both densities in each
     if ((flags & 1) && bv.istate[4 * f] == ST_DONE) return;
     const int n = bv.n, tid = threadIdx.x;
     const TopologyDev& tp = bv.topo;
     const GridDev& gd = bv.grid;
-    constexpr int PTP = PT + 1;
+    constexpr int PTP = PT + 1, NS = UKS ? 2 : 1;
     double* chi = lds;
     double* gx = chi + (size_t)n * PTP;
     double* gy = gx + (size_t)n * PTP;
@@ -2190,10 +2271,10 @@ __global__ void __launch_bounds__(XC_NT) xc_mgga_kernel(BatchView bv, int flags)
     double* X = gz + (size_t)n * PTP;
     double* A = X + (size_t)n * PTP;
     double* pw = A + (size_t)n * PTP;                 // [PT] weights
-    double* pc = pw + PT;                             // [5][PT]: w v_rho / 2, w c_x, w c_y, w c_z, w v_tau / 4
+    double* pc = pw + PT;                             // [5][PT]: w v_rho / 2, w c_x, w c_y, w c_z, w v_tau / 4 (this spin's)
 
     const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
-    const double* __restrict__ D = bv.D + (size_t)f * n * n;
+    const double* __restrict__ Dsp[2] = {bv.D + (size_t)f * n * n, UKS ? bv.Db + (size_t)f * n * n : nullptr};
     const double* __restrict__ wts = gd.weights + (size_t)f * gd.npts;
 
     double acc[NV];
@@ -2216,45 +2297,67 @@ __global__ void __launch_bounds__(XC_NT) xc_mgga_kernel(BatchView bv, int flags)
             }
         }
         if (tid < PT) pw[tid] = (g0 + tid < gd.npts) ? wts[g0 + tid] : 0.0;
-        double rho = 0.0, gr[3] = {0.0, 0.0, 0.0}, tau = 0.0;
-        for (int pass = 0; pass < 4; ++pass) {
-            const double* __restrict__ src = pass == 0 ? chi : pass == 1 ? gx : pass == 2 ? gy : gz;
-            __syncthreads();
-            for (int idx = tid; idx < n * PT; idx += XC_NT) {
-                const int mu = idx / PT, p = idx - mu * PT;
-                const double* __restrict__ dr = D + (size_t)mu * n;
-                double sum = 0.0;
-                for (int nu = 0; nu < n; ++nu) sum += dr[nu] * src[nu * PTP + p];
-                X[mu * PTP + p] = sum;
-            }
-            __syncthreads();
-            if (tid < PT) {
-                const int p = tid;
-                if (pass == 0) {
-                    for (int mu = 0; mu < n; ++mu) {
-                        const double x = X[mu * PTP + p];
-                        rho += x * chi[mu * PTP + p];
-                        gr[0] += x * gx[mu * PTP + p]; gr[1] += x * gy[mu * PTP + p]; gr[2] += x * gz[mu * PTP + p];
+        double rho[NS], gr[NS][3], tau[NS];
+#pragma unroll
+        for (int sp = 0; sp < NS; ++sp) { rho[sp] = 0.0; tau[sp] = 0.0; gr[sp][0] = gr[sp][1] = gr[sp][2] = 0.0; }
+#pragma unroll
+        for (int sp = 0; sp < NS; ++sp)
+            for (int pass = 0; pass < 4; ++pass) {
+                const double* __restrict__ src = pass == 0 ? chi : pass == 1 ? gx : pass == 2 ? gy : gz;
+                const double* __restrict__ D = Dsp[sp];
+                __syncthreads();
+                for (int idx = tid; idx < n * PT; idx += XC_NT) {
+                    const int mu = idx / PT, p = idx - mu * PT;
+                    const double* __restrict__ dr = D + (size_t)mu * n;
+                    double sum = 0.0;
+                    for (int nu = 0; nu < n; ++nu) sum += dr[nu] * src[nu * PTP + p];
+                    X[mu * PTP + p] = sum;
+                }
+                __syncthreads();
+                if (tid < PT) {
+                    const int p = tid;
+                    if (pass == 0) {
+                        for (int mu = 0; mu < n; ++mu) {
+                            const double x = X[mu * PTP + p];
+                            rho[sp] += x * chi[mu * PTP + p];
+                            gr[sp][0] += x * gx[mu * PTP + p]; gr[sp][1] += x * gy[mu * PTP + p]; gr[sp][2] += x * gz[mu * PTP + p];
+                        }
+                    } else {
+                        double t = 0.0;
+                        for (int mu = 0; mu < n; ++mu) t += X[mu * PTP + p] * src[mu * PTP + p];
+                        tau[sp] += 0.5 * t;
                     }
-                } else {
-                    double t = 0.0;
-                    for (int mu = 0; mu < n; ++mu) t += X[mu * PTP + p] * src[mu * PTP + p];
-                    tau += 0.5 * t;
                 }
             }
-        }
         if (tid < PT) {
             const int p = tid;
-            for (int d = 0; d < 3; ++d) gr[d] *= 2.0;
-            const double sigma = gr[0] * gr[0] + gr[1] * gr[1] + gr[2] * gr[2];
-            double fx, dv[3];
-            eval_functional_mgga(bv.xc, rho, sigma, tau, fx, dv);
             const double w = pw[p];
-            e_acc += w * fx;
-            n_acc += w * rho;
-            pc[p] = 0.5 * w * dv[0];
-            for (int d = 0; d < 3; ++d) pc[(1 + d) * PT + p] = w * 2.0 * dv[1] * gr[d];
-            pc[4 * PT + p] = 0.25 * w * dv[2];
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp)
+                for (int d = 0; d < 3; ++d) gr[sp][d] *= 2.0;
+            if (UKS) {
+                const double* ga = gr[0]; const double* gb = gr[NS - 1];
+                const double saa = ga[0] * ga[0] + ga[1] * ga[1] + ga[2] * ga[2];
+                const double sab = ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2];
+                const double sbb = gb[0] * gb[0] + gb[1] * gb[1] + gb[2] * gb[2];
+                double fx, dv[7];
+                eval_functional_mgga_pol(bv.xc, rho[0], rho[NS - 1], saa, sab, sbb, tau[0], tau[NS - 1], fx, dv);
+                e_acc += w * fx;
+                n_acc += w * (rho[0] + rho[NS - 1]);
+                pc[p] = 0.5 * w * (beta ? dv[1] : dv[0]);
+                const double vss = beta ? dv[4] : dv[2], vab = dv[3];
+                for (int d = 0; d < 3; ++d) pc[(1 + d) * PT + p] = w * (2.0 * vss * (beta ? gb[d] : ga[d]) + vab * (beta ? ga[d] : gb[d]));
+                pc[4 * PT + p] = 0.25 * w * (beta ? dv[6] : dv[5]);
+            } else {
+                const double sigma = gr[0][0] * gr[0][0] + gr[0][1] * gr[0][1] + gr[0][2] * gr[0][2];
+                double fx, dv[3];
+                eval_functional_mgga(bv.xc, rho[0], sigma, tau[0], fx, dv);
+                e_acc += w * fx;
+                n_acc += w * rho[0];
+                pc[p] = 0.5 * w * dv[0];
+                for (int d = 0; d < 3; ++d) pc[(1 + d) * PT + p] = w * 2.0 * dv[1] * gr[0][d];
+                pc[4 * PT + p] = 0.25 * w * dv[2];
+            }
         }
         __syncthreads();
         for (int idx = tid; idx < n * PT; idx += XC_NT) {
@@ -2280,17 +2383,19 @@ __global__ void __launch_bounds__(XC_NT) xc_mgga_kernel(BatchView bv, int flags)
         }
         __syncthreads();
     }
-    double* Vx = bv.Vxc + (size_t)f * n * n;
+    double* Vx = bv.Vxc + ((size_t)(beta ? bv.nfrag : 0) + f) * n * n;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int idx = tid + XC_NT * k;
         if (idx < n * n && acc[k] != 0.0) atomicAdd(&Vx[idx], acc[k]);
     }
+    if (!beta) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { e_acc += __shfl_down(e_acc, off, 64); n_acc += __shfl_down(n_acc, off, 64); }
-    if (tid == 0) {
-        atomicAdd(&bv.scal[(size_t)f * 8 + 5], e_acc);
-        atomicAdd(&bv.scal[(size_t)f * 8 + 6], n_acc);
+        for (int off = 32; off > 0; off >>= 1) { e_acc += __shfl_down(e_acc, off, 64); n_acc += __shfl_down(n_acc, off, 64); }
+        if (tid == 0) {
+            atomicAdd(&bv.scal[(size_t)f * 8 + 5], e_acc);
+            atomicAdd(&bv.scal[(size_t)f * 8 + 6], n_acc);
+        }
     }
 }
 
@@ -2299,13 +2404,20 @@ static void xc_mgga_launch(const BatchView& bv, int oa, hipStream_t s)
 {
     const int n = bv.n;
     const size_t lds = sizeof(double) * ((size_t)6 * n * (PT + 1) + 6 * PT + 16);
-    auto kern = xc_mgga_kernel<PT, NV>;
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int ntiles = (bv.grid.npts + PT - 1) / PT;
     int gx = (8192 + bv.nfrag - 1) / bv.nfrag;
     if (gx > ntiles) gx = ntiles;
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(kern, dim3(gx, bv.nfrag), dim3(XC_NT), lds, s, bv, oa);
+    if (bv.uhf) {
+        auto kern = xc_mgga_kernel<PT, NV, true>;
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        for (int spin = 0; spin < 2; ++spin)
+            hipLaunchKernelGGL(kern, dim3(gx, bv.nfrag), dim3(XC_NT), lds, s, bv, oa | (spin << 1));
+    } else {
+        auto kern = xc_mgga_kernel<PT, NV, false>;
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(gx, bv.nfrag), dim3(XC_NT), lds, s, bv, oa);
+    }
 }
 
 void launch_xc(const BatchView& bv, bool only_active, hipStream_t s)
@@ -2315,7 +2427,7 @@ void launch_xc(const BatchView& bv, bool only_active, hipStream_t s)
     hipLaunchKernelGGL(xc_reset_kernel, dim3((bv.nfrag + 255) / 256), dim3(256), 0, s, bv);
     const bool gga = bv.xc.gga != 0;
     if (bv.xc.gga == 2) {
-        // meta-GGA (restricted, n <= 140: validate_options refuses the rest): 16-point tiles, LDS 6 n 17 doubles <= 114 KB
+        // meta-GGA (restricted or unrestricted, n <= 140: validate_options refuses the rest): 16-point tiles, LDS 6 n 17 doubles <= 114 KB
         const int nv = (n * n + XC_NT - 1) / XC_NT;
         if (nv <= 10) xc_mgga_launch<16, 10>(bv, oa, s);
         else if (nv <= 29) xc_mgga_launch<16, 29>(bv, oa, s);

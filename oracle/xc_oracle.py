@@ -478,6 +478,61 @@ def eval_functional_mgga(name: str, rho, sigma, tau):
     return np.where(ok, f, zz), np.where(ok, dv[0], zz), np.where(ok, dv[1], zz), np.where(ok, dv[2], zz)
 
 
+
+# ---- spin-polarised TPSS: variables (rho_a, rho_b, sigma_aa, sigma_ab, sigma_bb, tau_a, tau_b)
+def mgga_x_tpss_pol(ra, rb, saa, sab, sbb, ta, tb):
+    """Exchange spin scaling: E[ra, rb] = (E[2 ra] + E[2 rb]) / 2 with sigma -> 4 sigma_ss, tau -> 2 tau_s."""
+    return 0.5 * (mgga_x_tpss(2.0 * ra, 4.0 * saa, 2.0 * ta) + mgga_x_tpss(2.0 * rb, 4.0 * sbb, 2.0 * tb))
+
+
+def mgga_c_tpss_pol(ra, rb, saa, sab, sbb, ta, tb):
+    """revPKZB / TPSS correlation for two spin densities (PRL 91, 146401 eqs. 11-14; libxc mgga_c_tpss):
+    C(zeta, xi) = C(zeta, 0) / {1 + xi^2 [(1+zeta)^(-4/3) + (1-zeta)^(-4/3)] / 2}^4,  xi = |grad zeta| / 2 (3 pi^2 rho)^(1/3)."""
+    d = 2.8
+    rho = ra + rb
+    zeta = (ra - rb) / rho
+    sig = saa + 2.0 * sab + sbb
+    tau = ta + tb
+    z = sig / (8.0 * rho * tau)
+    z2 = z * z
+    e_pbe = gga_c_pbe_pol(ra, rb, saa, sab, sbb) / rho
+    e_a = _pbe_c_eps_fixed_zeta(ra, saa, True)
+    e_b = _pbe_c_eps_fixed_zeta(rb, sbb, True)
+    et_a = _where(e_a.v > e_pbe.v, e_a, e_pbe)
+    et_b = _where(e_b.v > e_pbe.v, e_b, e_pbe)
+    omz, opz = 1.0 - zeta, 1.0 + zeta
+    gz2 = (omz * omz * saa - 2.0 * omz * opz * sab + opz * opz * sbb) / (rho * rho)          # |grad zeta|^2
+    xi2 = gz2 / (4.0 * (3.0 * math.pi ** 2) ** (2.0 / 3.0) * rho ** (2.0 / 3.0))
+    zeta2 = zeta * zeta
+    c0 = 0.53 + 0.87 * zeta2 + 0.50 * zeta2 * zeta2 + 2.26 * zeta2 * zeta2 * zeta2
+    den = 1.0 + 0.5 * xi2 * (opz ** (-4.0 / 3.0) + omz ** (-4.0 / 3.0))
+    den2 = den * den
+    C = c0 / (den2 * den2)
+    e_rev = e_pbe * (1.0 + C * z2) - (1.0 + C) * z2 * (ra * et_a + rb * et_b) / rho
+    return rho * e_rev * (1.0 + d * e_rev * z2 * z)
+
+
+MGGA_POLARISED = {mgga_x_tpss: mgga_x_tpss_pol, mgga_c_tpss: mgga_c_tpss_pol}
+
+
+def eval_functional_mgga_pol(name: str, ra, rb, saa, sab, sbb, ta, tb):
+    """-> f per volume and the seven derivatives (v_rho_a, v_rho_b, v_sigma_aa, v_sigma_ab, v_sigma_bb, v_tau_a, v_tau_b)."""
+    comps, _ = MGGA_FUNCTIONALS[name.lower()]
+    ok = (ra + rb) > DENS_THRESHOLD
+    xs = [np.where(ok, np.maximum(ra, SPIN_FLOOR), 0.5), np.where(ok, np.maximum(rb, SPIN_FLOOR), 0.5),
+          np.where(ok, np.maximum(saa, 1.0e-40), 1.0e-40), np.where(ok, sab, 0.0), np.where(ok, np.maximum(sbb, 1.0e-40), 1.0e-40),
+          np.where(ok, np.maximum(ta, TAU_THRESHOLD), 1.0), np.where(ok, np.maximum(tb, TAU_THRESHOLD), 1.0)]
+    V = [DualN.var(x, i, 7) for i, x in enumerate(xs)]
+    f = 0.0
+    dv = [0.0] * 7
+    for wgt, fn in comps:
+        q = MGGA_POLARISED[fn](*V)
+        f = f + wgt * q.v
+        dv = [a + wgt * b for a, b in zip(dv, q.d)]
+    zz = np.zeros_like(ra)
+    return np.where(ok, f, zz), [np.where(ok, t, zz) for t in dv]
+
+
 @dataclass
 class XCOracle:
     """`xc` object for scf_oracle.run_rhf: .exx and .potential(D) -> (E_xc, V_xc)."""
@@ -552,7 +607,15 @@ class XCOracle:
                 saa = np.einsum("dp,dp->p", ga, ga); sab = np.einsum("dp,dp->p", ga, gb); sbb = np.einsum("dp,dp->p", gb, gb)
             else:
                 saa = sab = sbb = np.zeros_like(ra)
-            f, (vra, vrb, vaa, vab, vbb) = eval_functional_pol(self.name, ra, rb, saa, sab, sbb)
+            if self.mgga:
+                ta = 0.5 * sum(np.einsum("pi,pi->p", g[k] @ Da, g[k]) for k in range(3))
+                tb = 0.5 * sum(np.einsum("pi,pi->p", g[k] @ Db, g[k]) for k in range(3))
+                f, (vra, vrb, vaa, vab, vbb, vta, vtb) = eval_functional_mgga_pol(self.name, ra, rb, saa, sab, sbb, ta, tb)
+                for k in range(3):
+                    Va += 0.5 * (g[k] * (w * vta)[:, None]).T @ g[k]
+                    Vb += 0.5 * (g[k] * (w * vtb)[:, None]).T @ g[k]
+            else:
+                f, (vra, vrb, vaa, vab, vbb) = eval_functional_pol(self.name, ra, rb, saa, sab, sbb)
             exc += float(np.dot(w, f)); nel += float(np.dot(w, ra + rb))
             Va += (ao * (w * vra)[:, None]).T @ ao
             Vb += (ao * (w * vrb)[:, None]).T @ ao

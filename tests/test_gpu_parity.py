@@ -243,7 +243,7 @@ def test_uhf_batch_and_closed_shell_limit():
 def _uks_cases():
     cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "manifest_subset.json")))["cases"]
     return [c for c in cases if c["method"] == "dft" and c["unrestricted"] and c["driver"] == "Energy"
-            and c["functional"] in xc_oracle.FUNCTIONALS and not c["density_fitting"]]
+            and c["functional"] in xc_oracle.RESTRICTED_FUNCTIONALS and not c["density_fitting"]]
 
 
 @pytest.mark.parametrize("case", _uks_cases(), ids=[c["name"] for c in _uks_cases()])

@@ -139,8 +139,8 @@ def test_tpss_batch_matches_oracle(df):
 
 def test_tpss_refusals_name_what_is_missing():
     w = wc.tpss_fragments()[0]
-    r = methods.run_hip_scf(methods.ScfSettings(basis_set="sto-3g", functional="tpss", unrestricted=True), w)
-    assert r.has_error and "restricted" in r.error_message
+    r = methods.run_hip_scf(methods.ScfSettings(basis_set="sto-3g", functional="m06-l"), w)
+    assert r.has_error and "not available" in r.error_message
     r = methods.run_hip_scf(methods.ScfSettings(basis_set="sto-3g", functional="tpss"), w, want_gradient=True)
     assert r.has_error and "gradient" in r.error_message
 

@@ -183,13 +183,14 @@ def test_manifest_kohn_sham(case):
     assert abs(xc.n_electrons - frag.nelec) < 1e-4
 
 
-_UKS = [c for c in _CASES if c["method"] == "dft" and c["functional"] in xc_oracle.FUNCTIONALS and c["unrestricted"]
+_UKS = [c for c in _CASES if c["method"] == "dft" and c["functional"] in xc_oracle.RESTRICTED_FUNCTIONALS and c["unrestricted"]
         and c["driver"] == "Energy" and not c["density_fitting"]]
 
 
 @pytest.mark.parametrize("case", _UKS, ids=[c["name"] for c in _UKS])
 def test_manifest_unrestricted_kohn_sham(case):
-    """UKS goldens (CH3 doublet SVWN / PBE / B3LYP, O2 triplet PBE), tolerance 1e-9: pins the spin-polarised forms --
+    """UKS goldens (CH3 doublet SVWN / PBE / B3LYP / TPSS, O2 triplet PBE), tolerance 1e-9: pins the spin-polarised forms --
+    TPSS exchange by spin scaling with tau_s, revPKZB correlation with C(zeta, xi) and the per-spin max[] terms --
     lda_x spin scaling, VWN5 with the spin stiffness, VWN-RPA's f(zeta) interpolation, B88 per spin, LYP for two
     spin densities, PBE exchange scaling and PBE correlation with phi(zeta) over polarised pw_mod -- and
     xc_add_potential_uks' cross-spin gradient term."""
@@ -258,6 +259,20 @@ def test_meta_gga_derivatives_by_finite_differences():
     r = np.array([0.3, 2.0]); tu = 0.3 * (3 * np.pi ** 2) ** (2 / 3) * r ** (5 / 3)
     V = [xc_oracle.DualN.var(x, i, 3) for i, x in enumerate((r, np.full(2, 1e-40), tu))]
     assert np.allclose(xc_oracle.mgga_x_tpss(*V).v, -0.75 * (3 / np.pi) ** (1 / 3) * r ** (4 / 3), rtol=1e-12)
+
+
+def test_polarised_meta_gga_reduces_to_the_restricted_form():
+    rng = np.random.default_rng(6)
+    rho = 10.0 ** rng.uniform(-3, 1, size=100)
+    sigma = (rho ** (4.0 / 3.0) * 10.0 ** rng.uniform(-2, 1, size=100)) ** 2
+    tau = sigma / (8.0 * rho) / rng.uniform(0.05, 0.95, size=100)
+    f0, vr, vs, vt = xc_oracle.eval_functional_mgga("tpss", rho, sigma, tau)
+    f1, dv = xc_oracle.eval_functional_mgga_pol("tpss", rho / 2, rho / 2, sigma / 4, sigma / 4, sigma / 4, tau / 2, tau / 2)
+    assert np.max(np.abs(f0 - f1) / np.abs(f0)) < 1e-13
+    assert np.max(np.abs(dv[0] - vr)) < 1e-12 and np.max(np.abs(dv[1] - vr)) < 1e-12          # d/d rho_a = d/d rho at zeta = 0
+    assert np.max(np.abs(dv[5] - vt)) < 1e-10 and np.max(np.abs(dv[6] - vt)) < 1e-10
+    # sigma = saa + 2 sab + sbb: the restricted v_sigma is the common value of v_aa + v_bb + v_ab weighted by d sigma_xy / d sigma
+    assert np.max(np.abs((dv[2] + dv[3] + dv[4]) / 4.0 - vs) / (np.abs(vs) + 1e-12)) < 1e-9
 
 
 def test_recorded_fixtures_spot_check_against_the_live_oracle():
