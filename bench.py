@@ -378,12 +378,25 @@ def main():
         if big_n == 0:       # small workloads (--side 2): all launches
             big_s, big_b, big_n = st.fock_kernel_seconds, st.fock_bytes, int(st.fock_launches)
         jk_name = "df_jk_mfma_kernel" if args.df else "jk_incore_kernel"
+        jk_layout = None
+        if not args.df and big_n > 0:
+            # which tensor the dimer launches streamed: the square (npair^2 doubles per fragment and launch) or its lower
+            # triangle (kern_fock.hip jk_tri_kernel, npair (npair + 1) / 2) -- told from the bytes the engine counted
+            from metalquicha_amd.basis import build_flat_basis
+            n_d = 2 * int(build_flat_basis(args.basis, [8, 1, 1]).nao)
+            npd = n_d * (n_d + 1) // 2
+            n_dimers = len(terms) - system0.n_monomers
+            per_frag = big_b / big_n / max(n_dimers // world, 1) / 8.0
+            if per_frag < 0.75 * npd * npd:
+                jk_name, jk_layout = "jk_tri_kernel", "lower triangle of the pair matrix, npair (npair + 1) / 2 = %d doubles per fragment (the square: %d)" % (npd * (npd + 1) // 2, npd * npd)
+            else:
+                jk_layout = "square pair matrix, npair^2 = %d doubles per fragment" % (npd * npd)
         jk_bytes = st.fock_bytes if args.df else big_b      # --df: the packed fitted tensor the kernel really reads (8 npair A per fragment-iteration)
         jk_secs = st.fock_kernel_seconds if args.df else big_s
         jk_launches = int(st.fock_launches) if args.df else big_n
         stages = {
             "jk": {"kernel": jk_name, "bound": "hbm", "seconds": st.fock_kernel_seconds, "big_launch_seconds": jk_secs,
-                   "launches": jk_launches, "algorithmic_bytes": jk_bytes,
+                   "launches": jk_launches, "algorithmic_bytes": jk_bytes, "tensor_layout": jk_layout,
                    "achieved_gbs": (jk_bytes / jk_secs / 1e9) if jk_secs > 0 else None,
                    "frac_of_hbm_peak": (jk_bytes / jk_secs / 1e9 / HBM_PEAK_GBS) if jk_secs > 0 else None},
             "eri": {"kernel": "eri class kernels (integral stage, all streams)", "bound": "fp64 valu", "seconds": st.eri_kernel_seconds,
@@ -413,7 +426,9 @@ def main():
             ach = stages["jk"]["achieved_gbs"]
             roof = {"bound": "hbm", "kernel": jk_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": (ach / HBM_PEAK_GBS) if ach else None,
-                    "traffic": (pmc or {}).get("jk_hbm_bytes_per_launch"),
+                    # counters of the committed --pmc passes, only when they belong to the kernel that ran here
+                    "traffic": ((pmc or {}).get("jk_hbm_bytes_per_launch")
+                                if str((pmc or {}).get("jk_kernel", "jk_incore_kernel")).startswith(jk_name) else None),
                     "kernel_seconds": jk_secs, "launches": jk_launches, "algorithmic_bytes": jk_bytes,
                     "algorithmic_bytes_per_launch": (jk_bytes / jk_launches) if jk_launches else None,
                     "avg_launch_ms": (1e3 * jk_secs / jk_launches) if jk_launches else None}

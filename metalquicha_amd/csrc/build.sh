@@ -14,8 +14,9 @@ stale() { # obj src
   return 1
 }
 pids=()
-njobs=0
-run() { ( "$@" ) & pids+=($!); njobs=$((njobs+1)); if [ $njobs -ge 8 ]; then wait ${pids[0]}; pids=("${pids[@]:1}"); njobs=$((njobs-1)); fi; }
+# at most $(nproc) compilers at a time; a finished one (any, not the oldest) makes room for the next
+NPAR=${MQC_BUILD_JOBS:-$(nproc)}
+run() { while [ "$(jobs -rp | wc -l)" -ge "$NPAR" ]; do wait -n || exit 1; done; ( "$@" ) & pids+=($!); }
 for g in 15 18 6 12 4 13 5 14 10 2 11 3 9 19 1 8 0 7 16 17; do
   o=_obj/kern_eri_inst_$g.o
   if stale "$o" kern_eri_inst.hip; then run hipcc $FLAGS -DERI_GROUP=$g -x hip -c kern_eri_inst.hip -o "$o"; fi

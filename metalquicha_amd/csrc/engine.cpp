@@ -221,10 +221,12 @@ static int carve_batch(mqc_hip_context* ctx, Slot& sl, const Topology& topo, con
     bv.counters = (int*)sl.misc->ensure(256);
     if (!bv.counters) return fail(MQC_HIP_ERR_DEVICE, "out of device memory (counters)");
     bv.eri_count = (unsigned long long*)(bv.counters + 16);
-    bv.eri = nullptr;
+    bv.eri = nullptr; bv.eri_tri = 0; bv.eri_stride = 0;
     if (with_eri) {
         const size_t np = (size_t)topo.npair;
-        bv.eri = (double*)sl.eri->ensure(sizeof(double) * nf * np * np);
+        bv.eri_tri = jk_tri_layout(n, topo.npair, nfrag, uhf) ? 1 : 0;
+        bv.eri_stride = bv.eri_tri ? np * (np + 1) / 2 : np * np;
+        bv.eri = (double*)sl.eri->ensure(sizeof(double) * nf * bv.eri_stride);
         if (!bv.eri) return fail(MQC_HIP_ERR_DEVICE, "out of device memory (ERI tensor)");
     }
     return MQC_HIP_OK;
@@ -699,8 +701,9 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
             }
             // density fitting: the J/K kernel reads the fitted tensor once, and it is stored packed [naux][npair] -- about
             // half of SURVEY 8d's 8 n^2 A (df_bytes keeps that figure; fock_bytes is what the kernel really streams)
+            // in-core: the tensor as stored -- the square, or its lower triangle (BatchView::eri_tri) -- once per spin density
             const double launch_bytes = use_df ? (double)remaining * (double)naux * (double)np * 8.0
-                                               : (double)remaining * (double)np * (double)np * 8.0 * (uhf ? 2.0 : 1.0);
+                                               : (double)remaining * (bv.eri_stride ? (double)bv.eri_stride : (double)np * (double)np) * 8.0 * (uhf ? 2.0 : 1.0);
             sx->stats.fock_kernel_seconds += ms * 1e-3 * block_len;
             sx->stats.fock_bytes += launch_bytes * block_len;
             sx->stats.fock_launches += block_len;
@@ -1530,7 +1533,7 @@ int mqc_hip_coulomb_batch(mqc_hip_context* ctx, int64_t nfrag, const mqc_hip_mol
             launch_jk_direct(bv, topo, 1.0e-12, false, ctx->stream);
         } else {
             // a restricted list leaves most of the tensor untouched: those blocks must read as zero
-            if (cross) HIP_CHECK_RET(hipMemsetAsync(bv.eri, 0, sizeof(double) * (size_t)nf * np * np, ctx->stream));
+            if (cross) HIP_CHECK_RET(hipMemsetAsync(bv.eri, 0, sizeof(double) * (size_t)nf * bv.eri_stride, ctx->stream));
             launch_eri(bv, topo, 0.0, ctx->stream, hx.data());
             launch_jk_incore(bv, false, ctx->stream);
         }

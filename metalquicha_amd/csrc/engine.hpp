@@ -139,7 +139,9 @@ struct BatchView {      // plain pointers handed to kernels
     double *S, *H, *X, *F, *D, *C, *J, *K, *W;   // [nfrag][n*n]; W = [nfrag][6][n*n] workspace
     double* Vprev;                // [nfrag][n*n] last eigenvectors in the orthogonal basis (Jacobi warm start)
     double* eps;                  // [nfrag][n]
-    double* eri;                  // [nfrag][npair*npair]
+    double* eri;                  // [nfrag][eri_stride]: the pair matrix, square [npair][npair] or (eri_tri) its lower triangle
+    int eri_tri;                  // 1: only col <= row stored, T[row (row + 1) / 2 + col] (kern_fock.hip, jk_tri_kernel)
+    size_t eri_stride;            // doubles per fragment: npair^2 or npair (npair + 1) / 2
     double *diis_f, *diis_e, *diis_b;   // [nfrag][8][n*n], [nfrag][8][n*n], [nfrag][8*8]
     int* diis_state;              // [nfrag][2] = n_stored, newest
     double* scal;                 // [nfrag][8]: e_elec, e_old, de, drms, e_final, E_xc, N_electrons, -
@@ -223,6 +225,8 @@ void release_all_pools();
 // launcher state that holds streams/events of the context's device (kern_eri.hip); reset by mqc_hip_finalize
 void eri_reset_state();
 
+// true when the in-core J/K of a batch of this shape runs from the triangular tensor (kern_fock.hip)
+bool jk_tri_layout(int n, int npair, int nfrag, bool uhf);
 // host-side pieces (basis_norm.cpp, boys_table.cpp, batch.cpp)
 void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);

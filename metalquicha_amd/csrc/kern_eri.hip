@@ -79,12 +79,15 @@ __global__ void __launch_bounds__(256) eri_broadcast_kernel(BatchView bv, const 
     const int ar = pair_apair[r];
     if (!apair_any[ar]) return;
     const int* __restrict__ prow = pp_row + (size_t)ar * nap;
-    double* __restrict__ dst = bv.eri + ((size_t)f * np + r) * np;
-    for (int c = threadIdx.x; c < np; c += blockDim.x) {
+    // square: the whole row; triangle: its stored part, columns 0..r
+    const size_t roff = bv.eri_tri ? (size_t)r * (r + 1) / 2 : (size_t)r * np;
+    const int ncol = bv.eri_tri ? r + 1 : np;
+    double* __restrict__ dst = bv.eri + (size_t)f * bv.eri_stride + roff;
+    for (int c = threadIdx.x; c < ncol; c += blockDim.x) {
         const int row = prow[pair_apair[c]];
         if (row < 0) continue;
         const int rep = rep_table[(size_t)row * bv.nfrag + f];
-        if (rep != f) dst[c] = bv.eri[((size_t)rep * np + r) * np + c];
+        if (rep != f) dst[c] = bv.eri[(size_t)rep * bv.eri_stride + roff + c];
     }
 }
 
@@ -229,6 +232,9 @@ struct EriSlotState {
     double* Q = nullptr;
     double bounds_tol = 0.0;
     std::vector<int> bucket[KERNEL_LMAX + 1][KERNEL_LMAX + 1];   // shell pairs by class, kept alive for the async upload
+    std::vector<int> bucket1[KERNEL_LMAX + 1][KERNEL_LMAX + 1];  // ... pairs whose two shells sit on ONE atom (see launch_eri_bounds)
+    std::vector<int> same_atom;                                  // all of them, for the copy to the other fragments
+    int* d_same = nullptr; int n_same = 0;
     DevicePool qpool, pairs;
     hipStream_t side[ERI_SIDE_MAX] = {};
     hipEvent_t fork = nullptr, join[ERI_SIDE_MAX] = {};
@@ -297,26 +303,60 @@ void launch_eri_bounds(const BatchView& bv, const Topology& topo, double schwarz
     const size_t np = (size_t)bv.npair;
     st.Q = (double*)st.qpool.ensure(sizeof(double) * (size_t)bv.nfrag * topo.shells.size() * topo.shells.size());
     st.bounds_tol = schwarz_tol;
-    int* d_pairs = (int*)st.pairs.ensure((topo.pairs.size() + 16) * sizeof(int));
+    int* d_pairs = (int*)st.pairs.ensure((2 * topo.pairs.size() + 32) * sizeof(int));
     for (auto& row : st.bucket) for (auto& b : row) b.clear();
+    for (auto& row : st.bucket1) for (auto& b : row) b.clear();
+    st.same_atom.clear();
+    // One-centre pairs.  (ab|ab) of two shells on the SAME atom involves no other position: the bound is the same
+    // number in every fragment of the batch -- and these are the pairs without any primitive screening (all 8^4
+    // primitive quartets of an oxygen (1s 1s|1s 1s) survive), i.e. the threads the whole launch waited for (the
+    // (ss| launch of 2016 dimers: 6.8 ms, ahead of every class kernel).  They are formed for fragment 0 only and
+    // copied (schwarz_copy_kernel, first thing in launch_eri).  MQC_HIP_SCHWARZ_ONE_CENTRE=0 turns that off.
+    static const bool one_centre = [] { const char* e = std::getenv("MQC_HIP_SCHWARZ_ONE_CENTRE"); return !(e && e[0] == '0'); }();
+    const bool split = one_centre && bv.nfrag >= 4;
     for (size_t k = 0; k + 1 < topo.pairs.size(); k += 2) {
         int A = topo.pairs[k], B = topo.pairs[k + 1];
         if (topo.shells[A].l < topo.shells[B].l) std::swap(A, B);
-        auto& bk = st.bucket[topo.shells[A].l][topo.shells[B].l];
+        const bool same = split && topo.shells[A].atom == topo.shells[B].atom && topo.shells[A].l <= CLASS_LMAX;
+        auto& bk = (same ? st.bucket1 : st.bucket)[topo.shells[A].l][topo.shells[B].l];
         bk.push_back(A); bk.push_back(B);
+        if (same) { st.same_atom.push_back(A); st.same_atom.push_back(B); }
     }
     (void)hipEventRecord(st.fork, s);
     for (int k = 0; k < ERI_SIDE_STREAMS; ++k) (void)hipStreamWaitEvent(st.side[k], st.fork, 0);
     size_t off = 0;
     int rr = 0;
     double* Q = st.Q;
-    // most expensive class first; the zero fill shares the last stream
+    // the zero fill first, on the last stream: with the one-centre bounds out of the way it is the longest item here
+    // (22 GB for 2016 dimers, 5 ms) and the class kernels wait for it
+    if (bv.eri) (void)hipMemsetAsync(bv.eri, 0, sizeof(double) * bv.eri_stride * bv.nfrag, st.side[ERI_SIDE_STREAMS - 1]);
+    // most expensive class first
 #define SCHWARZ_CASE(a, b)                                                                                                      \
     launch_schwarz_class<a, b>(bv, st.bucket[a][b].data(), (int)st.bucket[a][b].size() / 2, d_pairs + off, Q, st.side[rr++ % ERI_SIDE_STREAMS]); \
     off += st.bucket[a][b].size();
     SCHWARZ_CASE(0, 0) SCHWARZ_CASE(2, 1) SCHWARZ_CASE(1, 1)
     SCHWARZ_CASE(1, 0) SCHWARZ_CASE(2, 0)
 #undef SCHWARZ_CASE
+    st.n_same = 0;
+    if (!st.same_atom.empty()) {
+        BatchView b1 = bv;
+        b1.nfrag = 1;
+#define SCHWARZ_ONE(a, b)                                                                                                       \
+    launch_schwarz_class<a, b>(b1, st.bucket1[a][b].data(), (int)st.bucket1[a][b].size() / 2, d_pairs + off, Q, st.side[rr++ % ERI_SIDE_STREAMS]); \
+    off += st.bucket1[a][b].size();
+        SCHWARZ_ONE(0, 0) SCHWARZ_ONE(1, 1) SCHWARZ_ONE(1, 0) SCHWARZ_ONE(2, 1) SCHWARZ_ONE(2, 0)
+#undef SCHWARZ_ONE
+        if (!st.bucket1[2][2].empty()) {
+            hipStream_t ss = st.side[rr++ % ERI_SIDE_STREAMS];
+            (void)hipMemcpyAsync(d_pairs + off, st.bucket1[2][2].data(), st.bucket1[2][2].size() * sizeof(int), hipMemcpyHostToDevice, ss);
+            launch_schwarz_general(b1, 2, 2, d_pairs + off, (int)st.bucket1[2][2].size() / 2, Q, ss);
+            off += st.bucket1[2][2].size();
+        }
+        st.d_same = d_pairs + off;
+        st.n_same = (int)st.same_atom.size() / 2;
+        (void)hipMemcpyAsync(st.d_same, st.same_atom.data(), st.same_atom.size() * sizeof(int), hipMemcpyHostToDevice, st.side[rr++ % ERI_SIDE_STREAMS]);
+        off += st.same_atom.size();
+    }
     // (dd| bounds (the pass kernel carries 11.5 KB of scratch per lane) and the f classes: LDS kernel
     for (int a = CLASS_LMAX; a <= KERNEL_LMAX; ++a)
         for (int b = (a == CLASS_LMAX ? CLASS_LMAX : 0); b <= a; ++b) {
@@ -327,7 +367,6 @@ void launch_eri_bounds(const BatchView& bv, const Topology& topo, double schwarz
             launch_schwarz_general(bv, a, b, d_pairs + off, (int)bk.size() / 2, Q, ss);
             off += bk.size();
         }
-    if (bv.eri) (void)hipMemsetAsync(bv.eri, 0, sizeof(double) * np * np * bv.nfrag, st.side[ERI_SIDE_STREAMS - 1]);
     for (int k = 0; k < ERI_SIDE_STREAMS; ++k) (void)hipEventRecord(st.join[k], st.side[k]);
     st.bounds_pending = true;
 }
@@ -427,6 +466,19 @@ void eri_plan_lists(const BatchView& bv, const Topology& topo, hipStream_t s, co
     (void)eri_lists(bv, topo, s, host_xyz);
 }
 
+// bounds of one-centre pairs, formed for fragment 0 (launch_eri_bounds), to the other fragments
+__global__ void schwarz_copy_kernel(double* __restrict__ Q, const int* __restrict__ pairs, int npairs, int nfrag, int ns)
+{
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= (long)npairs * (nfrag - 1)) return;
+    const int ip = (int)(tid / (nfrag - 1)), f = 1 + (int)(tid % (nfrag - 1));
+    const int A = pairs[2 * ip], B = pairs[2 * ip + 1];
+    const double v = Q[A * ns + B];
+    double* q = Q + (size_t)f * ns * ns;
+    q[A * ns + B] = v;
+    q[B * ns + A] = v;
+}
+
 void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, hipStream_t s, const double* host_xyz)
 {
     EriSlotState& st = eri_slot_state(bv.slot);
@@ -441,6 +493,11 @@ void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, h
         st.bounds_pending = false;
         Q = st.Q;
         thresh = schwarz_tol;
+        if (st.n_same > 0 && bv.nfrag > 1) {
+            const long total = (long)st.n_same * (bv.nfrag - 1);
+            hipLaunchKernelGGL(schwarz_copy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, Q, st.d_same, st.n_same, bv.nfrag, (int)topo.shells.size());
+            st.n_same = 0;
+        }
     }
     EriListCache* cc = eri_lists(bv, topo, s, host_xyz);
     const int* d = (const int*)cc->pool.ensure(0);

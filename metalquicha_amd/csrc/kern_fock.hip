@@ -22,6 +22,8 @@
 //     so the 2x expansion packed -> square never touches HBM;
 //   * K is accumulated per workgroup in LDS (ds_add_f64) and flushed once with global atomics.
 #include "engine.hpp"
+#include <cmath>
+#include <cstdlib>
 
 namespace mqc {
 
@@ -410,6 +412,227 @@ __global__ void __launch_bounds__(JKC_NT) jk_rowcoop_kernel(BatchView bv, int on
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Triangular tensor (BatchView::eri_tri): only the elements col <= row of the symmetric pair matrix are stored,
+// T[f][row (row + 1) / 2 + col] -- half the bytes of the square per fragment and iteration, half the zero fill, half
+// the copy of shared blocks.  Every stored element plays both of its roles in ONE visit:
+//   J[row] += v D'[col]  (the dot product along the row, as before)   and   J[col] += v D'[row]  for col < row;
+//   K: a row is still the packed lower triangle of V^{ij}, cut off after (k, l) = (i, j).  The two symmetric mat-vecs
+//      run over what is there and give Kh; K = Kh + Kh^T at the flush -- the transposed role of an element
+//      contributes the transpose of what its stored role contributes, because D is symmetric -- and the diagonal
+//      element (ij|ij), which is its own transpose, enters Kh with weight 1/2.
+// Rows of a triangle hold 1 ... npair elements, so a wave takes them in PAIRS of constant length: row npair - 1 - t
+// (long) with row t (short), npair + 1 elements, the same 9.4 KB per step as one row of the square (n = 48).  Lane <->
+// stream position p = lane + 64 u: the long row first (its column IS p, so a lane's scattered J sums live in
+// registers), then the short row (column p - length of the long row: density from LDS, scattered J
+// through LDS atomics, a quarter of the elements on average).  In the wave's LDS buffer each row is completed with
+// zeros to the end of its last shell row, so that the mat-vec loops need no masks: [long triangle, padded | short
+// triangle, padded], at most jk_tri_buffer(npair) numbers.
+__device__ __forceinline__ void row_exchange_tri(const double* __restrict__ buf, const double* __restrict__ Di,
+                                                 const double* __restrict__ Dj, int i, int lane, double& acc_i, double& acc_j)
+{
+    typedef double double8 __attribute__((ext_vector_type(8)));
+    typedef const double8 __attribute__((address_space(4))) * scalar_ptr8;
+    acc_i = 0.0; acc_j = 0.0;
+    const int kk = lane <= i ? lane : i;          // lanes beyond the triangle read lane i's elements and are dropped at the flush
+    const int trik = kk * (kk + 1) / 2;
+    // full blocks of eight l: no clamps, one scalar add per l (tri(l + 1) = tri(l) + l + 1), as in row_exchange
+    int l0 = 0, lbase = 0;
+    for (; l0 + 8 <= i + 1; l0 += 8) {             // i is wave-uniform; n is a multiple of 8, so l0 + 8 <= n
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int l = l0 + u;
+            v[u] = buf[kk >= l ? trik + l : lbase + kk];
+            lbase += l + 1;
+        }
+        const double8 a = *(scalar_ptr8)(Di + l0), b = *(scalar_ptr8)(Dj + l0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc_i += v[u] * b[u];
+            acc_j += v[u] * a[u];
+        }
+    }
+    if (l0 <= i) {                                  // the last, partial block: l beyond i re-reads l = i with weight zero
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int l = (l0 + u <= i) ? l0 + u : i;                  // uniform
+            const int lb = l * (l + 1) / 2;
+            v[u] = buf[kk >= l ? trik + l : lb + kk];
+        }
+        const double8 a = *(scalar_ptr8)(Di + l0), b = *(scalar_ptr8)(Dj + l0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool live = l0 + u <= i;
+            acc_i += v[u] * (live ? b[u] : 0.0);
+            acc_j += v[u] * (live ? a[u] : 0.0);
+        }
+    }
+}
+
+template <int NW, int MAXU>
+__global__ void __launch_bounds__(64 * NW) jk_tri_kernel(BatchView bv, int only_active, int rs)
+{
+    extern __shared__ double lds[];
+    const int f = blockIdx.y;
+    if ((only_active & 1) && bv.istate[4 * f] == ST_DONE) return;
+    const int n = bv.n, np = bv.npair;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NTH = 64 * NW;
+    const double* __restrict__ Dg = bv.D + (size_t)f * n * n;
+    double* __restrict__ Jg = bv.J + (size_t)f * n * n;
+    double* __restrict__ Kg = bv.K + (size_t)f * n * n;
+    const double* __restrict__ T = bv.eri + (size_t)f * bv.eri_stride;
+    double* rowbuf = lds + (size_t)wave * rs;          // NW private buffers
+    double* Dp = lds + (size_t)NW * rs;                 // packed (2 - delta) D
+    double* Jl = Dp + np;                               // packed J of this workgroup
+    double* Kl = Jl + np;                               // n * n: Kh of this workgroup
+
+    for (int idx = tid; idx < np; idx += NTH) {
+        int k, l;
+        unpack_pair(idx, k, l);
+        const double d = Dg[k * n + l];
+        Dp[idx] = (k == l) ? d : 2.0 * d;
+        Jl[idx] = 0.0;
+    }
+    for (int idx = tid; idx < n * n; idx += NTH) Kl[idx] = 0.0;
+    __syncthreads();
+
+    // (the density factors of the long row come from LDS as well: with them in registers next to the scattered sums
+    // and the row in flight the twelve-wave workgroup spills)
+    double jsc[MAXU], v[MAXU];
+#pragma unroll
+    for (int u = 0; u < MAXU; ++u) jsc[u] = 0.0;
+    const int npairs = (np + 1) / 2;                    // odd npair: the middle row comes alone
+    const int stride = gridDim.x * NW;
+    int t = blockIdx.x * NW + wave;
+    auto load_pair = [&](int tt) {
+        const int rl = np - 1 - tt, llen = rl + 1, slen = (tt < rl) ? tt + 1 : 0;
+        const double* __restrict__ srcl = T + (size_t)rl * (rl + 1) / 2;
+        const double* __restrict__ srcs = T + (size_t)tt * (tt + 1) / 2;
+#pragma unroll
+        for (int u = 0; u < MAXU; ++u) {
+            const int p = lane + 64 * u, q = p - llen;
+            const double* a = p < llen ? srcl + p : srcs + (q < slen ? q : 0);
+            v[u] = (p < llen + slen) ? *a : 0.0;
+        }
+    };
+    if (t < npairs) load_pair(t);
+    while (t < npairs) {
+        const int rl = np - 1 - t, llen = rl + 1, slen = (t < rl) ? t + 1 : 0;
+        int il, jl, is = 0, js = 0;
+        unpack_pair(rl, il, jl);
+        if (slen > 0) unpack_pair(t, is, js);
+        il = __builtin_amdgcn_readfirstlane(il); jl = __builtin_amdgcn_readfirstlane(jl);
+        is = __builtin_amdgcn_readfirstlane(is); js = __builtin_amdgcn_readfirstlane(js);
+        const int sb = (il + 1) * (il + 2) / 2;         // the short triangle starts behind the padded long one
+        const double dpl = Dp[rl], dps = Dp[t];
+        // stage the pair (diagonal elements halved for the exchange), J along the rows, J scattered to the columns
+        double accl = 0.0, accs = 0.0;
+        const int lq = lane - llen;                     // column of a lane inside the short row, chunk 0
+        double* const sbuf = rowbuf + sb;
+#pragma unroll
+        for (int u = 0; u < MAXU; ++u) {
+            const int base = 64 * u;                    // the three cases below are wave-uniform (scalar branches)
+            const double x = v[u];
+            if (base + 64 <= llen - 1) {
+                // the whole chunk inside the long row and off its diagonal element: no per-lane tests
+                accl += x * Dp[lane + base];
+                jsc[u] += x * dpl;
+                rowbuf[lane + base] = x;
+            } else if (base >= llen && base + 64 <= llen + slen - 1) {
+                // the whole chunk inside the short row and off its diagonal element
+                const int q = lq + base;
+                accs += x * Dp[q];
+                atomicAdd(&Jl[q], x * dps);
+                sbuf[q] = x;
+            } else if (base < llen + slen) {
+                // a chunk with an end of a row in it (at most three per pair): the general form
+                const int p = lane + base, q = lq + base;
+                if (p < llen) {
+                    accl += x * Dp[p];
+                    jsc[u] += (p < llen - 1) ? x * dpl : 0.0;
+                    rowbuf[p] = (p == llen - 1) ? 0.5 * x : x;
+                } else if (q < slen) {
+                    accs += x * Dp[q];
+                    if (q < slen - 1) atomicAdd(&Jl[q], x * dps);
+                    sbuf[q] = (q == slen - 1) ? 0.5 * x : x;
+                }
+            }
+        }
+        if (lane < sb - llen) rowbuf[llen + lane] = 0.0;                                  // rest of shell row il
+        if (slen > 0 && lane < (is + 1) * (is + 2) / 2 - slen) rowbuf[sb + slen + lane] = 0.0;   // rest of shell row is
+        // the next pair's loads go out now and complete while this pair is contracted
+        const int nt = t + stride;
+        if (nt < npairs) load_pair(nt);
+        accl = wave_sum(accl);
+        accs = wave_sum(accs);
+        if (lane == 0) { atomicAdd(&Jl[rl], accl); if (slen > 0) atomicAdd(&Jl[t], accs); }
+        double ai, aj;
+        row_exchange_tri(rowbuf, Dg + il * n, Dg + jl * n, il, lane, ai, aj);
+        if (lane <= il) {
+            atomicAdd(&Kl[il * n + lane], ai);
+            if (il != jl) atomicAdd(&Kl[jl * n + lane], aj);
+        }
+        if (slen > 0) {
+            row_exchange_tri(rowbuf + sb, Dg + is * n, Dg + js * n, is, lane, ai, aj);
+            if (lane <= is) {
+                atomicAdd(&Kl[is * n + lane], ai);
+                if (is != js) atomicAdd(&Kl[js * n + lane], aj);
+            }
+        }
+        t = nt;
+    }
+#pragma unroll
+    for (int u = 0; u < MAXU; ++u) {
+        const int p = lane + 64 * u;
+        if (p < np && jsc[u] != 0.0) atomicAdd(&Jl[p], jsc[u]);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < np; idx += NTH) {
+        const double jv = Jl[idx];
+        if (jv == 0.0) continue;
+        int k, l;
+        unpack_pair(idx, k, l);
+        atomicAdd(&Jg[k * n + l], jv);
+        if (k != l) atomicAdd(&Jg[l * n + k], jv);
+    }
+    for (int idx = tid; idx < n * n; idx += NTH) {
+        const double kv = Kl[idx];
+        if (kv == 0.0) continue;
+        const int a = idx / n, b = idx - a * n;
+        atomicAdd(&Kg[idx], kv);                      // K = Kh + Kh^T
+        atomicAdd(&Kg[b * n + a], kv);
+    }
+}
+
+// numbers a wave's LDS buffer must hold: the padded long triangle plus the padded short one, worst row pair
+static int jk_tri_buffer(int np)
+{
+    auto shell_row = [](int idx) { int k = (int)((std::sqrt(8.0 * idx + 1.0) - 1.0) * 0.5); while ((k + 1) * (k + 2) / 2 <= idx) ++k; while (k * (k + 1) / 2 > idx) --k; return k; };
+    int worst = 0;
+    for (int t = 0; t < (np + 1) / 2; ++t) {
+        const int rl = np - 1 - t, il = shell_row(rl), is = shell_row(t);
+        const int need = (il + 1) * (il + 2) / 2 + (t < rl ? (is + 1) * (is + 2) / 2 : 0);
+        if (need > worst) worst = need;
+    }
+    return (worst + 1) & ~1;
+}
+
+constexpr int JK_TRI_NW = 12, JK_TRI_MAXU = 19;
+static size_t jk_tri_lds_bytes(int n, int np) { return sizeof(double) * ((size_t)JK_TRI_NW * jk_tri_buffer(np) + 2 * (size_t)np + (size_t)n * n); }
+
+// The triangular layout is taken for the batches the tuned square kernel served: restricted, dimer-sized fragments
+// (n <= 64, a multiple of 8; 640 < npair, npair + 1 <= 19 * 64) in batches of at least 64.  MQC_HIP_ERI_TRI=0: square.
+bool jk_tri_layout(int n, int np, int nfrag, bool uhf)
+{
+    static const bool on = [] { const char* e = std::getenv("MQC_HIP_ERI_TRI"); return !(e && e[0] == '0'); }();
+    if (!on || uhf || nfrag < 64 || n > 64 || n % 8 != 0 || np <= 10 * 64 || np + 1 > JK_TRI_MAXU * 64) return false;
+    return jk_tri_lds_bytes(n, np) <= (size_t)160 * 1024 - 1024;
+}
+
 static int jk_grid_x(const BatchView& bv, int nw)
 {
     // enough workgroups to cover 256 CUs several times over, but few enough that the per-workgroup
@@ -440,6 +663,19 @@ void launch_jk_incore(const BatchView& bv, bool only_active, hipStream_t s)
 {
     const int n = bv.n, np = bv.npair;
     (void)hipMemsetAsync(bv.K, 0, sizeof(double) * (size_t)bv.nfrag * n * n, s);
+    if (bv.eri_tri) {
+        // J is summed over the workgroups of a fragment here (row and column roles), so it starts from zero like K
+        (void)hipMemsetAsync(bv.J, 0, sizeof(double) * (size_t)bv.nfrag * n * n, s);
+        const size_t lds = jk_tri_lds_bytes(n, np);
+        auto kern = jk_tri_kernel<JK_TRI_NW, JK_TRI_MAXU>;
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int gx = (4096 + bv.nfrag - 1) / bv.nfrag;
+        const int maxx = ((np + 1) / 2 + JK_TRI_NW - 1) / JK_TRI_NW;
+        if (gx < 1) gx = 1;
+        if (gx > maxx) gx = maxx;
+        hipLaunchKernelGGL(kern, dim3(gx, bv.nfrag), dim3(64 * JK_TRI_NW), lds, s, bv, only_active ? 1 : 0, jk_tri_buffer(np));
+        return;
+    }
     const int kch = (n + 63) / 64;
     static const int skip_exchange = [] { const char* e = std::getenv("MQC_HIP_JK_SKIP_EXCHANGE"); return (e && e[0] == '1') ? 2 : 0; }();
     const int oa = (only_active ? 1 : 0) | skip_exchange;

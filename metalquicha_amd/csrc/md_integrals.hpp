@@ -166,12 +166,12 @@ struct HermiteLevel {
 };
 
 template <int L>
-MQC_HD void hermite_r(double alpha, double X, double Y, double Z, const double* __restrict__ table, double* R)
+MQC_HD void hermite_r(double alpha, double X, double Y, double Z, const double* __restrict__ table, double* R, double scale = 1.0)
 {
     double F[L + 1];
     boys<L>(alpha * (X * X + Y * Y + Z * Z), table, F);
-    // scale: R^n_000 = (-2 alpha)^n F_n
-    double s = 1.0;
+    // scale: R^n_000 = (-2 alpha)^n F_n (times the caller's prefactor, which then rides through the whole recursion)
+    double s = scale;
 #pragma unroll
     for (int n = 0; n <= L; ++n) { F[n] *= s; s *= -2.0 * alpha; }
     HermiteLevel<L, 0>::run(F, X, Y, Z, R);
@@ -348,6 +348,122 @@ MQC_HD constexpr int twin_mult(bool enabled, int l) { return (enabled && l == 0)
 MQC_HD double twin_coef(const double* const* c, double f, int m, int k) { return m == 0 ? c[0][k] : f * c[1][k]; }
 
 // ---------------------------------------------------------------------------------------
+// Hermite intermediate (bra-outer form).  A contracted integral is
+//   (ab|cd) = sum_P K_P sum_{tuv} Eab_{tuv}(P) [ sum_Q K_Q sum_{t'u'v'} (-1)^{t'+u'+v'} Ecd_{t'u'v'}(Q) R_{t+t',u+u',v+v'}(P,Q) ]
+// and the bracket H[cd][tuv] -- nherm(LA+LB) numbers per ket component -- knows nothing of the bra COMPONENT.  The
+// ket primitive loop therefore only accumulates H (a handful of FMAs per ket component), and the bra Hermite
+// coefficients are built and applied ONCE per bra primitive pair, after that loop.  The one-quartet-at-a-time form
+// applied them inside it: for a (pp| or (dp| bra that was 60-80 % of the arithmetic of every primitive quartet, and
+// the deep contractions of Dunning sets sit on the ket side (s shells of 3-9 primitives) of most classes.  The bra
+// tables are not live inside the ket loop either, which is what had pushed the d classes into scratch memory.
+#ifndef MQC_BRA_OUTER
+#define MQC_BRA_OUTER 1
+#endif
+#ifndef MQC_BRA_OUTER_HMAX
+#define MQC_BRA_OUTER_HMAX 72
+#endif
+// bra primitive pairs held at a time (one Hermite intermediate each): 4 while an intermediate is at most this many
+// numbers, 2 up to the second bound, else 1
+#ifndef MQC_BRA_BLOCK_H4
+#define MQC_BRA_BLOCK_H4 12
+#endif
+#ifndef MQC_BRA_BLOCK_H2
+#define MQC_BRA_BLOCK_H2 30
+#endif
+MQC_HD constexpr bool eri_bra_outer(int la, int lb, int lc, int ld)
+{
+    const int nab = ncart(la) * ncart(lb), ncd = ncart(lc) * ncart(ld);
+    // (ss|ss) and (ps|ss) have no bra contraction worth moving; H must stay in registers
+    return MQC_BRA_OUTER != 0 && nab * ncd > 3 && ncd * nherm(la + lb) <= MQC_BRA_OUTER_HMAX;
+}
+
+// H[icd][h] += sum_{t'u'v'} (-1)^{t'+u'+v'} Ecd[icd][t'u'v'] R[h + (t'u'v')], all Cartesian ket components
+template <int LAB, int LC, int LD>
+MQC_HD void ket_into_hermite(const E1D<LC, LD>& fx, const E1D<LC, LD>& fy, const E1D<LC, LD>& fz, const double* R, double* H)
+{
+    constexpr int NHAB = nherm(LAB);
+    int icd = 0;
+#pragma unroll
+    for (int cx = LC; cx >= 0; --cx) {
+#pragma unroll
+        for (int cy = LC - cx; cy >= 0; --cy) {
+            const int cz = LC - cx - cy;
+#pragma unroll
+            for (int dx = LD; dx >= 0; --dx) {
+#pragma unroll
+                for (int dy = LD - dx; dy >= 0; --dy) {
+                    const int dz = LD - dx - dy;
+#pragma unroll
+                    for (int tt = 0; tt <= cx + dx; ++tt) {
+#pragma unroll
+                        for (int uu = 0; uu <= cy + dy; ++uu) {
+#pragma unroll
+                            for (int ww = 0; ww <= cz + dz; ++ww) {
+                                double f = fx.get(cx, dx, tt) * fy.get(cy, dy, uu) * fz.get(cz, dz, ww);
+                                if ((tt + uu + ww) & 1) f = -f;
+#pragma unroll
+                                for (int N = 0; N <= LAB; ++N) {
+#pragma unroll
+                                    for (int t = N; t >= 0; --t) {
+#pragma unroll
+                                        for (int u = N - t; u >= 0; --u) {
+                                            const int v = N - t - u;
+                                            H[icd * NHAB + hidx(t, u, v)] += f * R[hidx(t + tt, u + uu, v + ww)];
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    ++icd;
+                }
+            }
+        }
+    }
+}
+
+// out[iab * NK + k] += kp * sum_{tuv} Eab[iab][tuv] H[k][tuv] for k < NK (ostride between consecutive out entries)
+template <int LA, int LB, int NK>
+MQC_HD void bra_from_hermite(const E1D<LA, LB>& ex, const E1D<LA, LB>& ey, const E1D<LA, LB>& ez, const double* H, double kp,
+                             double* out, int ostride = 1)
+{
+    constexpr int NHAB = nherm(LA + LB);
+    int iab = 0;
+#pragma unroll
+    for (int ax = LA; ax >= 0; --ax) {
+#pragma unroll
+        for (int ay = LA - ax; ay >= 0; --ay) {
+            const int az = LA - ax - ay;
+#pragma unroll
+            for (int bx = LB; bx >= 0; --bx) {
+#pragma unroll
+                for (int by = LB - bx; by >= 0; --by) {
+                    const int bz = LB - bx - by;
+                    double sm[NK];
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) sm[k] = 0.0;
+#pragma unroll
+                    for (int t = 0; t <= ax + bx; ++t) {
+#pragma unroll
+                        for (int u = 0; u <= ay + by; ++u) {
+#pragma unroll
+                            for (int v = 0; v <= az + bz; ++v) {
+                                const double e = ex.get(ax, bx, t) * ey.get(ay, by, u) * ez.get(az, bz, v);
+#pragma unroll
+                                for (int k = 0; k < NK; ++k) sm[k] += e * H[k * NHAB + hidx(t, u, v)];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) out[(iab * NK + k) * ostride] += kp * sm[k];
+                    ++iab;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Contracted Cartesian ERI block (ab|cd), out[((ia*NCB+ib)*NCC+ic)*NCD+id] (accumulated
 // into a zeroed buffer by this routine).
 template <int LA, int LB, int LC, int LD, class Bra, class Ket, class Twin = NoTwin>
@@ -508,7 +624,69 @@ MQC_HD void eri_cart_block_src(const Bra& bra, const Ket& ket, const double* __r
     constexpr int TK = !(UNROLLED && NCA * NCB * NCC * NCD <= 27) ? 1 : (NCA * NCB * NCC * NCD <= 3 ? 4 : MQC_PLAIN_TK);
     auto plain = [&](int i, double v) { out[i] += v; };
     (void)plain;
-    if constexpr (Twin::enabled) {
+    constexpr bool BRA_OUTER = UNROLLED && !Twin::enabled && eri_bra_outer(LA, LB, LC, LD);
+    if constexpr (BRA_OUTER) {
+        // Bra primitive pairs outside, TB of them at a time with one Hermite intermediate each; ket primitive pairs
+        // inside: a ket record (exponent sum, centre, exp() factor) and its Hermite tables are formed once per bra BLOCK
+        // and meet TB independent Boys / R_tuv evaluations, whose table loads overlap.  The bra tables exist only
+        // after the ket loop.
+        constexpr int NK = NCC * NCD, NKH = NK * NHAB;
+        constexpr int TB = NKH <= MQC_BRA_BLOCK_H4 ? 4 : (NKH <= MQC_BRA_BLOCK_H2 ? 2 : 1);
+        const int nkl = ket.npairs(), nb = bra.npairs();
+        int bi = 0, bj = 0;
+        for (int b0 = 0; b0 < nb; b0 += TB) {
+            PrimPair Pb[TB];
+            bool any = false;
+#pragma unroll
+            for (int t = 0; t < TB; ++t) {
+                if (b0 + t < nb) {
+                    Pb[t] = bra.get(bi, bj);
+                    if (++bj == bra.npb()) { bj = 0; ++bi; }
+                } else {
+                    Pb[t] = PrimPair{};
+                    Pb[t].p = 1.0; Pb[t].kp = 0.0;
+                }
+                any = any || (Pb[t].kp != 0.0);
+            }
+            if (!any) continue;
+            double H[TB][NKH];
+#pragma unroll
+            for (int t = 0; t < TB; ++t)
+#pragma unroll
+                for (int h = 0; h < NKH; ++h) H[t][h] = 0.0;
+            PrimPair Qn = ket.get(0, 0);
+            int kc = 0, kd = 0;
+            for (int kl = 0; kl < nkl; ++kl) {
+                const PrimPair Qp = Qn;
+                if (++kd == ket.npb()) { kd = 0; ++kc; }
+                if (kl + 1 < nkl) Qn = ket.get(kc, kd);
+                if (Qp.kp == 0.0) continue;
+                E1D<LC, LD> fx, fy, fz;
+                fx.build(Qp.px - ket.ax(), Qp.px - ket.bx(), Qp.hp);
+                fy.build(Qp.py - ket.ay(), Qp.py - ket.by(), Qp.hp);
+                fz.build(Qp.pz - ket.az(), Qp.pz - ket.bz(), Qp.hp);
+                const double kq = TWO_PI_25 * Qp.kp;
+#pragma unroll
+                for (int t = 0; t < TB; ++t) {
+                    if (TB > 1 && Pb[t].kp == 0.0) continue;
+                    const double rs = fast_rsqrt(Pb[t].p + Qp.p);
+                    const double alpha = Pb[t].p * Qp.p * rs * rs;
+                    double R[nherm(L)];
+                    hermite_r<L>(alpha, Pb[t].px - Qp.px, Pb[t].py - Qp.py, Pb[t].pz - Qp.pz, boys_table, R, kq * rs);
+                    ket_into_hermite<LAB, LC, LD>(fx, fy, fz, R, H[t]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TB; ++t) {
+                if (Pb[t].kp == 0.0) continue;
+                E1D<LA, LB> ex, ey, ez;
+                ex.build(Pb[t].px - bra.ax(), Pb[t].px - bra.bx(), Pb[t].hp);
+                ey.build(Pb[t].py - bra.ay(), Pb[t].py - bra.by(), Pb[t].hp);
+                ez.build(Pb[t].pz - bra.az(), Pb[t].pz - bra.bz(), Pb[t].hp);
+                bra_from_hermite<LA, LB, NK>(ex, ey, ez, H[t], Pb[t].kp, out);
+            }
+        }
+    } else if constexpr (Twin::enabled) {
         static_assert(!Twin::enabled || TK > 1, "twin blocks exist for the small register classes only");
         constexpr int TKT = (NC == 1) ? 2 : 1;   // ket records held at a time (register budget: NCOMB accumulator sets)
         const int nkl = ket.npairs();
@@ -677,6 +855,79 @@ MQC_HD void eri_pass(const Bra& bra, const Ket& ket,
 
     constexpr double TWO_PI_25 = 34.986836655249725693;
 
+#ifndef MQC_PASS_HMAX
+#define MQC_PASS_HMAX 96
+#endif
+    if constexpr (MQC_BRA_OUTER != 0 && NS * NHAB <= MQC_PASS_HMAX) {
+        // Hermite-intermediate form (see eri_bra_outer): per primitive quartet only H[s][tuv] of the pass's ket
+        // components is touched (registers); the bra tables are built after the ket loop and the LDS accumulators
+        // are updated once per bra primitive pair instead of once per primitive quartet
+        const int nkl = ket.npairs();
+        for (int ip = 0; ip < bra.npa(); ++ip) {
+            for (int jp = 0; jp < bra.npb(); ++jp) {
+                const PrimPair P = bra.get(ip, jp);
+                if (P.kp == 0.0) continue;
+                double H[NS * NHAB];
+#pragma unroll
+                for (int h = 0; h < NS * NHAB; ++h) H[h] = 0.0;
+                PrimPair Qn = ket.get(0, 0);
+                int kc = 0, kd = 0;
+                for (int kl = 0; kl < nkl; ++kl) {
+                    const PrimPair Qp = Qn;
+                    if (++kd == ket.npb()) { kd = 0; ++kc; }
+                    if (kl + 1 < nkl) Qn = ket.get(kc, kd);
+                    if (Qp.kp == 0.0) continue;
+                    E1D<LC, LD> fx, fy, fz;
+                    fx.build(Qp.px - ket.ax(), Qp.px - ket.bx(), Qp.hp);
+                    fy.build(Qp.py - ket.ay(), Qp.py - ket.by(), Qp.hp);
+                    fz.build(Qp.pz - ket.az(), Qp.pz - ket.bz(), Qp.hp);
+                    const double rs = fast_rsqrt(P.p + Qp.p);
+                    const double alpha = P.p * Qp.p * rs * rs;
+                    double R[nherm(L)];
+                    hermite_r<L>(alpha, P.px - Qp.px, P.py - Qp.py, P.pz - Qp.pz, boys_table, R, TWO_PI_25 * rs * Qp.kp);
+#pragma unroll
+                    for (int s = S0; s < S1; ++s) {
+                        const int mc = s / NSD, md = s - mc * NSD;
+#pragma unroll
+                        for (int kcc = 0; kcc < NCC; ++kcc) {
+                            const double wc = c2s_coef<LC>(c2s, mc, kcc);
+                            if (wc == 0.0) continue;
+                            int cx = 0, cy = 0, cz = 0;
+                            cart_lmn(LC, kcc, cx, cy, cz);
+#pragma unroll
+                            for (int kdd = 0; kdd < NCD; ++kdd) {
+                                const double wd = c2s_coef<LD>(c2s, md, kdd);
+                                if (wd == 0.0) continue;
+                                int dx = 0, dy = 0, dz = 0;
+                                cart_lmn(LD, kdd, dx, dy, dz);
+#pragma unroll
+                                for (int tt = 0; tt <= cx + dx; ++tt)
+#pragma unroll
+                                    for (int uu = 0; uu <= cy + dy; ++uu)
+#pragma unroll
+                                        for (int ww = 0; ww <= cz + dz; ++ww) {
+                                            double f = (wc * wd) * fx.get(cx, dx, tt) * fy.get(cy, dy, uu) * fz.get(cz, dz, ww);
+                                            if ((tt + uu + ww) & 1) f = -f;
+#pragma unroll
+                                            for (int N = 0; N <= LAB; ++N)
+#pragma unroll
+                                                for (int t = N; t >= 0; --t)
+#pragma unroll
+                                                    for (int u = N - t; u >= 0; --u)
+                                                        H[(s - S0) * NHAB + hidx(t, u, N - t - u)] += f * R[hidx(t + tt, u + uu, N - t - u + ww)];
+                                        }
+                            }
+                        }
+                    }
+                }
+                E1D<LA, LB> ex, ey, ez;
+                ex.build(P.px - bra.ax(), P.px - bra.bx(), P.hp);
+                ey.build(P.py - bra.ay(), P.py - bra.by(), P.hp);
+                ez.build(P.pz - bra.az(), P.pz - bra.bz(), P.hp);
+                bra_from_hermite<LA, LB, NS>(ex, ey, ez, H, P.kp, acc, stride);
+            }
+        }
+    } else
     for (int ip = 0; ip < bra.npa(); ++ip) {
         for (int jp = 0; jp < bra.npb(); ++jp) {
             const PrimPair P = bra.get(ip, jp);

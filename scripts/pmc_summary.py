@@ -79,11 +79,16 @@ def main():
         def pick(tag, counter, sub):
             for k, v in p[tag]["kernels"].items():
                 if sub in k and "12, 19" in k:
-                    return v.get(counter, 0.0), v["launches"]
-            return 0.0, 0
-        fk, nf = pick("fetch", "FETCH_SIZE", "jk_incore_kernel")
-        wk, nw = pick("write", "WRITE_SIZE", "jk_incore_kernel")
+                    return v.get(counter, 0.0), v["launches"], k
+            return 0.0, 0, None
+        # the triangular-tensor kernel where the batch runs from it, else the tuned square kernel
+        fk, nf, jk_kernel = pick("fetch", "FETCH_SIZE", "jk_tri_kernel")
+        wk, nw, _ = pick("write", "WRITE_SIZE", "jk_tri_kernel")
+        if not nf:
+            fk, nf, jk_kernel = pick("fetch", "FETCH_SIZE", "jk_incore_kernel")
+            wk, nw, _ = pick("write", "WRITE_SIZE", "jk_incore_kernel")
         if nf:
+            out["jk_kernel"] = jk_kernel
             out["jk_hbm_bytes_per_launch"] = (2.0 * fk * 1024.0) / nf + (wk * 1024.0) / max(nw, 1)
             out["jk_correction"] = "FETCH_SIZE x2 on gfx950 (64 B tallied per 128-B request); KiB -> bytes x1024"
         # integral stage: all eri_* / schwarz_* kernels
