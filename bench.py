@@ -388,7 +388,10 @@ def main():
             n_dimers = len(terms) - system0.n_monomers
             per_frag = big_b / big_n / max(n_dimers // world, 1) / 8.0
             if per_frag < 0.75 * npd * npd:
-                jk_name, jk_layout = "jk_tri_kernel", "lower triangle of the pair matrix, npair (npair + 1) / 2 = %d doubles per fragment (the square: %d)" % (npd * (npd + 1) // 2, npd * npd)
+                jk_name = "jk_tri_kernel"
+                jk_layout = ("lower triangle of the pair matrix in blocks of row pairs (zero-padded to whole shell rows): about %d doubles per "
+                             "fragment and launch as the engine counted them; the bare triangle npair (npair + 1) / 2 = %d, the square %d"
+                             % (int(round(per_frag)), npd * (npd + 1) // 2, npd * npd))
             else:
                 jk_layout = "square pair matrix, npair^2 = %d doubles per fragment" % (npd * npd)
         jk_bytes = st.fock_bytes if args.df else big_b      # --df: the packed fitted tensor the kernel really reads (8 npair A per fragment-iteration)

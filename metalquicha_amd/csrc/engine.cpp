@@ -218,14 +218,25 @@ static int carve_batch(mqc_hip_context* ctx, Slot& sl, const Topology& topo, con
     if (npc > 0) bv.pc = (double*)take(sizeof(double) * nf * npc * 4);
     if (npc > 0 || hx) bv.U = (double*)take(sizeof(double) * nf * nn);
     if (hx) bv.Hx = (double*)take(sizeof(double) * nf * nn);
-    bv.counters = (int*)sl.misc->ensure(256);
+    bv.counters = (int*)sl.misc->ensure(256 + sizeof(int) * (2 * (size_t)topo.npair + 8));      // + the block tables of a triangular tensor
     if (!bv.counters) return fail(MQC_HIP_ERR_DEVICE, "out of device memory (counters)");
     bv.eri_count = (unsigned long long*)(bv.counters + 16);
-    bv.eri = nullptr; bv.eri_tri = 0; bv.eri_stride = 0;
+    bv.eri = nullptr; bv.eri_tri = 0; bv.eri_tri_pb = 0; bv.eri_tri_sb = nullptr; bv.eri_stride = 0;
     if (with_eri) {
         const size_t np = (size_t)topo.npair;
         bv.eri_tri = jk_tri_layout(n, topo.npair, nfrag, uhf) ? 1 : 0;
-        bv.eri_stride = bv.eri_tri ? np * (np + 1) / 2 : np * np;
+        bv.eri_stride = np * np;
+        if (bv.eri_tri) {
+            // triangular block layout (kern_fock.hip): block length and the start of the short row of every block
+            static std::vector<int> sb_host[2];
+            std::vector<int>& sbh = sb_host[sl.id & 1];
+            bv.eri_tri_pb = jk_tri_block(topo.npair, &sbh);
+            bv.eri_stride = (size_t)((topo.npair + 1) / 2) * (size_t)bv.eri_tri_pb;
+            int* d_sb = (int*)((char*)bv.counters + 256);
+            if (hipMemcpyAsync(d_sb, sbh.data(), sizeof(int) * sbh.size(), hipMemcpyHostToDevice, sl.s) != hipSuccess)
+                return fail(MQC_HIP_ERR_DEVICE, "upload of the tensor block table failed");
+            bv.eri_tri_sb = d_sb;
+        }
         bv.eri = (double*)sl.eri->ensure(sizeof(double) * nf * bv.eri_stride);
         if (!bv.eri) return fail(MQC_HIP_ERR_DEVICE, "out of device memory (ERI tensor)");
     }
@@ -413,8 +424,10 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
 
     const int n = topo.nao;
     const size_t np = (size_t)topo.npair;
-    const size_t two_e = use_df ? (2 * (size_t)naux * np + 3 * (size_t)naux * naux) : (use_direct ? 2 * (size_t)n * n : np * np);
     const bool uhf_mem = opts.unrestricted || topo.multiplicity != 1 || (topo.nelec % 2) != 0;
+    // in-core tensor: the square, or -- where the batch takes the triangular block layout (kern_fock.hip) -- 0.53 of it
+    const size_t tensor = jk_tri_layout(n, topo.npair, ntot, uhf_mem) ? (size_t)((topo.npair + 1) / 2) * (size_t)jk_tri_block(topo.npair) : np * np;
+    const size_t two_e = use_df ? (2 * (size_t)naux * np + 3 * (size_t)naux * naux) : (use_direct ? 2 * (size_t)n * n : tensor);
     // radial cache of the quadrature (MQC_HIP_XC_RADIAL_CACHE=0 turns it off): 2 doubles per shell and (padded) grid point
     static const bool rad_cache_on = [] { const char* e = std::getenv("MQC_HIP_XC_RADIAL_CACHE"); return !(e && e[0] == '0'); }();
     const int rad_pt = xc_tile_points(n);

@@ -140,8 +140,12 @@ struct BatchView {      // plain pointers handed to kernels
     double* Vprev;                // [nfrag][n*n] last eigenvectors in the orthogonal basis (Jacobi warm start)
     double* eps;                  // [nfrag][n]
     double* eri;                  // [nfrag][eri_stride]: the pair matrix, square [npair][npair] or (eri_tri) its lower triangle
-    int eri_tri;                  // 1: only col <= row stored, T[row (row + 1) / 2 + col] (kern_fock.hip, jk_tri_kernel)
-    size_t eri_stride;            // doubles per fragment: npair^2 or npair (npair + 1) / 2
+    // eri_tri = 1: only the elements col <= row are stored, in BLOCKS of eri_tri_pb doubles, one per pair of rows
+    // (kern_fock.hip, jk_tri_kernel): block t = [row npair-1-t, zeros to the end of its last shell row | row t, zeros
+    // likewise]; eri_tri_sb[t] = where row t starts inside its block; the diagonal elements (ij|ij) are stored HALVED
+    int eri_tri, eri_tri_pb;
+    const int* eri_tri_sb;        // [(npair + 1) / 2] short-row starts, then [npair] the shell row i of every pair row (ij)
+    size_t eri_stride;            // doubles per fragment: npair^2, or (npair + 1) / 2 blocks
     double *diis_f, *diis_e, *diis_b;   // [nfrag][8][n*n], [nfrag][8][n*n], [nfrag][8*8]
     int* diis_state;              // [nfrag][2] = n_stored, newest
     double* scal;                 // [nfrag][8]: e_elec, e_old, de, drms, e_final, E_xc, N_electrons, -
@@ -174,6 +178,38 @@ struct BatchView {      // plain pointers handed to kernels
     int uhf, nalpha, nbeta;
     double *Db, *Cb, *Fb, *Jb, *Kb, *Vprevb, *epsb, *diis_fb, *diis_eb;
 };
+
+// Where an integral goes in the pair matrix of one fragment: both mirror elements of the square, or the one stored
+// element of the triangular block layout (diagonal elements halved, see BatchView::eri_tri).
+struct PairStore {
+    double* M;
+    size_t np;
+    int tri, pb, first_long;
+    const int* sb;
+#if defined(__HIPCC__)
+    __device__ __forceinline__ size_t row_start(size_t r) const
+    {
+        return ((int)r >= first_long) ? (np - 1 - r) * (size_t)pb : r * (size_t)pb + sb[r];
+    }
+    __device__ __forceinline__ void put(size_t row, size_t col, double v) const
+    {
+        if (tri) {
+            const size_t hi = row > col ? row : col, lo = row > col ? col : row;
+            M[row_start(hi) + lo] = (hi == lo) ? 0.5 * v : v;
+        } else {
+            M[row * np + col] = v;
+            M[col * np + row] = v;
+        }
+    }
+#endif
+};
+#if defined(__HIPCC__)
+__device__ __forceinline__ PairStore make_pair_store(const BatchView& bv, int f)
+{
+    const int np = bv.npair;
+    return PairStore{bv.eri + (size_t)f * bv.eri_stride, (size_t)np, bv.eri_tri, bv.eri_tri_pb, np - (np + 1) / 2, bv.eri_tri_sb};
+}
+#endif
 
 struct Stats {
     double t_setup = 0, t_int1e = 0, t_eri = 0, t_fock = 0, t_scf_step = 0, t_total = 0;
@@ -225,8 +261,10 @@ void release_all_pools();
 // launcher state that holds streams/events of the context's device (kern_eri.hip); reset by mqc_hip_finalize
 void eri_reset_state();
 
-// true when the in-core J/K of a batch of this shape runs from the triangular tensor (kern_fock.hip)
+// true when the in-core J/K of a batch of this shape runs from the triangular tensor (kern_fock.hip); block length and
+// the per-block start of the short row
 bool jk_tri_layout(int n, int npair, int nfrag, bool uhf);
+int jk_tri_block(int npair, std::vector<int>* short_row_start = nullptr);
 // host-side pieces (basis_norm.cpp, boys_table.cpp, batch.cpp)
 void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);

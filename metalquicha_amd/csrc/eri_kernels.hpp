@@ -53,18 +53,6 @@ __device__ __forceinline__ size_t pair_index(int i, int j)
     return i >= j ? (size_t)i * (i + 1) / 2 + j : (size_t)j * (j + 1) / 2 + i;
 }
 
-// one integral into the pair matrix: both mirror elements of the square, or the one element col <= row of the triangle
-__device__ __forceinline__ void store_pair_element(double* __restrict__ M, size_t np, bool tri, size_t row, size_t col, double v)
-{
-    if (tri) {
-        const size_t hi = row > col ? row : col, lo = row > col ? col : row;
-        M[hi * (hi + 1) / 2 + lo] = v;
-    } else {
-        M[row * np + col] = v;
-        M[col * np + row] = v;
-    }
-}
-
 // cart -> sph on ONE index of a block: in[pre][NC][post] -> out[pre][NS][post].
 // UNR: fully unrolled (register-resident small classes) or rolled (large classes, scratch).
 template <int L, int PRE, int POST, bool UNR>
@@ -189,8 +177,7 @@ __global__ void __launch_bounds__(64) eri_kernel(BatchView bv, const int* __rest
 
     const int oa = tp.sh_aoff[A], ob = tp.sh_aoff[B], oc = tp.sh_aoff[C], od = tp.sh_aoff[D];
     const size_t np = (size_t)bv.npair;
-    double* M = bv.eri + (size_t)f * bv.eri_stride;
-    const bool tri = bv.eri_tri != 0;
+    const PairStore M = make_pair_store(bv, f);
 #define MQC_ERI_STORE                                                              \
     {                                                                              \
         if (!(A == B && j > i)) {                                                  \
@@ -202,7 +189,7 @@ __global__ void __launch_bounds__(64) eri_kernel(BatchView bv, const int* __rest
                     if (!(C == D && l > k)) {                                      \
                         const size_t col = pair_index(oc + k, od + l);             \
                         const double v = sph[((i * NSB + j) * NSC + k) * NSD + l]; \
-                        store_pair_element(M, np, tri, row, col, v);               \
+                        M.put(row, col, v);                                        \
                     }                                                              \
                 }                                                                  \
             }                                                                      \
@@ -278,8 +265,7 @@ __global__ void __launch_bounds__(64) eri_twin_kernel(BatchView bv, const int* _
     eri_cart_block_twin<LA, LB, LC, LD>(sa, sb, sc, sd, tw, bv.boys, acc);
 
     const size_t np = (size_t)bv.npair;
-    double* M = bv.eri + (size_t)f * bv.eri_stride;
-    const bool tri = bv.eri_tri != 0;
+    const PairStore M = make_pair_store(bv, f);
 #pragma unroll
     for (int ma = 0; ma < MA; ++ma) {
 #pragma unroll
@@ -306,7 +292,7 @@ __global__ void __launch_bounds__(64) eri_twin_kernel(BatchView bv, const int* _
                                     if (c == d && l > k) continue;
                                     const size_t col = pair_index(oc + k, od + l);
                                     const double v = sph[((i * NSB + j) * NSC + k) * NSD + l];
-                                    store_pair_element(M, np, tri, row, col, v);
+                                    M.put(row, col, v);
                                 }
                             }
                         }
@@ -322,16 +308,15 @@ __global__ void __launch_bounds__(64) eri_twin_kernel(BatchView bv, const int* _
 // eri_pass): same (quartet, fragment) thread mapping; the accumulators of a wave sit in its own
 // LDS slab acc[entry][lane].
 struct TensorSink {
-    double* M;
-    size_t np;
+    PairStore M;
     int oa, ob, oc, od;
-    bool ab_same, cd_same, tri;
+    bool ab_same, cd_same;
     __device__ __forceinline__ void operator()(int i, int j, int k, int l, double v) const
     {
         if (ab_same && j > i) return;
         if (cd_same && l > k) return;
         const size_t row = pair_index(oa + i, ob + j), col = pair_index(oc + k, od + l);
-        store_pair_element(M, np, tri, row, col, v);
+        M.put(row, col, v);
     }
 };
 
@@ -361,7 +346,7 @@ __global__ void __launch_bounds__(64) eri_pass_kernel(BatchView bv, const int* _
     const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
     const PairFly bra(make_shell(tp, xyz, A), make_shell(tp, xyz, B)), ket(make_shell(tp, xyz, C), make_shell(tp, xyz, D));
     const size_t np = (size_t)bv.npair;
-    TensorSink sink{bv.eri + (size_t)f * bv.eri_stride, np, tp.sh_aoff[A], tp.sh_aoff[B], tp.sh_aoff[C], tp.sh_aoff[D], A == B, C == D, bv.eri_tri != 0};
+    TensorSink sink{make_pair_store(bv, f), tp.sh_aoff[A], tp.sh_aoff[B], tp.sh_aoff[C], tp.sh_aoff[D], A == B, C == D};
     constexpr int CH = eri_pass_chunk(LA, LB, LC, LD);
     eri_passes_src<LA, LB, LC, LD, CH, 0>(bra, ket, bv.boys, bv.c2s, lds + threadIdx.x, 64, sink);
 }

@@ -79,8 +79,8 @@ __global__ void __launch_bounds__(256) eri_broadcast_kernel(BatchView bv, const 
     const int ar = pair_apair[r];
     if (!apair_any[ar]) return;
     const int* __restrict__ prow = pp_row + (size_t)ar * nap;
-    // square: the whole row; triangle: its stored part, columns 0..r
-    const size_t roff = bv.eri_tri ? (size_t)r * (r + 1) / 2 : (size_t)r * np;
+    // square: the whole row; triangular blocks: the stored part of the row, columns 0..r
+    const size_t roff = bv.eri_tri ? make_pair_store(bv, 0).row_start((size_t)r) : (size_t)r * np;
     const int ncol = bv.eri_tri ? r + 1 : np;
     double* __restrict__ dst = bv.eri + (size_t)f * bv.eri_stride + roff;
     for (int c = threadIdx.x; c < ncol; c += blockDim.x) {
@@ -498,6 +498,10 @@ void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, h
             hipLaunchKernelGGL(schwarz_copy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, Q, st.d_same, st.n_same, bv.nfrag, (int)topo.shells.size());
             st.n_same = 0;
         }
+    }
+    else if (bv.eri_tri) {
+        // the triangular blocks carry zero padding that no class kernel writes: an unscreened build fills too
+        (void)hipMemsetAsync(bv.eri, 0, sizeof(double) * bv.eri_stride * bv.nfrag, s);
     }
     EriListCache* cc = eri_lists(bv, topo, s, host_xyz);
     const int* d = (const int*)cc->pool.ensure(0);

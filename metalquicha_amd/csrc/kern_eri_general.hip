@@ -403,8 +403,7 @@ __global__ void __launch_bounds__(64) eri_general_kernel(BatchView bv, int la, i
         return;
     }
     const size_t np = (size_t)bv.npair;
-    double* M = bv.eri + (size_t)f * bv.eri_stride;
-    const bool tri = bv.eri_tri != 0;
+    const PairStore M = make_pair_store(bv, f);
     for (int idx = lane; idx < nout; idx += 64) {
         int r = idx;
         const int l = r % nsd; r /= nsd;
@@ -418,13 +417,7 @@ __global__ void __launch_bounds__(64) eri_general_kernel(BatchView bv, int la, i
         // different lanes: only the lower triangle writes, so that M stays exactly symmetric
         if (A == C && B == D && row < col) continue;
         const double v = OUT[idx];
-        if (tri) {
-            const size_t hi = row > col ? row : col, lo = row > col ? col : row;
-            M[hi * (hi + 1) / 2 + lo] = v;
-        } else {
-            M[row * np + col] = v;
-            M[col * np + row] = v;
-        }
+        M.put(row, col, v);
     }
 }
 

@@ -23,6 +23,7 @@
 //   * K is accumulated per workgroup in LDS (ds_add_f64) and flushed once with global atomics.
 #include "engine.hpp"
 #include <cmath>
+#include <vector>
 #include <cstdlib>
 
 namespace mqc {
@@ -413,21 +414,20 @@ __global__ void __launch_bounds__(JKC_NT) jk_rowcoop_kernel(BatchView bv, int on
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Triangular tensor (BatchView::eri_tri): only the elements col <= row of the symmetric pair matrix are stored,
-// T[f][row (row + 1) / 2 + col] -- half the bytes of the square per fragment and iteration, half the zero fill, half
-// the copy of shared blocks.  Every stored element plays both of its roles in ONE visit:
-//   J[row] += v D'[col]  (the dot product along the row, as before)   and   J[col] += v D'[row]  for col < row;
+// Triangular tensor (BatchView::eri_tri): only the elements col <= row of the symmetric pair matrix are stored -- half
+// the bytes of the square per fragment and iteration, half the zero fill, half the copy of shared blocks.  Every stored
+// element plays both of its roles in ONE visit:
+//   J[row] += v D'[col]  (the dot product along the row, as before)   and   J[col] += v D'[row];
 //   K: a row is still the packed lower triangle of V^{ij}, cut off after (k, l) = (i, j).  The two symmetric mat-vecs
 //      run over what is there and give Kh; K = Kh + Kh^T at the flush -- the transposed role of an element
-//      contributes the transpose of what its stored role contributes, because D is symmetric -- and the diagonal
-//      element (ij|ij), which is its own transpose, enters Kh with weight 1/2.
-// Rows of a triangle hold 1 ... npair elements, so a wave takes them in PAIRS of constant length: row npair - 1 - t
-// (long) with row t (short), npair + 1 elements, the same 9.4 KB per step as one row of the square (n = 48).  Lane <->
-// stream position p = lane + 64 u: the long row first (its column IS p, so a lane's scattered J sums live in
-// registers), then the short row (column p - length of the long row: density from LDS, scattered J
-// through LDS atomics, a quarter of the elements on average).  In the wave's LDS buffer each row is completed with
-// zeros to the end of its last shell row, so that the mat-vec loops need no masks: [long triangle, padded | short
-// triangle, padded], at most jk_tri_buffer(npair) numbers.
+//      contributes the transpose of what its stored role contributes, because D is symmetric.
+//   The diagonal element (ij|ij) is its own transpose: the integral kernels store it HALVED (PairStore::put), and with
+//   that it needs no special case here, neither in J (row role + column role = the whole) nor in K.
+// Rows of a triangle hold 1 ... npair elements, so they are stored and streamed in PAIRS of constant length: block t
+// = [row npair - 1 - t | row t], each completed with zeros to the end of its last shell row (the mat-vec loops then
+// need no masks; the zeros come from the zero fill of the tensor), eri_tri_pb doubles per block -- 1240 for n = 48
+// against 1176 for a row of the square.  A wave streams a block exactly as the square kernel streams a row (16-byte
+// loads, the next block in flight in registers, the block parked in the wave's LDS buffer as it lies in HBM).
 __device__ __forceinline__ void row_exchange_tri(const double* __restrict__ buf, const double* __restrict__ Di,
                                                  const double* __restrict__ Dj, int i, int lane, double& acc_i, double& acc_j)
 {
@@ -457,9 +457,11 @@ __device__ __forceinline__ void row_exchange_tri(const double* __restrict__ buf,
         double v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int l = (l0 + u <= i) ? l0 + u : i;                  // uniform
-            const int lb = l * (l + 1) / 2;
-            v[u] = buf[kk >= l ? trik + l : lb + kk];
+            // scalar on purpose (readfirstlane): otherwise the compiler builds the two index forms under exec masks
+            const int l = __builtin_amdgcn_readfirstlane((l0 + u <= i) ? l0 + u : i);
+            const int lb = __builtin_amdgcn_readfirstlane(l * (l + 1) / 2);
+            const int ia = trik + l, ib = lb + kk;
+            v[u] = buf[kk >= l ? ia : ib];
         }
         const double8 a = *(scalar_ptr8)(Di + l0), b = *(scalar_ptr8)(Dj + l0);
 #pragma unroll
@@ -471,13 +473,14 @@ __device__ __forceinline__ void row_exchange_tri(const double* __restrict__ buf,
     }
 }
 
-template <int NW, int MAXU>
-__global__ void __launch_bounds__(64 * NW) jk_tri_kernel(BatchView bv, int only_active, int rs)
+template <int NW, int MAXU2>       // MAXU2 chunks of 128 doubles cover a block
+__global__ void __launch_bounds__(64 * NW) jk_tri_kernel(BatchView bv, int only_active)
 {
     extern __shared__ double lds[];
+    typedef double double2v __attribute__((ext_vector_type(2)));
     const int f = blockIdx.y;
     if ((only_active & 1) && bv.istate[4 * f] == ST_DONE) return;
-    const int n = bv.n, np = bv.npair;
+    const int n = bv.n, np = bv.npair, pb = bv.eri_tri_pb;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NTH = 64 * NW;
@@ -485,98 +488,100 @@ __global__ void __launch_bounds__(64 * NW) jk_tri_kernel(BatchView bv, int only_
     double* __restrict__ Jg = bv.J + (size_t)f * n * n;
     double* __restrict__ Kg = bv.K + (size_t)f * n * n;
     const double* __restrict__ T = bv.eri + (size_t)f * bv.eri_stride;
-    double* rowbuf = lds + (size_t)wave * rs;          // NW private buffers
-    double* Dp = lds + (size_t)NW * rs;                 // packed (2 - delta) D
-    double* Jl = Dp + np;                               // packed J of this workgroup
-    double* Kl = Jl + np;                               // n * n: Kh of this workgroup
+    double* rowbuf = lds + (size_t)wave * pb;          // NW private buffers, one block each
+    double* Dp = lds + (size_t)NW * pb;                 // packed (2 - delta) D, two zeros behind it
+    double* Jl = Dp + np + 2;                           // packed J of this workgroup (+ two slots the padding may touch)
+    double* Kl = Jl + np + 2;                           // n * n: Kh of this workgroup
 
-    for (int idx = tid; idx < np; idx += NTH) {
-        int k, l;
-        unpack_pair(idx, k, l);
-        const double d = Dg[k * n + l];
-        Dp[idx] = (k == l) ? d : 2.0 * d;
+    for (int idx = tid; idx < np + 2; idx += NTH) {
+        double d = 0.0;
+        if (idx < np) {
+            int k, l;
+            unpack_pair(idx, k, l);
+            d = Dg[k * n + l];
+            if (k != l) d *= 2.0;
+        }
+        Dp[idx] = d;
         Jl[idx] = 0.0;
     }
     for (int idx = tid; idx < n * n; idx += NTH) Kl[idx] = 0.0;
     __syncthreads();
 
-    // (the density factors of the long row come from LDS as well: with them in registers next to the scattered sums
-    // and the row in flight the twelve-wave workgroup spills)
-    double jsc[MAXU], v[MAXU];
+    double2v v2[MAXU2], jsc2[MAXU2];
 #pragma unroll
-    for (int u = 0; u < MAXU; ++u) jsc[u] = 0.0;
-    const int npairs = (np + 1) / 2;                    // odd npair: the middle row comes alone
+    for (int u = 0; u < MAXU2; ++u) jsc2[u] = (double2v){0.0, 0.0};
+    const int npairs = (np + 1) / 2;                    // odd npair: the middle row has a block to itself
     const int stride = gridDim.x * NW;
     int t = blockIdx.x * NW + wave;
-    auto load_pair = [&](int tt) {
-        const int rl = np - 1 - tt, llen = rl + 1, slen = (tt < rl) ? tt + 1 : 0;
-        const double* __restrict__ srcl = T + (size_t)rl * (rl + 1) / 2;
-        const double* __restrict__ srcs = T + (size_t)tt * (tt + 1) / 2;
+    auto load_block = [&](int tt) {
+        const double* __restrict__ src = T + (size_t)tt * pb;
 #pragma unroll
-        for (int u = 0; u < MAXU; ++u) {
-            const int p = lane + 64 * u, q = p - llen;
-            const double* a = p < llen ? srcl + p : srcs + (q < slen ? q : 0);
-            v[u] = (p < llen + slen) ? *a : 0.0;
+        for (int u = 0; u < MAXU2; ++u) {
+            const int idx = 2 * lane + 128 * u;
+            v2[u] = idx < pb ? *(const double2v*)(src + idx) : (double2v){0.0, 0.0};
         }
     };
-    if (t < npairs) load_pair(t);
+    if (t < npairs) load_block(t);
     while (t < npairs) {
-        const int rl = np - 1 - t, llen = rl + 1, slen = (t < rl) ? t + 1 : 0;
-        int il, jl, is = 0, js = 0;
-        unpack_pair(rl, il, jl);
-        if (slen > 0) unpack_pair(t, is, js);
-        il = __builtin_amdgcn_readfirstlane(il); jl = __builtin_amdgcn_readfirstlane(jl);
-        is = __builtin_amdgcn_readfirstlane(is); js = __builtin_amdgcn_readfirstlane(js);
-        const int sb = (il + 1) * (il + 2) / 2;         // the short triangle starts behind the padded long one
+        const int rl = np - 1 - t;
+        const bool two = t < rl;                        // the block holds a short row too
+        // shell rows of the two pair rows from the table behind eri_tri_sb (uniform addresses: scalar loads)
+        const int* __restrict__ shell_row = bv.eri_tri_sb + npairs;
+        const int il = __builtin_amdgcn_readfirstlane(shell_row[rl]), jl = rl - il * (il + 1) / 2;
+        const int is = two ? __builtin_amdgcn_readfirstlane(shell_row[t]) : 0, js = t - is * (is + 1) / 2;
+        const int sb = (il + 1) * (il + 2) / 2;         // = eri_tri_sb[t]: the short row starts behind the padded long one
+        const int se = two ? sb + (is + 1) * (is + 2) / 2 : sb;   // end of the padded short row
         const double dpl = Dp[rl], dps = Dp[t];
-        // stage the pair (diagonal elements halved for the exchange), J along the rows, J scattered to the columns
         double accl = 0.0, accs = 0.0;
-        const int lq = lane - llen;                     // column of a lane inside the short row, chunk 0
-        double* const sbuf = rowbuf + sb;
 #pragma unroll
-        for (int u = 0; u < MAXU; ++u) {
-            const int base = 64 * u;                    // the three cases below are wave-uniform (scalar branches)
-            const double x = v[u];
-            if (base + 64 <= llen - 1) {
-                // the whole chunk inside the long row and off its diagonal element: no per-lane tests
-                accl += x * Dp[lane + base];
-                jsc[u] += x * dpl;
-                rowbuf[lane + base] = x;
-            } else if (base >= llen && base + 64 <= llen + slen - 1) {
-                // the whole chunk inside the short row and off its diagonal element
-                const int q = lq + base;
-                accs += x * Dp[q];
-                atomicAdd(&Jl[q], x * dps);
-                sbuf[q] = x;
-            } else if (base < llen + slen) {
-                // a chunk with an end of a row in it (at most three per pair): the general form
-                const int p = lane + base, q = lq + base;
-                if (p < llen) {
-                    accl += x * Dp[p];
-                    jsc[u] += (p < llen - 1) ? x * dpl : 0.0;
-                    rowbuf[p] = (p == llen - 1) ? 0.5 * x : x;
-                } else if (q < slen) {
-                    accs += x * Dp[q];
-                    if (q < slen - 1) atomicAdd(&Jl[q], x * dps);
-                    sbuf[q] = (q == slen - 1) ? 0.5 * x : x;
+        for (int u = 0; u < MAXU2; ++u) {
+            const int base = 128 * u, idx = 2 * lane + base;   // the cases below are wave-uniform
+            const double2v x = v2[u];
+            if (base + 128 <= pb) *(double2v*)(rowbuf + idx) = x;
+            else if (idx < pb) *(double2v*)(rowbuf + idx) = x;
+            if (base + 128 <= sb) {
+                // the whole chunk inside the (padded) long row: column = position
+                const double2v d = *(const double2v*)(Dp + idx);
+                accl += x[0] * d[0] + x[1] * d[1];
+                jsc2[u] += x * dpl;
+            } else if (base >= sb) {
+                if (base < se) {
+                    // the whole chunk inside the (padded) short row: column = position - sb
+                    const int q = idx - sb;
+                    if (idx < se) {
+                        accs += x[0] * Dp[q] + x[1] * Dp[q + 1];
+                        atomicAdd(&Jl[q], x[0] * dps);
+                        atomicAdd(&Jl[q + 1], x[1] * dps);
+                    }
+                }
+            } else {
+                // the chunk with the boundary in it
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int p = idx + e;
+                    if (p < sb) {
+                        accl += x[e] * Dp[p];
+                        jsc2[u][e] += x[e] * dpl;
+                    } else if (p < se) {
+                        accs += x[e] * Dp[p - sb];
+                        atomicAdd(&Jl[p - sb], x[e] * dps);
+                    }
                 }
             }
         }
-        if (lane < sb - llen) rowbuf[llen + lane] = 0.0;                                  // rest of shell row il
-        if (slen > 0 && lane < (is + 1) * (is + 2) / 2 - slen) rowbuf[sb + slen + lane] = 0.0;   // rest of shell row is
-        // the next pair's loads go out now and complete while this pair is contracted
+        // the next block's loads go out now and complete while this one is contracted
         const int nt = t + stride;
-        if (nt < npairs) load_pair(nt);
+        if (nt < npairs) load_block(nt);
         accl = wave_sum(accl);
         accs = wave_sum(accs);
-        if (lane == 0) { atomicAdd(&Jl[rl], accl); if (slen > 0) atomicAdd(&Jl[t], accs); }
+        if (lane == 0) { atomicAdd(&Jl[rl], accl); if (two) atomicAdd(&Jl[t], accs); }
         double ai, aj;
         row_exchange_tri(rowbuf, Dg + il * n, Dg + jl * n, il, lane, ai, aj);
         if (lane <= il) {
             atomicAdd(&Kl[il * n + lane], ai);
             if (il != jl) atomicAdd(&Kl[jl * n + lane], aj);
         }
-        if (slen > 0) {
+        if (two) {
             row_exchange_tri(rowbuf + sb, Dg + is * n, Dg + js * n, is, lane, ai, aj);
             if (lane <= is) {
                 atomicAdd(&Kl[is * n + lane], ai);
@@ -586,11 +591,28 @@ __global__ void __launch_bounds__(64 * NW) jk_tri_kernel(BatchView bv, int only_
         t = nt;
     }
 #pragma unroll
-    for (int u = 0; u < MAXU; ++u) {
-        const int p = lane + 64 * u;
-        if (p < np && jsc[u] != 0.0) atomicAdd(&Jl[p], jsc[u]);
+    for (int u = 0; u < MAXU2; ++u) {
+        const int idx = 2 * lane + 128 * u;
+        if (idx < np && jsc2[u][0] != 0.0) atomicAdd(&Jl[idx], jsc2[u][0]);
+        if (idx + 1 < np && jsc2[u][1] != 0.0) atomicAdd(&Jl[idx + 1], jsc2[u][1]);
     }
     __syncthreads();
+    if (gridDim.x == 1) {
+        // one workgroup per fragment (large batches): J and K = Kh + Kh^T are complete here -- plain stores, and the
+        // launcher zeroes nothing
+        for (int idx = tid; idx < np; idx += NTH) {
+            int k, l;
+            unpack_pair(idx, k, l);
+            const double jv = Jl[idx];
+            Jg[k * n + l] = jv;
+            Jg[l * n + k] = jv;
+        }
+        for (int idx = tid; idx < n * n; idx += NTH) {
+            const int a = idx / n, b = idx - a * n;
+            Kg[idx] = Kl[idx] + Kl[b * n + a];
+        }
+        return;
+    }
     for (int idx = tid; idx < np; idx += NTH) {
         const double jv = Jl[idx];
         if (jv == 0.0) continue;
@@ -608,28 +630,39 @@ __global__ void __launch_bounds__(64 * NW) jk_tri_kernel(BatchView bv, int only_
     }
 }
 
-// numbers a wave's LDS buffer must hold: the padded long triangle plus the padded short one, worst row pair
-static int jk_tri_buffer(int np)
+// doubles per block: the padded long triangle plus the padded short one, worst row pair (even, so that blocks stay
+// 16-byte aligned); optionally where the short row starts in every block
+int jk_tri_block(int np, std::vector<int>* short_row_start)
 {
     auto shell_row = [](int idx) { int k = (int)((std::sqrt(8.0 * idx + 1.0) - 1.0) * 0.5); while ((k + 1) * (k + 2) / 2 <= idx) ++k; while (k * (k + 1) / 2 > idx) --k; return k; };
+    const int npairs = (np + 1) / 2;
+    // table: [npairs] start of the short row in every block, then [np] the shell row i of every pair row (ij)
+    if (short_row_start) {
+        short_row_start->assign((size_t)npairs + np, 0);
+        for (int r = 0; r < np; ++r) (*short_row_start)[(size_t)npairs + r] = shell_row(r);
+    }
     int worst = 0;
-    for (int t = 0; t < (np + 1) / 2; ++t) {
+    for (int t = 0; t < npairs; ++t) {
         const int rl = np - 1 - t, il = shell_row(rl), is = shell_row(t);
-        const int need = (il + 1) * (il + 2) / 2 + (t < rl ? (is + 1) * (is + 2) / 2 : 0);
+        const int sb = (il + 1) * (il + 2) / 2;
+        const int need = sb + (t < rl ? (is + 1) * (is + 2) / 2 : 0);
+        if (short_row_start) (*short_row_start)[t] = sb;
         if (need > worst) worst = need;
     }
     return (worst + 1) & ~1;
 }
 
-constexpr int JK_TRI_NW = 12, JK_TRI_MAXU = 19;
-static size_t jk_tri_lds_bytes(int n, int np) { return sizeof(double) * ((size_t)JK_TRI_NW * jk_tri_buffer(np) + 2 * (size_t)np + (size_t)n * n); }
+constexpr int JK_TRI_NW = 12, JK_TRI_MAXU2 = 10;
+static size_t jk_tri_lds_bytes(int n, int np) { return sizeof(double) * ((size_t)JK_TRI_NW * jk_tri_block(np) + 2 * ((size_t)np + 2) + (size_t)n * n); }
 
 // The triangular layout is taken for the batches the tuned square kernel served: restricted, dimer-sized fragments
-// (n <= 64, a multiple of 8; 640 < npair, npair + 1 <= 19 * 64) in batches of at least 64.  MQC_HIP_ERI_TRI=0: square.
+// (n <= 64, a multiple of 8; 640 < npair; a block within ten chunks of 128) in batches of at least 64.
+// MQC_HIP_ERI_TRI=0: the square.
 bool jk_tri_layout(int n, int np, int nfrag, bool uhf)
 {
     static const bool on = [] { const char* e = std::getenv("MQC_HIP_ERI_TRI"); return !(e && e[0] == '0'); }();
-    if (!on || uhf || nfrag < 64 || n > 64 || n % 8 != 0 || np <= 10 * 64 || np + 1 > JK_TRI_MAXU * 64) return false;
+    if (!on || uhf || nfrag < 64 || n > 64 || n % 8 != 0 || np <= 10 * 64) return false;
+    if (jk_tri_block(np) > JK_TRI_MAXU2 * 128) return false;
     return jk_tri_lds_bytes(n, np) <= (size_t)160 * 1024 - 1024;
 }
 
@@ -662,20 +695,27 @@ static bool jk_rowcoop_on()
 void launch_jk_incore(const BatchView& bv, bool only_active, hipStream_t s)
 {
     const int n = bv.n, np = bv.npair;
-    (void)hipMemsetAsync(bv.K, 0, sizeof(double) * (size_t)bv.nfrag * n * n, s);
     if (bv.eri_tri) {
-        // J is summed over the workgroups of a fragment here (row and column roles), so it starts from zero like K
-        (void)hipMemsetAsync(bv.J, 0, sizeof(double) * (size_t)bv.nfrag * n * n, s);
         const size_t lds = jk_tri_lds_bytes(n, np);
-        auto kern = jk_tri_kernel<JK_TRI_NW, JK_TRI_MAXU>;
+        auto kern = jk_tri_kernel<JK_TRI_NW, JK_TRI_MAXU2>;
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        int gx = (4096 + bv.nfrag - 1) / bv.nfrag;
+        // Workgroups per fragment: every workgroup pays a prologue (packed density, 23 KB of LDS zeroed) and a flush, so
+        // as few as keep three rounds of workgroups on the card -- ONE from 768 fragments on (2016 dimers, same box:
+        // 3.12 ms per launch with one, 3.27 with three, 3.55 with six).  MQC_HIP_JK_TRI_WG overrides (measurements).
+        static const int gx_env = [] { const char* e = std::getenv("MQC_HIP_JK_TRI_WG"); return e ? std::atoi(e) : 0; }();
+        int gx = gx_env > 0 ? gx_env : (768 + bv.nfrag - 1) / bv.nfrag;
         const int maxx = ((np + 1) / 2 + JK_TRI_NW - 1) / JK_TRI_NW;
         if (gx < 1) gx = 1;
         if (gx > maxx) gx = maxx;
-        hipLaunchKernelGGL(kern, dim3(gx, bv.nfrag), dim3(64 * JK_TRI_NW), lds, s, bv, only_active ? 1 : 0, jk_tri_buffer(np));
+        if (gx > 1) {
+            // several workgroups add into J and K (atomics): both start from zero
+            (void)hipMemsetAsync(bv.K, 0, sizeof(double) * (size_t)bv.nfrag * n * n, s);
+            (void)hipMemsetAsync(bv.J, 0, sizeof(double) * (size_t)bv.nfrag * n * n, s);
+        }
+        hipLaunchKernelGGL(kern, dim3(gx, bv.nfrag), dim3(64 * JK_TRI_NW), lds, s, bv, only_active ? 1 : 0);
         return;
     }
+    (void)hipMemsetAsync(bv.K, 0, sizeof(double) * (size_t)bv.nfrag * n * n, s);
     const int kch = (n + 63) / 64;
     static const int skip_exchange = [] { const char* e = std::getenv("MQC_HIP_JK_SKIP_EXCHANGE"); return (e && e[0] == '1') ? 2 : 0; }();
     const int oa = (only_active ? 1 : 0) | skip_exchange;

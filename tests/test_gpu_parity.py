@@ -799,10 +799,12 @@ def test_block_sharing_gives_the_unshared_result(basis):
 
 # ---- the large-batch J/K variant (12 waves) -----------------------------------------------
 def test_large_batch_jk_variant_matches_small_batch_variant_and_oracle():
-    """66 water dimers in ONE batch take the tuned J/K kernel (>= 64 fragments: 12-wave workgroups, 16-byte
-    loads into padded row buffers, 8-wide exchange blocks with the density rows through the scalar cache); the
-    same dimers in three batches of 22 take the generic 4-wave kernel.  Same iteration counts, energies
-    within 1e-10; two of them are also checked against the CPU oracle."""
+    """66 water dimers in ONE batch (>= 64 fragments) store the tensor as triangular blocks of row pairs and take
+    jk_tri_kernel (every stored element in both of its roles, K = Kh + Kh^T, diagonal elements pre-halved; with
+    MQC_HIP_ERI_TRI=0: the tuned square kernel); the same dimers in three batches of 22 keep the square tensor and
+    the generic 4-wave kernel.  Same iteration counts, energies within 1e-10; two of them are also checked against
+    the CPU oracle.  The unscreened build exercises the zero fill the block padding needs, the screened one the
+    copy of shared blocks in the triangular layout."""
     rng = np.random.default_rng(123)
     ws = [water_at(rng, [5.8 * (i % 4), 5.8 * (i // 4), 0.6 * (i % 3)]) for i in range(12)]
     pairs = [(i, j) for i in range(12) for j in range(i + 1, 12)]          # 66 dimers
