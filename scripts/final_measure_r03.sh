@@ -4,7 +4,7 @@
 set -e
 export GPU_MAX_HW_QUEUES=16       # rocprofv3 initialises HIP before python starts
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r03_final
+O=gpurun_out/${1:-r03_final}
 mkdir -p $O
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --functional b3lyp --no-secondary --no-cpu-baseline > $O/bench_b3lyp.json 2> $O/bench_b3lyp.err

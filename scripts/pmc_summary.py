@@ -78,7 +78,7 @@ def main():
     if "fetch" in p and "write" in p:
         def pick(tag, counter, sub):
             for k, v in p[tag]["kernels"].items():
-                if sub in k and "12, 19" in k:
+                if sub in k and ("12, 19" in k or sub == "jk_tri_kernel"):
                     return v.get(counter, 0.0), v["launches"], k
             return 0.0, 0, None
         # the triangular-tensor kernel where the batch runs from it, else the tuned square kernel
