@@ -193,6 +193,11 @@ struct PairStore {
     }
     __device__ __forceinline__ void put(size_t row, size_t col, double v) const
     {
+#if defined(MQC_ERI_NO_STORE)
+        // MEASUREMENT build only (scripts/build_variant.sh): the arithmetic stays alive, nothing is written
+        if (v == 1.2345e300) M[0] = v;
+        return;
+#endif
         if (tri) {
             const size_t hi = row > col ? row : col, lo = row > col ? col : row;
             M[row_start(hi) + lo] = (hi == lo) ? 0.5 * v : v;

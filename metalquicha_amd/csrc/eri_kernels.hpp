@@ -38,10 +38,16 @@ __device__ __forceinline__ ShellRef make_shell(const TopologyDev& tp, const doub
 // (the algorithmic unit of the integral stage, counted as direct_stats_t does, mqc_libcint_direct.f90:606-610)
 __device__ __forceinline__ void count_formed(unsigned long long* ctr, unsigned long long ballot)
 {
+#if defined(MQC_NO_ERI_COUNT)
+    return;       // MEASUREMENT build (scripts/build_variant.sh): no counter traffic
+#endif
     if (ctr && (threadIdx.x & 63) == 0) atomicAdd(ctr, (unsigned long long)__popcll(ballot));
 }
 __device__ __forceinline__ void count_formed_sum(unsigned long long* ctr, int mine)
 {
+#if defined(MQC_NO_ERI_COUNT)
+    return;
+#endif
     int v = mine;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
