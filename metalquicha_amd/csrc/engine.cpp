@@ -1533,7 +1533,9 @@ int mqc_hip_coulomb_batch(mqc_hip_context* ctx, int64_t nfrag, const mqc_hip_mol
         BatchView bv{};
         rc = carve_batch(ctx, sl0, topo, td, nf, !direct, bv);
         if (rc != MQC_HIP_OK) return rc;
-        bv.nocc = std::max(1, topo.nelec / 2); bv.exx = 1.0; bv.Vxc = nullptr; bv.xc = XcSpec(); bv.xc.ncomp = 0;
+        // only J is read back: the direct digest skips its exchange updates when exx = 0; the in-core kernels
+        // form K alongside J in the same pass over the tensor either way
+        bv.nocc = std::max(1, topo.nelec / 2); bv.exx = direct ? 0.0 : 1.0; bv.Vxc = nullptr; bv.xc = XcSpec(); bv.xc.ncomp = 0;
         bv.naux = 0; bv.unit = ctx->d_unit;
         hx.resize((size_t)nf * topo.natoms * 3);
         for (int f = 0; f < nf; ++f) std::memcpy(&hx[(size_t)f * topo.natoms * 3], mols[start + f].xyz, sizeof(double) * topo.natoms * 3);

@@ -462,7 +462,9 @@ __global__ void __launch_bounds__(64) eri_digest_kernel(BatchView bv, const int*
                 for (int j = 0; j < NSB; ++j) s += V(i, j, k, l) * Dm[(oa + i) * n + ob + j];
             atomicAdd(&J[(oc + k) * n + od + l], wj * s);
         }
-    // K~_ik, K~_il, K~_jk, K~_jl
+    // K~_ik, K~_il, K~_jk, K~_jl -- unless no exact exchange is asked for (pure functionals; the Coulomb-only requests of
+    // mqc_hip_coulomb_batch): the exchange digest is two thirds of the scatter work (wave-uniform branch)
+    if (bv.exx == 0.0) return;
 #pragma unroll 1
     for (int i = 0; i < NSA; ++i)
 #pragma unroll 1

@@ -375,6 +375,7 @@ __global__ void __launch_bounds__(64) eri_general_kernel(BatchView bv, int la, i
             for (int i = 0; i < nsa; ++i) for (int j = 0; j < nsb; ++j) sm += GV(i, j, k, l) * Dm[(oa + i) * n + ob + j];
             atomicAdd(&J[(oc + k) * n + od + l], wj * sm);
         }
+        if (bv.exx == 0.0) return;      // no exact exchange asked for (pure functionals, Coulomb-only requests): J is all
         for (int idx = lane; idx < nsa * nsc; idx += 64) {
             const int i = idx / nsc, k = idx - i * nsc;
             double sm = 0.0;
