@@ -638,7 +638,8 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         // drop out of every kernel by themselves (state machine), so an iteration enqueued past convergence is three
         // empty launches.  Large batches keep one read per iteration (MQC_HIP_SCF_SYNC_BLOCK overrides: 1 = always).
         static const int sync_block_env = [] { const char* e = std::getenv("MQC_HIP_SCF_SYNC_BLOCK"); return e ? std::atoi(e) : 0; }();
-        const bool blocked = sync_block_env != 1 && nf <= 256;
+        static const int block_max_frag = [] { const char* e = std::getenv("MQC_HIP_SCF_BLOCK_MAX_FRAGMENTS"); return e ? std::atoi(e) : 256; }();
+        const bool blocked = sync_block_env != 1 && nf <= block_max_frag;
         int blocks_done = 0;
         while (remaining > 0 && guard < opts.max_iter + 2) {
           int block_len = 1;
