@@ -310,6 +310,90 @@ __global__ void __launch_bounds__(64) eri_twin_kernel(BatchView bv, const int* _
 }
 
 // ---------------------------------------------------------------------------------------
+// Twin entries of a SMALL batch (the literal drop-in: one fragment per call).  With lane = (entry, fragment) a batch of
+// one leaves every entry to a single thread, and an oxygen (1s 2s|1s 2s) entry walks 8^4 primitive quartets: 2.5 ms of a
+// 3.3 ms integral stage waited for that thread.  Here ONE wave takes an (entry, fragment): its 64 lanes share the
+// entry's bra primitive pairs (lane, lane + 64, ...; eri_cart_block_twin's partial form), the partial blocks are summed
+// across the wave, lane 0 transforms and stores.
+template <int LA, int LB, int LC, int LD>
+__global__ void __launch_bounds__(64) eri_twin_wave_kernel(BatchView bv, const int* __restrict__ quartets, int nquart,
+                                                           const double* __restrict__ Q, double thresh)
+{
+    const int w = blockIdx.x, lane = threadIdx.x;
+    const int iq = w / bv.nfrag, f = w - iq * bv.nfrag;
+    if (iq >= nquart) return;
+    const int eA = quartets[4 * iq], eB = quartets[4 * iq + 1], eC = quartets[4 * iq + 2], eD = quartets[4 * iq + 3];
+    const int A = eA & (TWIN_FLAG - 1), B = eB & (TWIN_FLAG - 1), C = eC & (TWIN_FLAG - 1), D = eD & (TWIN_FLAG - 1);
+    const bool tA = (eA & TWIN_FLAG) != 0, tB = (eB & TWIN_FLAG) != 0, tC = (eC & TWIN_FLAG) != 0, tD = (eD & TWIN_FLAG) != 0;
+    const TopologyDev& tp = bv.topo;
+    if (Q != nullptr) {
+        const int ns = tp.nshell;
+        const double* q = Q + (size_t)f * ns * ns;
+        double qab = 0.0, qcd = 0.0;
+        for (int ma = 0; ma <= (tA ? 1 : 0); ++ma)
+            for (int mb = 0; mb <= (tB ? 1 : 0); ++mb) qab = fmax(qab, q[(A + ma) * ns + B + mb]);
+        for (int mc = 0; mc <= (tC ? 1 : 0); ++mc)
+            for (int md = 0; md <= (tD ? 1 : 0); ++md) qcd = fmax(qcd, q[(C + mc) * ns + D + md]);
+        if (!(qab * qcd >= thresh)) return;         // wave-uniform
+    }
+    if (bv.eri_count && lane == 0) atomicAdd(bv.eri_count, (unsigned long long)((tA ? 2 : 1) * (tB ? 2 : 1) * (tC ? 2 : 1) * (tD ? 2 : 1)));
+    const double* xyz = bv.xyz + (size_t)f * tp.natoms * 3;
+    const ShellRef sa = make_shell(tp, xyz, A), sb = make_shell(tp, xyz, B), sc = make_shell(tp, xyz, C), sd = make_shell(tp, xyz, D);
+    TwinCoefs tw;
+    tw.ca[0] = sa.coefs; tw.ca[1] = tA ? tp.coefs + tp.sh_poff[A + 1] : sa.coefs; tw.fa = tA ? 1.0 : 0.0;
+    tw.cb[0] = sb.coefs; tw.cb[1] = tB ? tp.coefs + tp.sh_poff[B + 1] : sb.coefs; tw.fb = tB ? 1.0 : 0.0;
+    tw.cc[0] = sc.coefs; tw.cc[1] = tC ? tp.coefs + tp.sh_poff[C + 1] : sc.coefs; tw.fc = tC ? 1.0 : 0.0;
+    tw.cd[0] = sd.coefs; tw.cd[1] = tD ? tp.coefs + tp.sh_poff[D + 1] : sd.coefs; tw.fd = tD ? 1.0 : 0.0;
+    constexpr int NC = ncart(LA) * ncart(LB) * ncart(LC) * ncart(LD);
+    constexpr int NSA = nsph(LA), NSB = nsph(LB), NSC = nsph(LC), NSD = nsph(LD);
+    constexpr int MA = twin_mult(true, LA), MB = twin_mult(true, LB), MC = twin_mult(true, LC), MD = twin_mult(true, LD);
+    double acc[MA * MB * MC * MD * NC];
+    eri_cart_block_twin<LA, LB, LC, LD>(sa, sb, sc, sd, tw, bv.boys, acc, lane, 64);
+#pragma unroll
+    for (int i = 0; i < MA * MB * MC * MD * NC; ++i) {
+        double v = acc[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        acc[i] = v;
+    }
+    if (lane != 0) return;
+    const PairStore M = make_pair_store(bv, f);
+#pragma unroll
+    for (int ma = 0; ma < MA; ++ma) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+            for (int mc = 0; mc < MC; ++mc) {
+#pragma unroll
+                for (int md = 0; md < MD; ++md) {
+                    if ((ma && !tA) || (mb && !tB) || (mc && !tC) || (md && !tD)) continue;
+                    const int a = A + ma, b = B + mb, c = C + mc, d = D + md;
+                    double sph[NC];
+                    block_to_spherical<LA, LB, LC, LD>(bv.c2s, acc + (((ma * MB + mb) * MC + mc) * MD + md) * NC, sph);
+                    const int oa = tp.sh_aoff[a], ob = tp.sh_aoff[b], oc = tp.sh_aoff[c], od = tp.sh_aoff[d];
+#pragma unroll
+                    for (int i = 0; i < NSA; ++i) {
+#pragma unroll
+                        for (int j = 0; j < NSB; ++j) {
+                            if (a == b && j > i) continue;
+                            const size_t row = pair_index(oa + i, ob + j);
+#pragma unroll
+                            for (int k = 0; k < NSC; ++k) {
+#pragma unroll
+                                for (int l = 0; l < NSD; ++l) {
+                                    if (c == d && l > k) continue;
+                                    M.put(row, pair_index(oc + k, od + l), sph[((i * NSB + j) * NSC + k) * NSD + l]);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Pass kernel for the classes whose accumulators exceed the register file (md_integrals.hpp,
 // eri_pass): same (quartet, fragment) thread mapping; the accumulators of a wave sit in its own
 // LDS slab acc[entry][lane].
@@ -543,6 +627,15 @@ void launch_eri_twin_class(const BatchView& bv, const int* d_list, int nq, const
     const long total = d_tasks ? (long)ntasks : (long)nq * bv.nfrag;
     if (nq == 0 || total == 0) return;
     hipLaunchKernelGGL((eri_twin_kernel<LA, LB, LC, LD>), dim3((int)((total + 63) / 64)), dim3(64), 0, s, bv, d_list, nq, d_tasks, ntasks, Q, thresh);
+}
+
+// batches of at most this many fragments form their twin entries one WAVE per (entry, fragment)
+constexpr int ERI_TWIN_WAVE_MAX_FRAGMENTS = 16;
+template <int LA, int LB, int LC, int LD>
+void launch_eri_twin_wave_class(const BatchView& bv, const int* d_list, int nq, const double* Q, double thresh, hipStream_t s)
+{
+    if (nq == 0 || bv.nfrag == 0) return;
+    hipLaunchKernelGGL((eri_twin_wave_kernel<LA, LB, LC, LD>), dim3((unsigned)nq * (unsigned)bv.nfrag), dim3(64), 0, s, bv, d_list, nq, Q, thresh);
 }
 
 template <int LA, int LB>

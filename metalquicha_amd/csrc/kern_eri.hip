@@ -38,6 +38,9 @@ ERI_DECL(2, 2, 0, 0) ERI_DECL(2, 2, 1, 0) ERI_DECL(2, 2, 1, 1) ERI_DECL(2, 2, 2,
     extern template void launch_eri_twin_class<a, b, c, d>(const BatchView&, const int*, int, const int*, int, const double*, double, hipStream_t);
 TWIN_DECL(0, 0, 0, 0) TWIN_DECL(1, 0, 0, 0) TWIN_DECL(1, 0, 1, 0) TWIN_DECL(1, 1, 0, 0)
 TWIN_DECL(1, 1, 1, 0) TWIN_DECL(2, 0, 0, 0) TWIN_DECL(2, 0, 1, 0) TWIN_DECL(2, 1, 0, 0)
+#define TWINW_DECL(a, b, c, d) \
+    extern template void launch_eri_twin_wave_class<a, b, c, d>(const BatchView&, const int*, int, const double*, double, hipStream_t);
+TWINW_DECL(0, 0, 0, 0) TWINW_DECL(1, 0, 0, 0)
 SCHWARZ_DECL(0, 0) SCHWARZ_DECL(1, 0) SCHWARZ_DECL(1, 1) SCHWARZ_DECL(2, 0) SCHWARZ_DECL(2, 1) SCHWARZ_DECL(2, 2)
 
 #define DIG_DECL(a, b, c, d) \
@@ -547,6 +550,10 @@ void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, h
         std::sort(cost.begin(), cost.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
         for (auto& ck : cost) issue_order.push_back(ck.second);
         double load[ERI_SIDE_MAX + 1] = {};
+        // side stream 2 carries the one-electron chain of this chunk (int1e classes, orthogonaliser, guess: engine.cpp) ahead of
+        // anything queued here -- 1.9 ms for a single fragment, as much as the heaviest class launch: in a batch of one,
+        // three class launches placed on it waited for the guess and the whole stage with them (1.3 of 3.2 ms)
+        if (ERI_SIDE_STREAMS >= 3 && !cost.empty()) load[3] = 1.5 * cost.front().first;
         for (auto& ck : cost) {
             int best = 0;
             for (int q = 1; q <= ERI_SIDE_STREAMS; ++q) if (load[q] < load[best]) best = q;
@@ -568,9 +575,18 @@ void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, h
     }
 #define TWIN_CASE(a, b, c, d_)                                                                                        \
     if (cl.la == a && cl.lb == b && cl.lc == c && cl.ld == d_) {                                                      \
+        if (twin_wave && (a) <= 1 && (b) == 0 && (c) == 0 && (d_) == 0)                                               \
+            launch_twin_wave(a, d + L.dense_off, L.dense_n, dense_stream());                                          \
+        else                                                                                                          \
         launch_eri_twin_class<a, b, c, d_>(bv, d + L.dense_off, L.dense_n, nullptr, 0, Q, thresh, dense_stream());    \
         launch_eri_twin_class<a, b, c, d_>(bv, d + L.sh_off, L.sh_n, d + L.task_off, L.ntasks, Q, thresh, st.side[rr++ % ERI_SIDE_STREAMS]); \
     }
+    // small batches: the twin (ss|ss) and (ps|ss) entries one wave per (entry, fragment) (eri_twin_wave_kernel)
+    const bool twin_wave = bv.nfrag <= ERI_TWIN_WAVE_MAX_FRAGMENTS;
+    auto launch_twin_wave = [&](int la, const int* list, int nq, hipStream_t st_) {
+        if (la == 0) launch_eri_twin_wave_class<0, 0, 0, 0>(bv, list, nq, Q, thresh, st_);
+        else launch_eri_twin_wave_class<1, 0, 0, 0>(bv, list, nq, Q, thresh, st_);
+    };
     // in spread mode the launches are issued heaviest first (stream order = issue order)
     std::vector<int> order(cc->launches.size());
     for (size_t k = 0; k < order.size(); ++k) order[k] = (int)k;

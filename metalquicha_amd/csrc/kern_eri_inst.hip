@@ -9,6 +9,8 @@ namespace mqc {
     template void launch_eri_digest_class<a, b, c, d>(const BatchView&, const int*, int, const double*, const double*, double, double*, double*, int, hipStream_t);
 #define TWIN_INST(a, b, c, d) \
     template void launch_eri_twin_class<a, b, c, d>(const BatchView&, const int*, int, const int*, int, const double*, double, hipStream_t);
+#define TWINW_INST(a, b, c, d) \
+    template void launch_eri_twin_wave_class<a, b, c, d>(const BatchView&, const int*, int, const double*, double, hipStream_t);
 #define SCHWARZ_INST(a, b) \
     template void launch_schwarz_class<a, b>(const BatchView&, const int*, int, int*, double*, hipStream_t);
 
@@ -50,6 +52,7 @@ DIG_INST(2, 2, 1, 1)
 DIG_INST(2, 2, 2, 0)
 #elif ERI_GROUP == 16
 TWIN_INST(0, 0, 0, 0) TWIN_INST(1, 0, 0, 0) TWIN_INST(1, 0, 1, 0) TWIN_INST(1, 1, 0, 0)
+TWINW_INST(0, 0, 0, 0) TWINW_INST(1, 0, 0, 0)
 #elif ERI_GROUP == 17
 TWIN_INST(1, 1, 1, 0) TWIN_INST(2, 0, 0, 0) TWIN_INST(2, 0, 1, 0) TWIN_INST(2, 1, 0, 0)
 #elif ERI_GROUP == 14

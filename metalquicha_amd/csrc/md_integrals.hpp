@@ -468,7 +468,7 @@ MQC_HD void bra_from_hermite(const E1D<LA, LB>& ex, const E1D<LA, LB>& ey, const
 // into a zeroed buffer by this routine).
 template <int LA, int LB, int LC, int LD, class Bra, class Ket, class Twin = NoTwin>
 MQC_HD void eri_cart_block_src(const Bra& bra, const Ket& ket, const double* __restrict__ boys_table, double* out,
-                               const Twin& tw = Twin())
+                               const Twin& tw = Twin(), int bra_first = 0, int bra_step = 0)
 {
     constexpr int NCA = ncart(LA), NCB = ncart(LB), NCC = ncart(LC), NCD = ncart(LD);
     constexpr int LAB = LA + LB, LCD = LC + LD, L = LAB + LCD;
@@ -687,6 +687,65 @@ MQC_HD void eri_cart_block_src(const Bra& bra, const Ket& ket, const double* __r
             }
         }
     } else if constexpr (Twin::enabled) {
+      if (bra_step > 0) {
+        // PARTIAL twin block over the bra primitive pairs bra_first, bra_first + bra_step, ... (eri_twin_wave_kernel: the
+        // 64 lanes of a wave share ONE deeply contracted entry of a small batch and add their parts up afterwards).
+        // Bra pairs outside, one Hermite intermediate per ket member combination, as in the bra-outer form above: the
+        // ket loop only accumulates H[mcd][cd][tuv]; bra tables, bra members' weights and the accumulator sets come in
+        // once per bra pair.
+        constexpr int NK = NCC * NCD, MCD = MC * MD, HSZ = MCD * NK * NHAB;
+        const int nkl = ket.npairs(), nb = bra.npairs();
+        for (int b = bra_first; b < nb; b += bra_step) {
+            const int pi = b / bra.npb(), pj = b - pi * bra.npb();
+            const PrimPair P = bra.get(pi, pj);
+            if (P.kp == 0.0) continue;
+            double H[HSZ];
+#pragma unroll
+            for (int h = 0; h < HSZ; ++h) H[h] = 0.0;
+            PrimPair Qn = ket.get(0, 0);
+            int kc = 0, kd = 0;
+            for (int kl = 0; kl < nkl; ++kl) {
+                const PrimPair Qp = Qn;
+                double wcd[MCD];
+#pragma unroll
+                for (int mc = 0; mc < MC; ++mc)
+#pragma unroll
+                    for (int md = 0; md < MD; ++md) wcd[mc * MD + md] = twin_coef(tw.cc, tw.fc, mc, kc) * twin_coef(tw.cd, tw.fd, md, kd);
+                if (++kd == ket.npb()) { kd = 0; ++kc; }
+                if (kl + 1 < nkl) Qn = ket.get(kc, kd);
+                if (Qp.kp == 0.0) continue;
+                E1D<LC, LD> fx, fy, fz;
+                fx.build(Qp.px - ket.ax(), Qp.px - ket.bx(), Qp.hp);
+                fy.build(Qp.py - ket.ay(), Qp.py - ket.by(), Qp.hp);
+                fz.build(Qp.pz - ket.az(), Qp.pz - ket.bz(), Qp.hp);
+                const double rs = fast_rsqrt(P.p + Qp.p);
+                const double alpha = P.p * Qp.p * rs * rs;
+                double R[nherm(L)];
+                hermite_r<L>(alpha, P.px - Qp.px, P.py - Qp.py, P.pz - Qp.pz, boys_table, R, TWO_PI_25 * Qp.kp * rs);
+                double G[NK * NHAB];
+#pragma unroll
+                for (int h = 0; h < NK * NHAB; ++h) G[h] = 0.0;
+                ket_into_hermite<LAB, LC, LD>(fx, fy, fz, R, G);
+#pragma unroll
+                for (int m = 0; m < MCD; ++m)
+#pragma unroll
+                    for (int h = 0; h < NK * NHAB; ++h) H[m * NK * NHAB + h] += wcd[m] * G[h];
+            }
+            E1D<LA, LB> ex, ey, ez;
+            ex.build(P.px - bra.ax(), P.px - bra.bx(), P.hp);
+            ey.build(P.py - bra.ay(), P.py - bra.by(), P.hp);
+            ez.build(P.pz - bra.az(), P.pz - bra.bz(), P.hp);
+#pragma unroll
+            for (int ma = 0; ma < MA; ++ma)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const double wab = P.kp * twin_coef(tw.ca, tw.fa, ma, pi) * twin_coef(tw.cb, tw.fb, mb, pj);
+#pragma unroll
+                    for (int m = 0; m < MCD; ++m)
+                        bra_from_hermite<LA, LB, NK>(ex, ey, ez, H + m * NK * NHAB, wab, out + ((ma * MB + mb) * MCD + m) * NC);
+                }
+        }
+      } else {
         static_assert(!Twin::enabled || TK > 1, "twin blocks exist for the small register classes only");
         constexpr int TKT = (NC == 1) ? 2 : 1;   // ket records held at a time (register budget: NCOMB accumulator sets)
         const int nkl = ket.npairs();
@@ -739,6 +798,7 @@ MQC_HD void eri_cart_block_src(const Bra& bra, const Ket& ket, const double* __r
                 }
             }
         }
+      }
     } else if constexpr (TK > 1) {
         const int nkl = ket.npairs();
         int kc = 0, kd = 0;
@@ -818,10 +878,10 @@ constexpr int eri_twin_combos(int la, int lb, int lc, int ld)
 }
 template <int LA, int LB, int LC, int LD>
 MQC_HD void eri_cart_block_twin(const ShellRef& A, const ShellRef& B, const ShellRef& C, const ShellRef& D, const TwinCoefs& tw,
-                                const double* __restrict__ boys_table, double* out)
+                                const double* __restrict__ boys_table, double* out, int bra_first = 0, int bra_step = 0)
 {
     const PairFlyRaw bra(A, B), ket(C, D);
-    eri_cart_block_src<LA, LB, LC, LD, PairFlyRaw, PairFlyRaw, TwinCoefs>(bra, ket, boys_table, out, tw);
+    eri_cart_block_src<LA, LB, LC, LD, PairFlyRaw, PairFlyRaw, TwinCoefs>(bra, ket, boys_table, out, tw, bra_first, bra_step);
 }
 
 // ---------------------------------------------------------------------------------------

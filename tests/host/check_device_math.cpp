@@ -80,6 +80,17 @@ static double run_twin(const ShellRef* sh, const double* const* second, const bo
     tw.cd[0] = sh[3].coefs; tw.cd[1] = second[3]; tw.fd = is_twin[3] ? 1.0 : 0.0;
     eri_cart_block_twin<LA, LB, LC, LD>(sh[0], sh[1], sh[2], sh[3], tw, g_boys.data(), acc.data());
     double worst = 0.0;
+    {
+        // the partial blocks of eri_twin_wave_kernel (bra primitive pairs first, first + 3, ...) add up to the whole block
+        std::vector<double> part(acc.size(), 0.0), tmp(acc.size());
+        for (int first = 0; first < 3; ++first) {
+            eri_cart_block_twin<LA, LB, LC, LD>(sh[0], sh[1], sh[2], sh[3], tw, g_boys.data(), tmp.data(), first, 3);
+            for (size_t i = 0; i < acc.size(); ++i) part[i] += tmp[i];
+        }
+        double scale = 1.0;
+        for (double v : acc) scale = std::max(scale, std::fabs(v));
+        for (size_t i = 0; i < acc.size(); ++i) worst = std::max(worst, std::fabs(part[i] - acc[i]) / scale);
+    }
     const int M[4] = {MA, MB, MC, MD};
     for (int ma = 0; ma < MA; ++ma) for (int mb = 0; mb < MB; ++mb) for (int mc = 0; mc < MC; ++mc) for (int md = 0; md < MD; ++md) {
         const int m[4] = {ma, mb, mc, md};
