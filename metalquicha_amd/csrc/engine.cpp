@@ -24,6 +24,7 @@ void eri_plan_lists(const BatchView& bv, const Topology& topo, hipStream_t s, co
 bool launch_gradient(const BatchView& bv, const Topology& topo, const Topology* aux, double* d_grad, double* work, int* d_lists,
                      size_t list_capacity_ints, hipStream_t s, std::string& err);                                                      // kern_grad.hip
 void launch_scale(double* p, size_t count, double f, hipStream_t s);      // kern_df.hip
+void int1e_reset_state();                                                 // kern_int1e.hip: fan-out streams of small batches
 void launch_jk_direct_incremental(const BatchView& bv, const Topology& topo, double thresh, bool only_active, hipStream_t s);   // kern_eri.hip
 static DevicePool g_grad_pool[2];
 
@@ -1204,6 +1205,7 @@ int mqc_hip_finalize(void)
     // launcher state bound to this device (side streams, fork/join events, list caches), then every pool:
     // the context's own and the launchers' function-static ones -- a later context_get starts from nothing
     eri_reset_state();
+    int1e_reset_state();
     release_all_pools();
     for (int l = 0; l < 2; ++l) {
         for (int k = 0; k < 3; ++k) if (g_ctx->side[l][k]) (void)hipStreamDestroy(g_ctx->side[l][k]);

@@ -374,6 +374,29 @@ void launch_dipole(const BatchView& bv, const Topology& topo, hipStream_t s, boo
 #undef DIP_CASE
 }
 
+// Small batches: the class launches of the one-electron stage are latency-bound (0.05-0.26 ms each for one fragment,
+// 0.83 ms one after the other -- and the orthogonaliser, the guess and with them the SCF loop wait for the last one):
+// they are independent, so they fan out over three more streams and join before the caller's next launch.
+namespace {
+struct Int1eFan {
+    hipStream_t x[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
+    bool ready = false;
+};
+Int1eFan g_int1e_fan[2];
+constexpr int INT1E_FAN_MAX_FRAGMENTS = 16;
+}  // namespace
+
+void int1e_reset_state()
+{
+    for (auto& f : g_int1e_fan) {
+        if (!f.ready) continue;
+        for (int k = 0; k < 3; ++k) { if (f.x[k]) (void)hipStreamDestroy(f.x[k]); if (f.join[k]) (void)hipEventDestroy(f.join[k]); f.x[k] = nullptr; f.join[k] = nullptr; }
+        if (f.fork) (void)hipEventDestroy(f.fork);
+        f.fork = nullptr; f.ready = false;
+    }
+}
+
 void launch_int1e(const BatchView& bv_in, const Topology& topo, hipStream_t s)
 {
     static DevicePool scratch_slot[2];
@@ -415,10 +438,30 @@ void launch_int1e(const BatchView& bv_in, const Topology& topo, hipStream_t s)
     }
     int* d = (int*)scratch_slot[bv.slot & 1].ensure((topo.pairs.size() + 16) * sizeof(int));
     size_t off = 0;
-#define I1_CASE(a, b) launch_class<a, b>(bv, bucket[a][b], d + off, s); off += bucket[a][b].size();
-    I1_CASE(0, 0) I1_CASE(1, 0) I1_CASE(1, 1) I1_CASE(2, 0) I1_CASE(2, 1) I1_CASE(2, 2)
-    I1_CASE(3, 0) I1_CASE(3, 1) I1_CASE(3, 2) I1_CASE(3, 3)
+    Int1eFan& fan = g_int1e_fan[bv.slot & 1];
+    bool fanned = bv.nfrag <= INT1E_FAN_MAX_FRAGMENTS;
+    if (fanned && !fan.ready) {
+        bool ok = hipEventCreateWithFlags(&fan.fork, hipEventDisableTiming) == hipSuccess;
+        for (int k = 0; k < 3 && ok; ++k)
+            ok = hipStreamCreateWithFlags(&fan.x[k], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&fan.join[k], hipEventDisableTiming) == hipSuccess;
+        fan.ready = ok;
+        if (!ok) fanned = false;
+    }
+    if (fanned) {
+        (void)hipEventRecord(fan.fork, s);
+        for (int k = 0; k < 3; ++k) (void)hipStreamWaitEvent(fan.x[k], fan.fork, 0);
+    }
+    // stream of a class: the caller's for (ss|, the others dealt so that the four chains are about as long
+    auto st = [&](int k) { return (fanned && k > 0) ? fan.x[k - 1] : s; };
+#define I1_CASE(a, b, k) launch_class<a, b>(bv, bucket[a][b], d + off, st(k)); off += bucket[a][b].size();
+    I1_CASE(0, 0, 0) I1_CASE(1, 0, 2) I1_CASE(1, 1, 3) I1_CASE(2, 0, 1) I1_CASE(2, 1, 2) I1_CASE(2, 2, 1)
+    I1_CASE(3, 0, 3) I1_CASE(3, 1, 3) I1_CASE(3, 2, 2) I1_CASE(3, 3, 1)
 #undef I1_CASE
+    if (fanned)
+        for (int k = 0; k < 3; ++k) {
+            (void)hipEventRecord(fan.join[k], fan.x[k]);
+            (void)hipStreamWaitEvent(s, fan.join[k], 0);
+        }
 }
 
 }  // namespace mqc
