@@ -582,7 +582,8 @@ void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, h
         launch_eri_twin_class<a, b, c, d_>(bv, d + L.sh_off, L.sh_n, d + L.task_off, L.ntasks, Q, thresh, st.side[rr++ % ERI_SIDE_STREAMS]); \
     }
     // small batches: the twin (ss|ss) and (ps|ss) entries one wave per (entry, fragment) (eri_twin_wave_kernel)
-    const bool twin_wave = bv.nfrag <= ERI_TWIN_WAVE_MAX_FRAGMENTS;
+    static const int twin_wave_max = [] { const char* e = std::getenv("MQC_HIP_TWIN_WAVE_MAX"); return e ? std::atoi(e) : ERI_TWIN_WAVE_MAX_FRAGMENTS; }();
+    const bool twin_wave = bv.nfrag <= twin_wave_max;
     auto launch_twin_wave = [&](int la, const int* list, int nq, hipStream_t st_) {
         if (la == 0) launch_eri_twin_wave_class<0, 0, 0, 0>(bv, list, nq, Q, thresh, st_);
         else launch_eri_twin_wave_class<1, 0, 0, 0>(bv, list, nq, Q, thresh, st_);
