@@ -685,6 +685,20 @@ def test_direct_scf_matches_incore_and_oracle():
     assert abs(dire.energy.scf - (-76.0220988827)) < 1e-9
 
 
+def test_direct_scf_with_a_pure_functional_skips_exchange_and_matches_incore():
+    """A functional without exact exchange on the direct path: the digest kernels leave after their Coulomb updates
+    (exx = 0: K is never formed).  Same energy and iteration count as the in-core path, which forms K alongside J and
+    weights it with zero; the hybrid next to it still digests the exchange."""
+    frag = fragment_bohr(*WATER)
+    for fun in ("pbe", "b3lyp"):
+        kw = dict(basis_set="cc-pvdz", functional=fun, energy_tol=1e-10, density_tol=1e-8, guess="gwh")
+        inc = methods.run_hip_scf(methods.ScfSettings(eri_mode="incore", **kw), frag)
+        dire = methods.run_hip_scf(methods.ScfSettings(eri_mode="direct", **kw), frag)
+        assert not inc.has_error and not dire.has_error, (inc.error_message, dire.error_message)
+        assert abs(dire.energy.scf - inc.energy.scf) < 1e-9, (fun, dire.energy.scf, inc.energy.scf)
+        assert dire.scf_iterations == inc.scf_iterations
+
+
 def test_direct_scf_batch_with_far_apart_dimer_screens_and_agrees():
     rng = np.random.default_rng(31)
     ws = [water_at(rng, c) for c in ([0, 0, 0], [14.0, 0.5, -0.3])]
@@ -830,6 +844,28 @@ def test_large_batch_jk_variant_matches_small_batch_variant_and_oracle():
         assert not b.has_error, b.error_message
         assert a.scf_iterations == b.scf_iterations
         assert abs(a.energy.scf - b.energy.scf) < 1e-10
+
+
+def test_small_batch_paths_match_the_large_batch_paths():
+    """Batches of at most 16 fragments form their twin (ss|ss) / (ps|ss) entries one wave per (entry, fragment) with the
+    lanes over the bra primitive pairs, fan the one-electron classes over four streams and skip the Schwarz bounds;
+    larger ones run lane = fragment throughout.  The same four dimers alone and inside a batch of twenty: same
+    iteration counts, energies within 1e-10; one of them against the oracle."""
+    rng = np.random.default_rng(77)
+    ws = [water_at(rng, [5.6 * (i % 3), 5.9 * (i // 3), 0.4 * (i % 2)]) for i in range(7)]
+    pairs = [(i, j) for i in range(7) for j in range(i + 1, 7)][:20]
+    frags = [fragment_bohr([8, 1, 1, 8, 1, 1], np.vstack([ws[i], ws[j]])) for i, j in pairs]
+    st = methods.ScfSettings(basis_set="cc-pvdz", energy_tol=1e-9, density_tol=1e-7, guess="gwh", eri_mode="incore")
+    big = methods.run_hip_scf_batch(st, frags)
+    small = methods.run_hip_scf_batch(st, frags[:4])
+    one = methods.run_hip_scf(st, frags[2])
+    for a, b in zip(big[:4], small):
+        assert not a.has_error and not b.has_error, (a.error_message, b.error_message)
+        assert a.scf_iterations == b.scf_iterations
+        assert abs(a.energy.scf - b.energy.scf) < 1e-10
+    assert abs(one.energy.scf - big[2].energy.scf) < 1e-10 and one.scf_iterations == big[2].scf_iterations
+    o = so.run_rhf(oracle_mol("cc-pvdz", frags[2]), 20, 100, 1e-9, 1e-7)
+    assert abs(one.energy.scf - o.energy) < 1e-8 and one.scf_iterations == o.iterations
 
 
 # ---- concurrent topology groups ---------------------------------------------------------------------
