@@ -846,6 +846,33 @@ def test_large_batch_jk_variant_matches_small_batch_variant_and_oracle():
         assert abs(a.energy.scf - b.energy.scf) < 1e-10
 
 
+def test_triangular_tensor_at_another_fragment_size():
+    """n = 40 (four hydrogen molecules, cc-pVDZ: npair = 820, blocks of 874 doubles): the triangular J/K path away from
+    the water dimers' 48 functions.  70 fragments in one batch (triangular blocks, several workgroups per fragment with
+    atomic flushes) against the same fragments in batches of 14 (square tensor): iteration counts equal, energies
+    within 1e-10; one against the oracle."""
+    rng = np.random.default_rng(2024)
+    frags = []
+    for _ in range(70):
+        centres = np.array([[0.0, 0.0, 0.0], [4.2, 0.3, -0.2], [0.4, 4.4, 0.3], [4.0, 4.1, 0.5]]) + rng.normal(scale=0.25, size=(4, 3))
+        xyz = []
+        for c in centres:
+            d = rng.normal(size=3); d *= 0.70 / np.linalg.norm(d)
+            xyz += [c - d, c + d]
+        frags.append(fragment_bohr([1] * 8, np.array(xyz)))
+    st = methods.ScfSettings(basis_set="cc-pvdz", energy_tol=1e-9, density_tol=1e-7, guess="gwh", eri_mode="incore", schwarz_tol=1e-12)
+    big = methods.run_hip_scf_batch(st, frags)
+    small = []
+    for k in range(0, 70, 14):
+        small += methods.run_hip_scf_batch(st, frags[k:k + 14])
+    for a, b in zip(big, small):
+        assert not a.has_error and not b.has_error, (a.error_message, b.error_message)
+        assert a.scf_iterations == b.scf_iterations
+        assert abs(a.energy.scf - b.energy.scf) < 1e-10
+    o = so.run_rhf(oracle_mol("cc-pvdz", frags[5]), 8, 100, 1e-9, 1e-7)          # eight electrons
+    assert abs(big[5].energy.scf - o.energy) < 1e-8 and big[5].scf_iterations == o.iterations
+
+
 def test_small_batch_paths_match_the_large_batch_paths():
     """Batches of at most 16 fragments form their twin (ss|ss) / (ps|ss) entries one wave per (entry, fragment) with the
     lanes over the bra primitive pairs, fan the one-electron classes over four streams and skip the Schwarz bounds;
