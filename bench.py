@@ -389,8 +389,9 @@ def main():
             per_frag = big_b / big_n / max(n_dimers // world, 1) / 8.0
             if per_frag < 0.75 * npd * npd:
                 jk_name = "jk_tri_kernel"
-                jk_layout = ("lower triangle of the pair matrix in blocks of row pairs (zero-padded to whole shell rows): about %d doubles per "
-                             "fragment and launch as the engine counted them; the bare triangle npair (npair + 1) / 2 = %d, the square %d"
+                jk_layout = ("lower triangle of the pair matrix in blocks of row pairs (zero-padded to whole shell rows); the kernel skips pair rows "
+                             "the Schwarz bounds prove zero and counts the 1 KiB chunks it reads: %d doubles per fragment and launch on average "
+                             "(stored: about 729 k with the padding; the bare triangle npair (npair + 1) / 2 = %d, the square %d)"
                              % (int(round(per_frag)), npd * (npd + 1) // 2, npd * npd))
             else:
                 jk_layout = "square pair matrix, npair^2 = %d doubles per fragment" % (npd * npd)

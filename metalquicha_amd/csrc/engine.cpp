@@ -25,6 +25,7 @@ bool launch_gradient(const BatchView& bv, const Topology& topo, const Topology* 
                      size_t list_capacity_ints, hipStream_t s, std::string& err);                                                      // kern_grad.hip
 void launch_scale(double* p, size_t count, double f, hipStream_t s);      // kern_df.hip
 void int1e_reset_state();                                                 // kern_int1e.hip: fan-out streams of small batches
+void eri_schwarz_view(int slot, const double** q, double* thresh);        // kern_eri.hip
 void launch_jk_direct_incremental(const BatchView& bv, const Topology& topo, double thresh, bool only_active, hipStream_t s);   // kern_eri.hip
 static DevicePool g_grad_pool[2];
 
@@ -219,10 +220,10 @@ static int carve_batch(mqc_hip_context* ctx, Slot& sl, const Topology& topo, con
     if (npc > 0) bv.pc = (double*)take(sizeof(double) * nf * npc * 4);
     if (npc > 0 || hx) bv.U = (double*)take(sizeof(double) * nf * nn);
     if (hx) bv.Hx = (double*)take(sizeof(double) * nf * nn);
-    bv.counters = (int*)sl.misc->ensure(256 + sizeof(int) * (2 * (size_t)topo.npair + 8));      // + the block tables of a triangular tensor
+    bv.counters = (int*)sl.misc->ensure(256 + sizeof(int) * (2 * (size_t)topo.npair + 8 + (size_t)nfrag));      // + the block tables of a triangular tensor + its per-fragment read counters
     if (!bv.counters) return fail(MQC_HIP_ERR_DEVICE, "out of device memory (counters)");
     bv.eri_count = (unsigned long long*)(bv.counters + 16);
-    bv.eri = nullptr; bv.eri_tri = 0; bv.eri_tri_pb = 0; bv.eri_tri_sb = nullptr; bv.eri_stride = 0;
+    bv.eri = nullptr; bv.eri_tri = 0; bv.eri_tri_pb = 0; bv.eri_tri_sb = nullptr; bv.eri_stride = 0; bv.jk_q = nullptr; bv.jk_qthresh = 0.0; bv.jk_loaded = nullptr;
     if (with_eri) {
         const size_t np = (size_t)topo.npair;
         bv.eri_tri = jk_tri_layout(n, topo.npair, nfrag, uhf) ? 1 : 0;
@@ -237,6 +238,7 @@ static int carve_batch(mqc_hip_context* ctx, Slot& sl, const Topology& topo, con
             if (hipMemcpyAsync(d_sb, sbh.data(), sizeof(int) * sbh.size(), hipMemcpyHostToDevice, sl.s) != hipSuccess)
                 return fail(MQC_HIP_ERR_DEVICE, "upload of the tensor block table failed");
             bv.eri_tri_sb = d_sb;
+            bv.jk_loaded = d_sb + 2 * (size_t)topo.npair + 8;
         }
         bv.eri = (double*)sl.eri->ensure(sizeof(double) * nf * bv.eri_stride);
         if (!bv.eri) return fail(MQC_HIP_ERR_DEVICE, "out of device memory (ERI tensor)");
@@ -580,7 +582,11 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         HIP_CHECK_RET(hipEventRecord(sl.q0, s));
         if (use_df) launch_df_build(bv, topo, *aux, s);
         else if (use_direct) launch_direct_setup(bv, topo, s);
-        else launch_eri(bv, topo, stol, s, job.hx.data());
+        else {
+            launch_eri(bv, topo, stol, s, job.hx.data());
+            // the bounds of a screened build tell the J/K kernel which pair rows are all zeros (triangular tensor only)
+            if (stol > 0.0 && bv.eri_tri) eri_schwarz_view(bv.slot, &bv.jk_q, &bv.jk_qthresh);
+        }
         HIP_CHECK_RET(hipEventRecord(sl.q1, s));
         if ((rc = stage_check("two-electron setup")) != MQC_HIP_OK) return rc;
         sx->stats.eri_quartets += topo.n_quartets * nf;
@@ -627,6 +633,7 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
         }
         int remaining = nf;
         int guard = 0;
+        double tri_doubles_per_fragment = -1.0;      // read back after the first J/K launch of the chunk
         // Kohn-Sham: the quadrature needs the density only, like J/K -- it runs on the lane's side stream next to the
         // J/K build and joins before the SCF step (the event pair that synchronised orthogonaliser and guess is free now)
         hipStream_t sxc = ctx->side[sl.id & 1][2];
@@ -716,9 +723,20 @@ int run_batch(mqc_hip_context* ctx, const Topology& topo, const Topology* aux, c
             }
             // density fitting: the J/K kernel reads the fitted tensor once, and it is stored packed [naux][npair] -- about
             // half of SURVEY 8d's 8 n^2 A (df_bytes keeps that figure; fock_bytes is what the kernel really streams)
-            // in-core: the tensor as stored -- the square, or its lower triangle (BatchView::eri_tri) -- once per spin density
+            // in-core: the tensor as stored -- the square, or its lower triangle (BatchView::eri_tri) -- once per spin density;
+            // the triangular kernel skips rows the Schwarz bounds prove zero and reports the chunks it did read
+            if (bv.eri_tri && bv.jk_loaded && tri_doubles_per_fragment < 0.0) {
+                std::vector<int> ld(nf);
+                if (hipMemcpy(ld.data(), bv.jk_loaded, sizeof(int) * (size_t)nf, hipMemcpyDeviceToHost) == hipSuccess) {
+                    double sum = 0.0;
+                    for (int v : ld) sum += v;
+                    tri_doubles_per_fragment = 128.0 * sum / (double)nf;
+                } else tri_doubles_per_fragment = (double)bv.eri_stride;
+            }
+            const double tensor_doubles = (bv.eri_tri && tri_doubles_per_fragment >= 0.0) ? tri_doubles_per_fragment
+                                                                                         : (bv.eri_stride ? (double)bv.eri_stride : (double)np * (double)np);
             const double launch_bytes = use_df ? (double)remaining * (double)naux * (double)np * 8.0
-                                               : (double)remaining * (bv.eri_stride ? (double)bv.eri_stride : (double)np * (double)np) * 8.0 * (uhf ? 2.0 : 1.0);
+                                               : (double)remaining * tensor_doubles * 8.0 * (uhf ? 2.0 : 1.0);
             sx->stats.fock_kernel_seconds += ms * 1e-3 * block_len;
             sx->stats.fock_bytes += launch_bytes * block_len;
             sx->stats.fock_launches += block_len;

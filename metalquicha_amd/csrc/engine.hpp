@@ -146,6 +146,12 @@ struct BatchView {      // plain pointers handed to kernels
     int eri_tri, eri_tri_pb;
     const int* eri_tri_sb;        // [(npair + 1) / 2] short-row starts, then [npair] the shell row i of every pair row (ij)
     size_t eri_stride;            // doubles per fragment: npair^2, or (npair + 1) / 2 blocks
+    // Schwarz bounds of the screened in-core build, for the J/K kernel: a pair row (ij) whose bound times the fragment's
+    // largest bound is below the threshold was never written by any class kernel -- it is all zeros, and jk_tri_kernel
+    // neither loads nor contracts it (three quarters of the dimers of an MBE list are far apart: half of their rows)
+    const double* jk_q;           // [nfrag][nshell][nshell] or nullptr
+    double jk_qthresh;
+    int* jk_loaded;               // [nfrag] chunks of 128 doubles the last jk_tri_kernel launch read for each fragment (byte accounting)
     double *diis_f, *diis_e, *diis_b;   // [nfrag][8][n*n], [nfrag][8][n*n], [nfrag][8*8]
     int* diis_state;              // [nfrag][2] = n_stored, newest
     double* scal;                 // [nfrag][8]: e_elec, e_old, de, drms, e_final, E_xc, N_electrons, -

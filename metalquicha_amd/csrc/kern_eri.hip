@@ -464,6 +464,13 @@ static EriListCache* eri_lists(const BatchView& bv, const Topology& topo, hipStr
     return cc;
 }
 
+// the Schwarz bounds and threshold the slot's last screened build used (engine.cpp hands them to the J/K kernel)
+void eri_schwarz_view(int slot, const double** q, double* thresh)
+{
+    EriSlotState& st = eri_slot_state(slot);
+    *q = st.Q; *thresh = st.bounds_tol;
+}
+
 void eri_plan_lists(const BatchView& bv, const Topology& topo, hipStream_t s, const double* host_xyz)
 {
     (void)eri_lists(bv, topo, s, host_xyz);

@@ -492,6 +492,40 @@ __global__ void __launch_bounds__(64 * NW) jk_tri_kernel(BatchView bv, int only_
     double* Dp = lds + (size_t)NW * pb;                 // packed (2 - delta) D, two zeros behind it
     double* Jl = Dp + np + 2;                           // packed J of this workgroup (+ two slots the padding may touch)
     double* Kl = Jl + np + 2;                           // n * n: Kh of this workgroup
+    unsigned char* rz = (unsigned char*)(Kl + (size_t)n * n);          // [np] 1 = pair row known to be all zeros
+    int* ao2sh = (int*)(rz + ((np + 15) & ~15));                        // [64] shell of every function
+    double* wred = (double*)(ao2sh + 64);                               // [NW]
+
+    // Zero rows.  A screened build leaves a pair row (ij) untouched -- all zeros from the fill -- when Q_ij times the
+    // fragment's largest bound is below the threshold: every quartet on that bra pair was dropped.  For the far-apart
+    // dimers of an MBE list that is every row with i and j on different monomers, half of the tensor; such rows are
+    // neither loaded nor contracted.  (Twin blocks are kept or dropped as a whole, so a row this test calls zero can
+    // hold integrals below the threshold: dropping them is what the threshold means.)
+    const bool screen = bv.jk_q != nullptr;
+    if (screen) {
+        const TopologyDev& tp = bv.topo;
+        const int ns = tp.nshell;
+        const double* __restrict__ Qf = bv.jk_q + (size_t)f * ns * ns;
+        for (int sh = tid; sh < ns; sh += NTH) {
+            const int o = tp.sh_aoff[sh], nfun = 2 * tp.sh_l[sh] + 1;
+            for (int m = 0; m < nfun; ++m) ao2sh[o + m] = sh;
+        }
+        double qm = 0.0;
+        for (int idx = tid; idx < ns * ns; idx += NTH) qm = fmax(qm, Qf[idx]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) qm = fmax(qm, __shfl_xor(qm, off, 64));
+        if (lane == 0) wred[wave] = qm;
+        __syncthreads();
+        double qmax = 0.0;
+        for (int w = 0; w < NW; ++w) qmax = fmax(qmax, wred[w]);
+        for (int idx = tid; idx < np; idx += NTH) {
+            int k, l;
+            unpack_pair(idx, k, l);
+            rz[idx] = (Qf[ao2sh[k] * ns + ao2sh[l]] * qmax < bv.jk_qthresh) ? 1 : 0;
+        }
+    } else {
+        for (int idx = tid; idx < np; idx += NTH) rz[idx] = 0;
+    }
 
     for (int idx = tid; idx < np + 2; idx += NTH) {
         double d = 0.0;
@@ -505,6 +539,9 @@ __global__ void __launch_bounds__(64 * NW) jk_tri_kernel(BatchView bv, int only_
         Jl[idx] = 0.0;
     }
     for (int idx = tid; idx < n * n; idx += NTH) Kl[idx] = 0.0;
+    // slot 0 of the function -> shell map doubles as the workgroup's count of chunks read: function 0 sits in shell 0, so
+    // the slot already holds 0 where the map was built, and is set to 0 where it was not
+    if (tid == 0) ao2sh[0] = 0;
     __syncthreads();
 
     double2v v2[MAXU2], jsc2[MAXU2];
@@ -513,26 +550,48 @@ __global__ void __launch_bounds__(64 * NW) jk_tri_kernel(BatchView bv, int only_
     const int npairs = (np + 1) / 2;                    // odd npair: the middle row has a block to itself
     const int stride = gridDim.x * NW;
     int t = blockIdx.x * NW + wave;
+    const int* __restrict__ shell_row = bv.eri_tri_sb + npairs;
+    int chunks_read = 0;          // wave-uniform: chunks of 128 doubles this wave asked HBM for
     auto load_block = [&](int tt) {
         const double* __restrict__ src = T + (size_t)tt * pb;
+        // chunks that hold nothing but rows known to be zero are not read
+        const int rln = np - 1 - tt;
+        const bool zln = __builtin_amdgcn_readfirstlane((int)rz[rln]) != 0;
+        const bool zsn = (tt < rln) ? (__builtin_amdgcn_readfirstlane((int)rz[tt]) != 0) : true;
+        const int iln = __builtin_amdgcn_readfirstlane(shell_row[rln]), isn = __builtin_amdgcn_readfirstlane(shell_row[tt]);
+        const int sbn = (iln + 1) * (iln + 2) / 2, sen = (tt < rln) ? sbn + (isn + 1) * (isn + 2) / 2 : sbn;
+        // first and one-past-last chunk to read (wave-uniform, scalar): [0, ceil(sb / 128)) for the long row, [sb / 128,
+        // ceil(se / 128)) for the short one; the union is one interval because the short row starts where the long ends
+        int c0 = zln ? sbn >> 7 : 0, c1 = zsn ? (sbn + 127) >> 7 : (sen + 127) >> 7;
+        if (zln && zsn) { c0 = 0; c1 = 0; }
+        c0 = __builtin_amdgcn_readfirstlane(c0); c1 = __builtin_amdgcn_readfirstlane(c1);
+        chunks_read += (c1 < MAXU2 ? c1 : MAXU2) - c0;
+        const double* __restrict__ srcl = src + 2 * lane;
 #pragma unroll
         for (int u = 0; u < MAXU2; ++u) {
-            const int idx = 2 * lane + 128 * u;
-            v2[u] = idx < pb ? *(const double2v*)(src + idx) : (double2v){0.0, 0.0};
+            if (u >= c0 && u < c1) {          // scalar branch (kept one by the empty asm: as a select the load needs a second register set)
+                asm volatile("" ::: "memory");
+                v2[u] = (2 * lane + 128 * u < pb) ? *(const double2v*)(srcl + 128 * u) : (double2v){0.0, 0.0};
+            } else {
+                v2[u] = (double2v){0.0, 0.0};
+            }
         }
     };
     if (t < npairs) load_block(t);
     while (t < npairs) {
         const int rl = np - 1 - t;
         const bool two = t < rl;                        // the block holds a short row too
+        const bool zl = __builtin_amdgcn_readfirstlane((int)rz[rl]) != 0;
+        const bool zs = two ? (__builtin_amdgcn_readfirstlane((int)rz[t]) != 0) : true;
         // shell rows of the two pair rows from the table behind eri_tri_sb (uniform addresses: scalar loads)
-        const int* __restrict__ shell_row = bv.eri_tri_sb + npairs;
         const int il = __builtin_amdgcn_readfirstlane(shell_row[rl]), jl = rl - il * (il + 1) / 2;
         const int is = two ? __builtin_amdgcn_readfirstlane(shell_row[t]) : 0, js = t - is * (is + 1) / 2;
         const int sb = (il + 1) * (il + 2) / 2;         // = eri_tri_sb[t]: the short row starts behind the padded long one
         const int se = two ? sb + (is + 1) * (is + 2) / 2 : sb;   // end of the padded short row
         const double dpl = Dp[rl], dps = Dp[t];
         double accl = 0.0, accs = 0.0;
+        // a block whose rows are both known to be zero was not loaded and is not staged (its registers hold zeros)
+        if (!(zl && zs))
 #pragma unroll
         for (int u = 0; u < MAXU2; ++u) {
             const int base = 128 * u, idx = 2 * lane + base;   // the cases below are wave-uniform
@@ -574,14 +633,16 @@ __global__ void __launch_bounds__(64 * NW) jk_tri_kernel(BatchView bv, int only_
         if (nt < npairs) load_block(nt);
         accl = wave_sum(accl);
         accs = wave_sum(accs);
-        if (lane == 0) { atomicAdd(&Jl[rl], accl); if (two) atomicAdd(&Jl[t], accs); }
+        if (lane == 0) { if (!zl) atomicAdd(&Jl[rl], accl); if (!zs) atomicAdd(&Jl[t], accs); }
         double ai, aj;
-        row_exchange_tri(rowbuf, Dg + il * n, Dg + jl * n, il, lane, ai, aj);
-        if (lane <= il) {
-            atomicAdd(&Kl[il * n + lane], ai);
-            if (il != jl) atomicAdd(&Kl[jl * n + lane], aj);
+        if (!zl) {
+            row_exchange_tri(rowbuf, Dg + il * n, Dg + jl * n, il, lane, ai, aj);
+            if (lane <= il) {
+                atomicAdd(&Kl[il * n + lane], ai);
+                if (il != jl) atomicAdd(&Kl[jl * n + lane], aj);
+            }
         }
-        if (two) {
+        if (!zs) {
             row_exchange_tri(rowbuf + sb, Dg + is * n, Dg + js * n, is, lane, ai, aj);
             if (lane <= is) {
                 atomicAdd(&Kl[is * n + lane], ai);
@@ -596,7 +657,12 @@ __global__ void __launch_bounds__(64 * NW) jk_tri_kernel(BatchView bv, int only_
         if (idx < np && jsc2[u][0] != 0.0) atomicAdd(&Jl[idx], jsc2[u][0]);
         if (idx + 1 < np && jsc2[u][1] != 0.0) atomicAdd(&Jl[idx + 1], jsc2[u][1]);
     }
+    if (lane == 0 && chunks_read > 0) atomicAdd((int*)&ao2sh[0], chunks_read);      // ao2sh is done with: slot 0 becomes the workgroup's count
     __syncthreads();
+    if (tid == 0 && bv.jk_loaded) {
+        if (gridDim.x == 1) bv.jk_loaded[f] = ao2sh[0];
+        else atomicAdd(&bv.jk_loaded[f], ao2sh[0]);
+    }
     if (gridDim.x == 1) {
         // one workgroup per fragment (large batches): J and K = Kh + Kh^T are complete here -- plain stores, and the
         // launcher zeroes nothing
@@ -653,7 +719,11 @@ int jk_tri_block(int np, std::vector<int>* short_row_start)
 }
 
 constexpr int JK_TRI_NW = 12, JK_TRI_MAXU2 = 10;
-static size_t jk_tri_lds_bytes(int n, int np) { return sizeof(double) * ((size_t)JK_TRI_NW * jk_tri_block(np) + 2 * ((size_t)np + 2) + (size_t)n * n); }
+static size_t jk_tri_lds_bytes(int n, int np)
+{
+    // row buffers, packed D' and J (+ 2), Kh; zero-row flags, function -> shell map, per-wave maxima
+    return sizeof(double) * ((size_t)JK_TRI_NW * jk_tri_block(np) + 2 * ((size_t)np + 2) + (size_t)n * n) + (((size_t)np + 15) & ~(size_t)15) + 64 * sizeof(int) + JK_TRI_NW * sizeof(double);
+}
 
 // The triangular layout is taken for the batches the tuned square kernel served: restricted, dimer-sized fragments
 // (n <= 64, a multiple of 8; 640 < npair; a block within ten chunks of 128) in batches of at least 64.
@@ -707,6 +777,7 @@ void launch_jk_incore(const BatchView& bv, bool only_active, hipStream_t s)
         const int maxx = ((np + 1) / 2 + JK_TRI_NW - 1) / JK_TRI_NW;
         if (gx < 1) gx = 1;
         if (gx > maxx) gx = maxx;
+        if (gx > 1 && bv.jk_loaded) (void)hipMemsetAsync(bv.jk_loaded, 0, sizeof(int) * (size_t)bv.nfrag, s);
         if (gx > 1) {
             // several workgroups add into J and K (atomics): both start from zero
             (void)hipMemsetAsync(bv.K, 0, sizeof(double) * (size_t)bv.nfrag * n * n, s);
