@@ -238,6 +238,11 @@ struct EriSlotState {
     std::vector<int> bucket1[KERNEL_LMAX + 1][KERNEL_LMAX + 1];  // ... pairs whose two shells sit on ONE atom (see launch_eri_bounds)
     std::vector<int> same_atom;                                  // all of them, for the copy to the other fragments
     int* d_same = nullptr; int n_same = 0;
+    // one-centre bounds depend on the basis only: kept per topology across calls (q1_vals[ns][ns], valid for q1_key)
+    std::string q1_key;
+    DevicePool q1pool;
+    double* q1_vals = nullptr;
+    bool q1_cached = false, q1_save = false;
     DevicePool qpool, pairs;
     hipStream_t side[ERI_SIDE_MAX] = {};
     hipEvent_t fork = nullptr, join[ERI_SIDE_MAX] = {};
@@ -276,7 +281,7 @@ void eri_reset_state()
             g_preset_side[sl][k] = nullptr;
         }
         for (auto& c : st.cache) { c.valid = false; c.key = 0; c.host.clear(); c.launches.clear(); }
-        st.bounds_pending = false; st.Q = nullptr; st.next = 0;
+        st.bounds_pending = false; st.Q = nullptr; st.next = 0; st.q1_key.clear(); st.q1_vals = nullptr;
     }
 }
 
@@ -330,34 +335,52 @@ void launch_eri_bounds(const BatchView& bv, const Topology& topo, double schwarz
     size_t off = 0;
     int rr = 0;
     double* Q = st.Q;
-    // the zero fill first, on the last stream: with the one-centre bounds out of the way it is the longest item here
-    // (22 GB for 2016 dimers, 5 ms) and the class kernels wait for it
+    // the zero fill first, on the last stream, which it keeps to itself when there are streams to spare: with the
+    // one-centre bounds out of the way it is the longest item here (12 GB for 2016 dimers, 2.8 ms), the class kernels wait
+    // for it, and a bound launch queued behind it made them wait for both
     if (bv.eri) (void)hipMemsetAsync(bv.eri, 0, sizeof(double) * bv.eri_stride * bv.nfrag, st.side[ERI_SIDE_STREAMS - 1]);
+    const int nb_streams = (bv.eri && ERI_SIDE_STREAMS >= 4) ? ERI_SIDE_STREAMS - 1 : ERI_SIDE_STREAMS;
     // most expensive class first
 #define SCHWARZ_CASE(a, b)                                                                                                      \
-    launch_schwarz_class<a, b>(bv, st.bucket[a][b].data(), (int)st.bucket[a][b].size() / 2, d_pairs + off, Q, st.side[rr++ % ERI_SIDE_STREAMS]); \
+    launch_schwarz_class<a, b>(bv, st.bucket[a][b].data(), (int)st.bucket[a][b].size() / 2, d_pairs + off, Q, st.side[rr++ % nb_streams]); \
     off += st.bucket[a][b].size();
     SCHWARZ_CASE(0, 0) SCHWARZ_CASE(2, 1) SCHWARZ_CASE(1, 1)
     SCHWARZ_CASE(1, 0) SCHWARZ_CASE(2, 0)
 #undef SCHWARZ_CASE
     st.n_same = 0;
+    st.q1_cached = false; st.q1_save = false;
     if (!st.same_atom.empty()) {
+        const size_t nsq = topo.shells.size() * topo.shells.size();
+        st.q1_cached = st.q1_vals != nullptr && st.q1_key == topo.key;
+        if (!st.q1_cached) {
+            st.q1_vals = (double*)st.q1pool.ensure(sizeof(double) * nsq);
+            st.q1_key.clear();
+            st.q1_save = st.q1_vals != nullptr;
+        }
+    }
+    if (!st.same_atom.empty() && st.q1_cached) {
+        // the numbers are there from an earlier call with this topology: only the pair list goes up (launch_eri copies)
+        st.d_same = d_pairs + off;
+        st.n_same = (int)st.same_atom.size() / 2;
+        (void)hipMemcpyAsync(st.d_same, st.same_atom.data(), st.same_atom.size() * sizeof(int), hipMemcpyHostToDevice, st.side[rr++ % nb_streams]);
+        off += st.same_atom.size();
+    } else if (!st.same_atom.empty()) {
         BatchView b1 = bv;
         b1.nfrag = 1;
 #define SCHWARZ_ONE(a, b)                                                                                                       \
-    launch_schwarz_class<a, b>(b1, st.bucket1[a][b].data(), (int)st.bucket1[a][b].size() / 2, d_pairs + off, Q, st.side[rr++ % ERI_SIDE_STREAMS]); \
+    launch_schwarz_class<a, b>(b1, st.bucket1[a][b].data(), (int)st.bucket1[a][b].size() / 2, d_pairs + off, Q, st.side[rr++ % nb_streams]); \
     off += st.bucket1[a][b].size();
         SCHWARZ_ONE(0, 0) SCHWARZ_ONE(1, 1) SCHWARZ_ONE(1, 0) SCHWARZ_ONE(2, 1) SCHWARZ_ONE(2, 0)
 #undef SCHWARZ_ONE
         if (!st.bucket1[2][2].empty()) {
-            hipStream_t ss = st.side[rr++ % ERI_SIDE_STREAMS];
+            hipStream_t ss = st.side[rr++ % nb_streams];
             (void)hipMemcpyAsync(d_pairs + off, st.bucket1[2][2].data(), st.bucket1[2][2].size() * sizeof(int), hipMemcpyHostToDevice, ss);
             launch_schwarz_general(b1, 2, 2, d_pairs + off, (int)st.bucket1[2][2].size() / 2, Q, ss);
             off += st.bucket1[2][2].size();
         }
         st.d_same = d_pairs + off;
         st.n_same = (int)st.same_atom.size() / 2;
-        (void)hipMemcpyAsync(st.d_same, st.same_atom.data(), st.same_atom.size() * sizeof(int), hipMemcpyHostToDevice, st.side[rr++ % ERI_SIDE_STREAMS]);
+        (void)hipMemcpyAsync(st.d_same, st.same_atom.data(), st.same_atom.size() * sizeof(int), hipMemcpyHostToDevice, st.side[rr++ % nb_streams]);
         off += st.same_atom.size();
     }
     // (dd| bounds (the pass kernel carries 11.5 KB of scratch per lane) and the f classes: LDS kernel
@@ -365,7 +388,7 @@ void launch_eri_bounds(const BatchView& bv, const Topology& topo, double schwarz
         for (int b = (a == CLASS_LMAX ? CLASS_LMAX : 0); b <= a; ++b) {
             auto& bk = st.bucket[a][b];
             if (bk.empty()) continue;
-            hipStream_t ss = st.side[rr++ % ERI_SIDE_STREAMS];
+            hipStream_t ss = st.side[rr++ % nb_streams];
             (void)hipMemcpyAsync(d_pairs + off, bk.data(), bk.size() * sizeof(int), hipMemcpyHostToDevice, ss);
             launch_schwarz_general(bv, a, b, d_pairs + off, (int)bk.size() / 2, Q, ss);
             off += bk.size();
@@ -477,16 +500,28 @@ void eri_plan_lists(const BatchView& bv, const Topology& topo, hipStream_t s, co
 }
 
 // bounds of one-centre pairs, formed for fragment 0 (launch_eri_bounds), to the other fragments
-__global__ void schwarz_copy_kernel(double* __restrict__ Q, const int* __restrict__ pairs, int npairs, int nfrag, int ns)
+// src: [ns][ns] holding the one-centre values (fragment 0's block of Q, or the per-topology cache); fragments f0 .. nfrag-1
+__global__ void schwarz_copy_kernel(double* __restrict__ Q, const double* __restrict__ src, const int* __restrict__ pairs, int npairs,
+                                    int f0, int nfrag, int ns)
 {
+    const int nf = nfrag - f0;
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= (long)npairs * (nfrag - 1)) return;
-    const int ip = (int)(tid / (nfrag - 1)), f = 1 + (int)(tid % (nfrag - 1));
+    if (tid >= (long)npairs * nf) return;
+    const int ip = (int)(tid / nf), f = f0 + (int)(tid % nf);
     const int A = pairs[2 * ip], B = pairs[2 * ip + 1];
-    const double v = Q[A * ns + B];
+    const double v = src[A * ns + B];
     double* q = Q + (size_t)f * ns * ns;
     q[A * ns + B] = v;
     q[B * ns + A] = v;
+}
+// the one-centre values just formed for fragment 0 into the per-topology cache
+__global__ void schwarz_save_kernel(const double* __restrict__ Q, double* __restrict__ dst, const int* __restrict__ pairs, int npairs, int ns)
+{
+    const int ip = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ip >= npairs) return;
+    const int A = pairs[2 * ip], B = pairs[2 * ip + 1];
+    dst[A * ns + B] = Q[A * ns + B];
+    dst[B * ns + A] = Q[A * ns + B];
 }
 
 void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, hipStream_t s, const double* host_xyz)
@@ -503,9 +538,18 @@ void launch_eri(const BatchView& bv, const Topology& topo, double schwarz_tol, h
         st.bounds_pending = false;
         Q = st.Q;
         thresh = schwarz_tol;
-        if (st.n_same > 0 && bv.nfrag > 1) {
-            const long total = (long)st.n_same * (bv.nfrag - 1);
-            hipLaunchKernelGGL(schwarz_copy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, Q, st.d_same, st.n_same, bv.nfrag, (int)topo.shells.size());
+        if (st.n_same > 0) {
+            const int ns = (int)topo.shells.size();
+            if (st.q1_save) {
+                hipLaunchKernelGGL(schwarz_save_kernel, dim3((unsigned)((st.n_same + 255) / 256)), dim3(256), 0, s, Q, st.q1_vals, st.d_same, st.n_same, ns);
+                st.q1_key = topo.key;
+                st.q1_save = false;
+            }
+            const int f0 = st.q1_cached ? 0 : 1;
+            const long total = (long)st.n_same * (bv.nfrag - f0);
+            if (total > 0)
+                hipLaunchKernelGGL(schwarz_copy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, Q,
+                                   st.q1_cached ? (const double*)st.q1_vals : (const double*)Q, st.d_same, st.n_same, f0, bv.nfrag, ns);
             st.n_same = 0;
         }
     }
