@@ -19,8 +19,11 @@ list / block-sharing plan, fragment layouts) can be reused; the energy is invari
 reports as `rigid_motion_energy_spread`.  `cold_ms` is the very first evaluation of the process (term-list generation,
 topology build, pool allocation, kernel loading included): the one-shot cost of an MBE-2 energy.
 
-Multi-GPU: fragments are independent, so ranks take a static round-robin share of the cost-sorted term list; the
-TOTAL work is fixed -> "strong".  No collective sits on the data path.
+Multi-GPU: fragments are independent units -- no collective sits on the data path.  Default (`--scaling weak`): per-GPU work
+is fixed, every rank evaluates the 2080 SCFs of its own copy of the cluster (its own rigid motion; all copies have the
+same MBE-2 energy, which the line checks) and `value` is the iterations of all ranks over the slowest rank's time.
+`--scaling strong`: the ONE cluster's cost-sorted term list round-robin over the ranks, one all-reduce of the zero-padded
+energy vector -- total work fixed; at 2080 fragments that regime is latency-bound.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     -- the dominant kernel of THIS run (J/K stream, integral stage, XC quadrature or SCF step, whichever
@@ -61,6 +64,9 @@ def parse_args():
     ap.add_argument("--functional", default="", help="empty = RHF (configs[2]); e.g. b3lyp")
     ap.add_argument("--df", action="store_true", help="density-fitted J/K with the repo's even-tempered auxiliary set")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for CPU rehearsal)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: weak = every rank evaluates the MBE-2 of its own copy of the cluster (per-GPU work fixed); "
+                         "strong = the ONE cluster's term list round-robin over the ranks (total work fixed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-dimers-per-core", type=int, default=2, help="CPU-baseline sample: dimers per host core")
     ap.add_argument("--cpu-procs", type=int, default=0, help="CPU-baseline worker processes (0 = the cores this process may use, at most 32)")
@@ -171,6 +177,8 @@ def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MQC_BENCH_DEVICE"):          # rehearsal on a one-GPU box: all ranks on one device (with --backend gloo)
+        local_rank = int(os.environ["MQC_BENCH_DEVICE"])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     torch = None
@@ -197,11 +205,32 @@ def main():
             if use_cuda_tensors:
                 torch.cuda.synchronize()
 
+    weak = args.scaling == "weak"
+    rank_totals = []          # weak scaling: every rank's MBE-2 energy of every evaluation (one cluster, moved differently)
+
     def evaluate(system, st, terms):
-        run = mbe.run_mbe(system, st, level=2, rank=rank, world=world, terms=terms)
+        if weak:
+            # per-GPU work fixed: this rank evaluates ALL terms of its own copy of the cluster -- the units are independent
+            # fragments, nothing crosses between the GPUs on the data path
+            run = mbe.run_mbe(system, st, level=2, rank=0, world=1, terms=terms)
+        else:
+            run = mbe.run_mbe(system, st, level=2, rank=rank, world=world, terms=terms)
         if run.errors:
             raise RuntimeError("fragment failed: " + run.errors[0])
         energies, iters = run.energies, run.iterations.astype(np.float64)
+        if world > 1 and weak:
+            total, by_order, _ = mbe.compute_mbe(terms, energies)
+            # the only inter-GPU traffic: every rank's iteration count and MBE-2 energy, gathered
+            mine = torch.tensor([float(np.sum(iters)), float(total)], dtype=torch.float64)
+            if use_cuda_tensors:
+                mine = mine.cuda()
+            gathered = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(gathered, mine)
+            if use_cuda_tensors:
+                torch.cuda.synchronize()
+            both = np.array([g.cpu().numpy() for g in gathered])
+            rank_totals.extend(float(x) for x in both[:, 1])
+            return float(both[0, 1]), energies, float(np.sum(both[:, 0]))
         if world > 1:
             # the only inter-GPU traffic: one all-reduce of the zero-padded per-fragment vectors
             buf = torch.from_numpy(np.concatenate([energies, iters]))
@@ -216,7 +245,9 @@ def main():
         return total, energies, float(np.sum(iters))
 
     def moved(step):
-        return system0 if args.fixed_geometry else rigid_motion(system0, step)
+        if args.fixed_geometry:
+            return system0
+        return rigid_motion(system0, step + (100003 * rank if (weak and world > 1) else 0))
 
     # ---- the cold evaluation: first call of the process, unmoved cluster, term list generated inside
     barrier()
@@ -239,6 +270,7 @@ def main():
         tot_iters += it
     barrier()
     elapsed = time.perf_counter() - t0
+    main_totals = list(rank_totals)       # cold, warm-up and timed evaluations of the headline method on every rank
     st = methods.get_stats()
     if world > 1:
         tmax = torch.tensor([elapsed, cold_s], dtype=torch.float64)
@@ -386,7 +418,7 @@ def main():
             n_d = 2 * int(build_flat_basis(args.basis, [8, 1, 1]).nao)
             npd = n_d * (n_d + 1) // 2
             n_dimers = len(terms) - system0.n_monomers
-            per_frag = big_b / big_n / max(n_dimers // world, 1) / 8.0
+            per_frag = big_b / big_n / max(n_dimers if weak else n_dimers // world, 1) / 8.0
             if per_frag < 0.75 * npd * npd:
                 jk_name = "jk_tri_kernel"
                 jk_layout = ("lower triangle of the pair matrix in blocks of row pairs (zero-padded to whole shell rows); the kernel skips pair rows "
@@ -438,7 +470,8 @@ def main():
                     "avg_launch_ms": (1e3 * jk_secs / jk_launches) if jk_launches else None}
         roof["dominant_stage"] = dominant
         roof["stages"] = stages
-        spread = float(np.max(np.abs(np.array(e_steps + [e_cold]) - e_cold))) if e_steps else None
+        spread = float(np.max(np.abs(np.array(e_steps + main_totals + [e_cold]) - e_cold))) if e_steps else None
+        jobs = world if weak else 1
         line = {
             "metric": "SCF iterations/s (whole job); MBE-2 wall time @64 fragments",
             "value": tot_iters / elapsed,
@@ -448,7 +481,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / n_steps,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -459,7 +492,10 @@ def main():
                                       len(terms), system0.n_monomers, len(terms) - system0.n_monomers, args.energy_tol, args.density_tol,
                                       ", grid level 3 (pruned)" if args.functional else "",
                                       "bit-identical geometry every step" if args.fixed_geometry else "fresh rigid motion of the cluster every step"),
-                       "fragments": len(terms), "parallelism": "fragments round-robin over %d GPU(s)" % world},
+                       "fragments": len(terms) * jobs,
+                       "parallelism": ("one MBE-2 job of %d independent SCFs per GPU, %d GPU(s): every rank its own rigid motion of the cluster, "
+                                       "no data-path collective (one all-gather of two numbers per evaluation)" % (len(terms), world)) if weak
+                                      else "fragments round-robin over %d GPU(s)" % world},
             "mbe2_wall_s": elapsed / n_steps,
             "cold_ms": 1e3 * cold_s,
             "mbe2_energy_hartree": e_cold,
