@@ -311,7 +311,7 @@ def main():
     # the same cluster (one warm-up + one timed evaluation each, moved geometry), and the literal drop-in: ONE fragment
     # per mqc_hip_scf_run call, as an unchanged do_fragment_work would drive the engine
     secondary = None
-    if not args.no_secondary and not args.functional and not args.df:
+    if not args.no_secondary and not args.functional and not args.df and world == 1:     # single-GPU measurements: the N = 1 line carries them
         secondary = {}
         for label, kw in (("rhf_density_fitted", dict(density_fitting=True)),
                           ("b3lyp_density_fitted", dict(functional="b3lyp", density_fitting=True))):
