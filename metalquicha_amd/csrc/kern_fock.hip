@@ -436,14 +436,26 @@ __device__ __forceinline__ void row_exchange_tri(const double* __restrict__ buf,
     acc_i = 0.0; acc_j = 0.0;
     const int kk = lane <= i ? lane : i;          // lanes beyond the triangle read lane i's elements and are dropped at the flush
     const int trik = kk * (kk + 1) / 2;
-    // full blocks of eight l: no clamps, one scalar add per l (tri(l + 1) = tri(l) + l + 1), as in row_exchange
+    // full blocks of eight l: no clamps, one scalar add per l (tri(l + 1) = tri(l) + l + 1), as in row_exchange.
+    // Element (k, l) of the packed triangle sits at tri(max) + min = max(tri(k) + l, tri(l) + k) -- the form that is not
+    // the valid one is the smaller of the two, (k - l)(k + l + 1) / 2 >= k - l -- so the index needs no compare and
+    // select; with u taken out of both forms the read is [max(tri(k) + l0, tri(l) + k - u)] + u, u in the instruction's
+    // offset field: two integer instructions per element instead of five (the loop is bound by instruction issue)
+    // (all of it in LDS byte addresses, so that no shift is left either)
+    typedef const double __attribute__((address_space(3))) * lds_cptr;
+    const unsigned base = (unsigned)(size_t)(lds_cptr)buf;
+    unsigned rowbase = base + 8u * (unsigned)trik, colbase = base + 8u * (unsigned)kk;
+    asm volatile("" : "+v"(rowbase), "+v"(colbase));      // opaque: otherwise the compiler re-associates the shift back into the loop
     int l0 = 0, lbase = 0;
     for (; l0 + 8 <= i + 1; l0 += 8) {             // i is wave-uniform; n is a multiple of 8, so l0 + 8 <= n
         double v[8];
+        const unsigned rowaddr = rowbase + 8u * (unsigned)l0;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int l = l0 + u;
-            v[u] = buf[kk >= l ? trik + l : lbase + kk];
+            const unsigned coladdr = colbase + 8u * (unsigned)(lbase - u);
+            const unsigned sel = rowaddr > coladdr ? rowaddr : coladdr;
+            v[u] = *(lds_cptr)(size_t)(sel + 8u * (unsigned)u);
             lbase += l + 1;
         }
         const double8 a = *(scalar_ptr8)(Di + l0), b = *(scalar_ptr8)(Dj + l0);
@@ -460,8 +472,8 @@ __device__ __forceinline__ void row_exchange_tri(const double* __restrict__ buf,
             // scalar on purpose (readfirstlane): otherwise the compiler builds the two index forms under exec masks
             const int l = __builtin_amdgcn_readfirstlane((l0 + u <= i) ? l0 + u : i);
             const int lb = __builtin_amdgcn_readfirstlane(l * (l + 1) / 2);
-            const int ia = trik + l, ib = lb + kk;
-            v[u] = buf[kk >= l ? ia : ib];
+            const unsigned ra = rowbase + 8u * (unsigned)l, ca = colbase + 8u * (unsigned)lb;
+            v[u] = *(lds_cptr)(size_t)(ra > ca ? ra : ca);
         }
         const double8 a = *(scalar_ptr8)(Di + l0), b = *(scalar_ptr8)(Dj + l0);
 #pragma unroll
