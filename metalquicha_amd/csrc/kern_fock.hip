@@ -84,7 +84,8 @@ __device__ __forceinline__ void row_exchange(const double* __restrict__ rowbuf, 
                 const int l = l0 + u;
 #pragma unroll
                 for (int c = 0; c < KCH; ++c) {
-                    const int idx = kk[c] >= l ? tri[c] + l : lbase + kk[c];
+                    const int ia = tri[c] + l, ib = lbase + kk[c];
+                    const int idx = ia > ib ? ia : ib;      // tri(max) + min is the larger of the two forms (see row_exchange_tri)
                     v[u][c] = rowbuf[idx];
                 }
                 lbase += l + 1;
@@ -96,7 +97,8 @@ __device__ __forceinline__ void row_exchange(const double* __restrict__ rowbuf, 
                 const int lbase = l * (l + 1) / 2;                  // uniform
 #pragma unroll
                 for (int c = 0; c < KCH; ++c) {
-                    const int idx = kk[c] >= l ? tri[c] + l : lbase + kk[c];
+                    const int ia = tri[c] + l, ib = lbase + kk[c];
+                    const int idx = ia > ib ? ia : ib;      // tri(max) + min is the larger of the two forms (see row_exchange_tri)
                     v[u][c] = rowbuf[idx];
                 }
             }
@@ -388,7 +390,8 @@ __global__ void __launch_bounds__(JKC_NT) jk_rowcoop_kernel(BatchView bv, int on
                     const double dil = live ? ((scalar_ptr)Di)[l] : 0.0, djl = live ? ((scalar_ptr)Dj)[l] : 0.0;
 #pragma unroll
                     for (int c = 0; c < KCH; ++c) {
-                        const double v = buf[kk[c] >= l ? tri[c] + l : lbase + kk[c]];
+                        const int ia = tri[c] + l, ib = lbase + kk[c];
+                        const double v = buf[ia > ib ? ia : ib];      // tri(max) + min is the larger of the two forms
                         acc_i[c] += v * djl;
                         acc_j[c] += v * dil;
                     }
