@@ -35,6 +35,27 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// Wave sum through the DPP lane network: quad swaps, half-row and row mirrors, then the two row broadcasts -- 18 VALU
+// instructions and no LDS round trip (a shuffle is two ds_bpermute_b32 per step and a wait for each).  The total is
+// valid in lanes 48..63 only.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_take(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_top(double v)
+{
+    v += dpp_take<0xB1, 0xf>(v);        // quad_perm [1, 0, 3, 2]
+    v += dpp_take<0x4E, 0xf>(v);        // quad_perm [2, 3, 0, 1]
+    v += dpp_take<0x141, 0xf>(v);       // row_half_mirror
+    v += dpp_take<0x140, 0xf>(v);       // row_mirror: every lane of a row of 16 holds the row's sum
+    v += dpp_take<0x142, 0xa>(v);       // row_bcast15 into rows 1 and 3
+    v += dpp_take<0x143, 0xc>(v);       // row_bcast31 into rows 2 and 3: row 3 holds the wave's sum
+    return v;
+}
+
 __device__ __forceinline__ void unpack_pair(int idx, int& k, int& l)
 {
     k = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
@@ -646,9 +667,9 @@ __global__ void __launch_bounds__(64 * NW) jk_tri_kernel(BatchView bv, int only_
         // the next block's loads go out now and complete while this one is contracted
         const int nt = t + stride;
         if (nt < npairs) load_block(nt);
-        accl = wave_sum(accl);
-        accs = wave_sum(accs);
-        if (lane == 0) { if (!zl) atomicAdd(&Jl[rl], accl); if (!zs) atomicAdd(&Jl[t], accs); }
+        accl = wave_sum_top(accl);
+        accs = wave_sum_top(accs);
+        if (lane == 63) { if (!zl) atomicAdd(&Jl[rl], accl); if (!zs) atomicAdd(&Jl[t], accs); }
         double ai, aj;
         if (!zl) {
             row_exchange_tri(rowbuf, Dg + il * n, Dg + jl * n, il, lane, ai, aj);
